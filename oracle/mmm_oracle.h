@@ -1,0 +1,142 @@
+/*
+ * mmm_oracle.h -- CPU ORACLE for the variational-EM hot path of MultiModalMuSig.jl.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference's Julia algorithm
+ * (src/LDA.jl, src/MMCTM.jl, src/IMMCTM.jl, src/common.jl) plus a restatement of the two third-party
+ * pieces the reference calls but does not vendor (NLopt `LD_MMA`, SpecialFunctions `digamma`).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (multimodalmusig.jl_amd/, libmmmusig_hip.so) never links, imports or calls anything in here.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - closed-form updates (phi/gamma/lambda of LDA; zeta/theta/mu/Sigma/gamma/Elnphi/loglik of MMCTM
+ *     and IMMCTM; the lambda/nu objectives and gradients): PINNED by the reference's own known-answer
+ *     tests (test/lda.jl, test/mmctm.jl, test/immctm.jl, test/common.jl) -> tests/golden/ (JSON).
+ *   - MMA optimiser outputs (lambda, nu after update_λ!/update_ν!), full fit! trajectories and every
+ *     ELBO value: "PARITY UNPINNED" -- the reference's tests assert only qualitative facts there and the
+ *     Julia reference + libnlopt cannot be executed in the build container (no julia, no NLopt).
+ *
+ * Layout conventions (shared with include/mmmusig.h):
+ *   all reals are double, term indices are 0-based int32, counts int32, CSR offsets int64.
+ *   LDA:    lambda/Elnbeta/beta  V x K column-major  -> [v + V*k]
+ *           gamma/Elntheta/theta K x D column-major  -> [k + K*d]
+ *           phi                  per doc K x W_d (k fastest), docs concatenated -> [K*doc_ptr[d] + k + K*w]
+ *   MMCTM:  doc_ptr              M*(D+1) absolute offsets into term/count (modality-major concatenation)
+ *           lambda/nu/props      MK x D -> [i + MK*d];  zeta M x D -> [m + M*d]
+ *           gamma/Elnphi/phi     [goff[m] + k*V[m] + v],  goff[m] = sum_{m'<m} K[m']*V[m']
+ *           theta                [toff[m] + (e - doc_ptr[m*(D+1)])*K[m] + k] for absolute entry e of
+ *                                modality m, toff[m] = sum_{m'<m} nnz[m']*K[m']
+ *           mu MK; Sigma/invSigma MK x MK column-major
+ *   IMMCTM: features             [foff[m] + i*V[m] + v] (0-based values), foff[m] = sum_{m'<m} I[m']*V[m']
+ *           gamma/Elnphi         [goff[m] + k*SJ[m] + joff[m][i] + j], SJ[m] = sum_i J[m][i],
+ *                                goff[m] = sum_{m'<m} K[m']*SJ[m'];  alpha [aoff[m] + i], aoff = sum I
+ */
+#ifndef MMM_ORACLE_H
+#define MMM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar math ---------------------------------------------------------------------------- */
+double orc_digamma(double x);                 /* SpecialFunctions.jl digamma algorithm           */
+double orc_lgamma(double x);                  /* logabsgamma(x)[1]                                */
+void   orc_digamma_vec(int n, const double* x, double* out);
+double orc_logmvbeta(int n, const double* vals);        /* common.jl:1-9 */
+
+/* ---- NLopt LD_MMA (m = 0 constraints) restatement ---------------------------------------------- */
+typedef double (*orc_objective)(int n, const double* x, double* grad, void* data);
+/* xtol_rule: 0 = NLopt >= 2.7 (L1 norm rule), 1 = NLopt <= 2.6 (per-coordinate rule).
+ * minimises f. lb/ub may be NULL (= -inf/+inf). Returns number of objective evaluations (>0) or
+ * -1 when the evaluation cap was hit. x is overwritten with the best accepted point. */
+int orc_mma_minimize(int n, orc_objective f, void* data, const double* lb, const double* ub,
+                     double* x, double* minf, double xtol_rel, double xtol_abs, int xtol_rule,
+                     int max_eval, int* n_outer);
+
+/* common.jl:11-23 / 25-36 -- value returned, gradient written when grad != NULL (objective is MAXIMISED) */
+double orc_lambda_objective(int n, const double* lambda, double* grad, const double* nu,
+                            const double* Ndivzeta, const double* sumtheta, const double* mu,
+                            const double* invSigma);
+double orc_nu_objective(int n, const double* nu, double* grad, const double* lambda,
+                        const double* Ndivzeta, const double* mu, const double* invSigma);
+
+/* ---- LDA (src/LDA.jl) -------------------------------------------------------------------------- */
+void orc_lda_update_Elntheta(int K, int D, const double* gamma, double* Elntheta);
+void orc_lda_update_gamma(int K, int D, double alpha, const int64_t* doc_ptr, const int32_t* count,
+                          const double* phi, double* gamma, double* Elntheta);
+void orc_lda_update_phi(int K, int D, int V, const int64_t* doc_ptr, const int32_t* term,
+                        const double* Elntheta, const double* Elnbeta, double* phi);
+void orc_lda_update_Elnbeta(int V, int K, const double* lambda, double* Elnbeta);
+void orc_lda_update_lambda(int K, int D, int V, double eta, const int64_t* doc_ptr,
+                           const int32_t* term, const int32_t* count, const double* phi,
+                           double* lambda, double* Elnbeta);
+void orc_lda_update_beta(int V, int K, const double* lambda, double* beta);
+void orc_lda_update_theta(int K, int D, const double* gamma, double* theta);
+double orc_lda_loglik(int K, int D, int V, const int64_t* doc_ptr, const int32_t* term,
+                      const int32_t* count, const double* theta, const double* beta);
+/* terms[7] = ElnPbeta, ElnPtheta, ElnPZ, ElnPX, ElnQbeta, ElnQtheta, ElnQZ; returns the ELBO */
+double orc_lda_elbo(int K, int D, int V, double alpha, double eta, const int64_t* doc_ptr,
+                    const int32_t* term, const int32_t* count, const double* lambda,
+                    const double* Elnbeta, const double* gamma, const double* Elntheta,
+                    const double* phi, double* terms);
+/* constructor (LDA.jl:24-54) + fit! (LDA.jl:198-224). lambda is in/out (lambda0 on entry). */
+int orc_lda_fit(int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr,
+                const int32_t* term, const int32_t* count, int maxiter, double tol,
+                double* lambda, double* gamma, double* Elntheta, double* theta, double* Elnbeta,
+                double* beta, double* phi, double* ll_hist, int* n_iter, int* converged,
+                double* elbo);
+
+/* ---- MMCTM / IMMCTM (src/MMCTM.jl, src/IMMCTM.jl) ------------------------------------------------ */
+typedef struct {
+    int D, M, MK;
+    const int* K;             /* M */
+    const int* V;             /* M */
+    const int64_t* doc_ptr;   /* M*(D+1) absolute */
+    const int32_t* term;
+    const int32_t* count;
+    /* independent-feature extension (IMMCTM); n_feat == NULL for plain MMCTM */
+    const int* n_feat;        /* I[m] */
+    const int* J;             /* concatenated J[m][i] */
+    const int32_t* features;  /* see header comment */
+    double* alpha;            /* MMCTM: M ; IMMCTM: sum_m I[m] */
+    /* globals */
+    double* mu; double* Sigma; double* invSigma;
+    double* gamma; double* Elnphi; double* phi;   /* phi unused (may be NULL) for IMMCTM */
+    /* per document */
+    double* lambda; double* nu; double* zeta; double* props; double* theta;
+    /* solver configuration (MMCTM.jl:127-130,156-160) */
+    double xtol_rel, xtol_abs, nu_lower; int xtol_rule; int max_eval;
+    /* statistics out */
+    int64_t n_eval_lambda, n_eval_nu, n_solver_cap;
+} orc_ctm;
+
+void orc_ctm_update_zeta(orc_ctm* m, int d);
+void orc_ctm_update_theta(orc_ctm* m, int d);
+void orc_ctm_update_nu(orc_ctm* m, int d);
+void orc_ctm_update_lambda(orc_ctm* m, int d);
+void orc_ctm_fitdoc(orc_ctm* m, int d);
+void orc_ctm_calc_sumtheta(const orc_ctm* m, int d, double* out);
+void orc_ctm_calc_Ndivzeta(const orc_ctm* m, int d, double* out);
+void orc_ctm_update_mu(orc_ctm* m);
+int  orc_ctm_update_Sigma(orc_ctm* m);
+void orc_ctm_update_Elnphi(orc_ctm* m);
+void orc_ctm_update_gamma(orc_ctm* m);
+void orc_ctm_update_props(orc_ctm* m);
+void orc_ctm_update_phi(orc_ctm* m);
+void orc_ctm_loglik(const orc_ctm* m, double* ll /* M */);
+double orc_ctm_elbo(const orc_ctm* m, double* terms /* 7 */);
+/* the E-step over a doc range (used by sharding tests) */
+void orc_ctm_estep_range(orc_ctm* m, int d0, int d1);
+/* fit!: MMCTM.jl:457-494 / IMMCTM.jl:437-466. State must be constructor-initialised by the caller
+ * via orc_ctm_init (lambda=0, nu=1, mu=0, Sigma=I, theta=1/K, Elnphi from gamma, zeta). */
+void orc_ctm_init(orc_ctm* m);
+int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
+                int* n_iter, int* converged, double* elbo);
+
+/* dense helper: inverse + log|det| of a column-major n x n matrix by LU with partial pivoting */
+int orc_inv_logdet(int n, const double* A, double* Ainv, double* logabsdet, int* sign);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
