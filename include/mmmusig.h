@@ -1,0 +1,165 @@
+/*
+ * mmmusig.h -- C ABI of libmmmusig_hip.so: the MI355X (gfx950) variational-EM backend that sits under the
+ * MultiModalMuSig.jl API (LDA / MMCTM / IMMCTM, fit!).
+ *
+ * The reference has no FFI: its hot path is reached by ordinary Julia dispatch.  Each entry point below
+ * therefore names the Julia function (file:line under the reference's src/) whose work it replaces; the Julia
+ * shim that `ccall`s them is multimodalmusig.jl_amd/julia/MultiModalMuSigHIP.jl.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = MMM_OK, negative = error);
+ *     nothing throws across the ABI; mmm_last_error() returns the message of the last failure.
+ *   - all reals are double; term ids are 0-based int32, counts int32, CSR offsets int64 (the shim converts
+ *     the reference's 1-based Int64 `X[d][:,1]`).
+ *   - host pointers in/out unless a name ends in `_dev`; the library copies inside the call and keeps no
+ *     host pointer after return.  Model state lives in HBM between calls, owned by the handle.
+ *   - one mmm_ctx per host thread / process = one GPU + one HIP stream (+ one RCCL rank when
+ *     mmm_comm_init_rank has been called).  Calls on a ctx are serialised by the caller.
+ *   - array layouts are exactly the reference's Julia (column-major) layouts flattened:
+ *       LDA    lambda/Elnbeta/beta  V x K   [v + V*k]        (LDA.jl:8-10)
+ *              gamma/Elntheta/theta K x D   [k + K*d]        (LDA.jl:13-15)
+ *              phi   per doc K x W_d, docs concatenated      [K*doc_ptr[d] + k + K*w]   (LDA.jl:16)
+ *       MMCTM  doc_ptr M*(D+1) absolute offsets into the modality-major concatenated term/count arrays
+ *              lambda/nu/props MK x D [i + MK*d]; zeta M x D [m + M*d]
+ *              gamma/Elnphi/phi [goff[m] + k*V[m] + v]
+ *              theta [toff[m] + (e - doc_ptr[m*(D+1)])*K[m] + k]   (e = absolute entry index)
+ *              mu MK; Sigma/invSigma MK x MK column-major
+ *       IMMCTM features [foff[m] + i*V[m] + v] 0-based; gamma/Elnphi [goff[m] + k*SJ[m] + joff[m][i] + j]
+ */
+#ifndef MMMUSIG_H
+#define MMMUSIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMM_VERSION 100
+
+enum {
+    MMM_OK = 0,
+    MMM_ERR_ARG = -1,         /* bad argument / inconsistent sizes                         */
+    MMM_ERR_HIP = -2,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    MMM_ERR_RCCL = -3,        /* an RCCL call failed                                       */
+    MMM_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for              */
+    MMM_ERR_NUMERIC = -5,     /* singular Sigma in the M-step                              */
+    MMM_ERR_NO_DEVICE = -6    /* no gfx950 device visible                                  */
+};
+
+typedef struct mmm_ctx mmm_ctx;
+typedef struct mmm_lda mmm_lda;
+typedef struct mmm_ctm mmm_ctm;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int mmm_version(void);
+/* Create a context on HIP device `device_id` with its own non-blocking stream. */
+int mmm_ctx_create(int device_id, mmm_ctx** out);
+int mmm_ctx_destroy(mmm_ctx* ctx);
+/* Message of the last error on this ctx (ctx == NULL: last error of a failed mmm_ctx_create). */
+const char* mmm_last_error(const mmm_ctx* ctx);
+int mmm_ctx_synchronize(mmm_ctx* ctx);
+/* The hipStream_t every kernel of this ctx is launched on (for event timing by the caller). */
+void* mmm_ctx_stream(mmm_ctx* ctx);
+/* Average duration [ms] of the kernels launched between two marks on the ctx stream (HIP events). */
+int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n);
+
+/* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------
+ * (no counterpart in the reference, which is single-threaded; replaces the doc loops' cross-document sums
+ *  LDA.jl:103-105, MMCTM.jl:201,205-210,230-240 and the log-likelihood sums) */
+#define MMM_UNIQUE_ID_BYTES 128
+int mmm_comm_unique_id(char out[MMM_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId   */
+int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id[MMM_UNIQUE_ID_BYTES]);
+int mmm_comm_nranks(const mmm_ctx* ctx);
+
+/* ---- LDA (src/LDA.jl) ----------------------------------------------------------------------------------- */
+enum { /* field ids for mmm_lda_get / mmm_lda_set; sizes in doubles */
+    MMM_LDA_LAMBDA = 0,   /* V*K  */
+    MMM_LDA_ELNBETA = 1,  /* V*K  */
+    MMM_LDA_BETA = 2,     /* V*K  */
+    MMM_LDA_GAMMA = 3,    /* K*D  */
+    MMM_LDA_ELNTHETA = 4, /* K*D  */
+    MMM_LDA_THETA = 5,    /* K*D  */
+    MMM_LDA_PHI = 6       /* K*nnz */
+};
+/* Constructor LDA(k, alpha, eta, V, X) -- LDA.jl:24-54.  lambda0 (V*K) is the random init the shim draws with
+ * rand(1:100, V, K) (LDA.jl:36); the ctor state gamma=1, phi=1/K, Elnbeta, Elntheta is built on the GPU.
+ * With an RCCL communicator on ctx, (D, doc_ptr, term, count) is THIS RANK'S shard of the documents. */
+int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr,
+                   const int32_t* term, const int32_t* count, const double* lambda0, mmm_lda** out);
+int mmm_lda_destroy(mmm_lda* m);
+int mmm_lda_get(mmm_lda* m, int field, double* host, size_t n);
+int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n);
+/* One-to-one GPU counterparts of the reference's update functions (stage API; used by the parity tests) */
+int mmm_lda_update_gamma(mmm_lda* m);   /* update_γ!  LDA.jl:82-90  (+ update_Elnθ! :78-80)  */
+int mmm_lda_update_phi(mmm_lda* m);     /* update_ϕ!  LDA.jl:69-76                           */
+int mmm_lda_update_lambda(mmm_lda* m);  /* update_λ!  LDA.jl:100-108 (+ update_Elnβ! :96-98) */
+int mmm_lda_update_beta(mmm_lda* m);    /* update_β!  LDA.jl:110-112                         */
+int mmm_lda_update_theta(mmm_lda* m);   /* update_θ!  LDA.jl:92-94                           */
+int mmm_lda_loglik(mmm_lda* m, double* ll);                    /* calculate_loglikelihood LDA.jl:174-196 */
+int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7]);   /* calculate_elbo LDA.jl:114-172          */
+/* Fused hot path: n_iter passes of { update_γ!; update_ϕ!; update_λ!; update_β!; update_θ!; ll } (the body of
+ * fit!, LDA.jl:201-209) enqueued on the ctx stream without host synchronisation.  ll of pass i is written
+ * to an internal device history; read it with mmm_lda_ll_history. */
+int mmm_lda_iterate(mmm_lda* m, int n_iter);
+int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n);
+/* fit!(model; maxiter, tol) -- LDA.jl:198-224: iterate until |dll|/|ll| < tol after > 10 passes, then ELBO. */
+int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged,
+                double* elbo);
+
+/* ---- MMCTM (src/MMCTM.jl) and IMMCTM (src/IMMCTM.jl) -------------------------------------------------------- */
+typedef struct {
+    double xtol_rel;     /* 1e-4   MMCTM.jl:129,158 */
+    double xtol_abs;     /* 1e-4   MMCTM.jl:130,159 */
+    double nu_lower;     /* 1e-7   MMCTM.jl:157     */
+    int xtol_rule;       /* 0: NLopt >= 2.7 stopping rule, 1: NLopt <= 2.6 (Project.toml:15 allows both) */
+    int max_eval;        /* safety cap on objective evaluations per MMA solve (NLopt: unlimited); 0 -> 2000 */
+} mmm_solver_opts;
+void mmm_solver_opts_default(mmm_solver_opts* o);
+
+enum { /* field ids for mmm_ctm_get / mmm_ctm_set */
+    MMM_CTM_MU = 0, MMM_CTM_SIGMA = 1, MMM_CTM_INVSIGMA = 2, MMM_CTM_GAMMA = 3, MMM_CTM_ELNPHI = 4,
+    MMM_CTM_PHI = 5, MMM_CTM_LAMBDA = 6, MMM_CTM_NU = 7, MMM_CTM_ZETA = 8, MMM_CTM_PROPS = 9,
+    MMM_CTM_THETA = 10, MMM_CTM_ALPHA = 11
+};
+/* Constructor MMCTM(k, alpha, V, X) -- MMCTM.jl:29-91 (init = :random; gamma0 is the rand(1:100, V[m]) draw per
+ * topic, MMCTM.jl:60-63).  n_feat/J/features == NULL: MMCTM.  Otherwise IMMCTM(k, alpha, features, X) --
+ * IMMCTM.jl:29-78 with alpha of length sum_m I[m] and gamma0 in the IMMCTM layout. */
+int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha,
+                   const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const int* n_feat,
+                   const int* J, const int32_t* features, const double* gamma0, const mmm_solver_opts* opts,
+                   mmm_ctm** out);
+int mmm_ctm_destroy(mmm_ctm* m);
+int mmm_ctm_get(mmm_ctm* m, int field, double* host, size_t n);
+int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n);
+/* stage API (GPU counterparts of the reference's per-document and M-step functions) */
+int mmm_ctm_update_zeta(mmm_ctm* m);    /* update_ζ! for every doc      MMCTM.jl:172-181              */
+int mmm_ctm_update_theta(mmm_ctm* m);   /* update_θ! for every doc      MMCTM.jl:183-198 / IMMCTM.jl:152-172 */
+int mmm_ctm_update_nu(mmm_ctm* m);      /* update_ν! for every doc      MMCTM.jl:156-170 (LD_MMA)     */
+int mmm_ctm_update_lambda(mmm_ctm* m);  /* update_λ! for every doc      MMCTM.jl:127-143 (LD_MMA)     */
+int mmm_ctm_update_mu(mmm_ctm* m);      /* update_μ!                    MMCTM.jl:200-202              */
+int mmm_ctm_update_Sigma(mmm_ctm* m);   /* update_Σ!                    MMCTM.jl:204-212              */
+int mmm_ctm_update_gamma(mmm_ctm* m);   /* update_γ! (+ update_Elnϕ!)   MMCTM.jl:224-242,214-222      */
+int mmm_ctm_update_Elnphi(mmm_ctm* m);  /* update_Elnϕ!                 MMCTM.jl:214-222 / IMMCTM.jl:188-197 */
+int mmm_ctm_update_props(mmm_ctm* m);   /* update_props!                MMCTM.jl:145-154              */
+int mmm_ctm_update_phi(mmm_ctm* m);     /* update_ϕ!                    MMCTM.jl:244-250              */
+int mmm_ctm_loglik(mmm_ctm* m, double* ll /* M */);                /* calculate_loglikelihoods MMCTM.jl:384-448 */
+int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7]);       /* calculate_elbo MMCTM.jl:271-382           */
+/* objective/gradient of one document evaluated by the device code the MMA solves use (common.jl:11-36) */
+int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_grad, double* nu_val,
+                       double* nu_grad);
+/* solver statistics of the last E-step: total objective evaluations of the nu and lambda solves, number of
+ * solves that hit max_eval, and (optional, D ints each) per-document evaluation counts */
+int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped,
+                         int* per_doc_nu, int* per_doc_lambda);
+/* Fused hot path: n_iter passes of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) */
+int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma);
+int mmm_ctm_ll_history(mmm_ctm* m, double* ll /* M*max_n */, int max_n, int* n);
+int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
+                int* n_iter, int* converged, double* elbo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMMUSIG_H */

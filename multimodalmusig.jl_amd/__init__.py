@@ -1,0 +1,14 @@
+"""multimodalmusig.jl_amd -- MI355X (gfx950) backend for the variational-EM hot path of MultiModalMuSig.jl.
+
+Exports mirror the reference module (src/MultiModalMuSig.jl:9): IMMCTM, MMCTM, LDA, fit (`fit!`),
+format_counts_lda / _ctm / _mmctm.  (ILDA is out of scope: SURVEY.md §2a.)
+"""
+from . import _lib
+from ._lib import Context, MmmError, build, comm_unique_id, default_context, lib
+from .models import (LDA, calculate_elbo, calculate_loglikelihood, fit, fit_bang, update_β, update_γ, update_θ,
+                     update_λ, update_ϕ)
+from .utils import (format_counts_ctm, format_counts_lda, format_counts_mmctm, make_count_matrix, pack_lda,
+                    pack_mm, read_counts_tsv, shard_documents)
+
+__all__ = ["LDA", "fit", "fit_bang", "format_counts_lda", "format_counts_ctm", "format_counts_mmctm", "Context",
+           "MmmError", "build"]

@@ -1,0 +1,203 @@
+"""ctypes binding of libmmmusig_hip.so (include/mmmusig.h).
+
+There is NO CPU fallback: if the shared library is missing or no gfx950 device is visible, loading / context
+creation raises.  `build()` compiles the library in-tree with hipcc (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmmmusig_hip.so")
+_LIB = None
+
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+vp = C.c_void_p
+
+
+class MmmError(RuntimeError):
+    pass
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("xtol_rel", C.c_double), ("xtol_abs", C.c_double), ("nu_lower", C.c_double),
+                ("xtol_rule", C.c_int), ("max_eval", C.c_int)]
+
+
+def build(force=False, jobs=4):
+    """hipcc --offload-arch=gfx950 build of every HIP translation unit into lib/libmmmusig_hip.so."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-s", "-C", csrc, "-j%d" % jobs, "all"]
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+# symbol -> (restype, argtypes); every symbol include/mmmusig.h declares is listed here
+_SIGS = {
+    "mmm_version": (C.c_int, []),
+    "mmm_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "mmm_ctx_destroy": (C.c_int, [vp]),
+    "mmm_last_error": (C.c_char_p, [vp]),
+    "mmm_ctx_synchronize": (C.c_int, [vp]),
+    "mmm_ctx_stream": (vp, [vp]),
+    "mmm_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
+    "mmm_comm_nranks": (C.c_int, [vp]),
+    "mmm_lda_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, vp, vp, f64p, C.POINTER(vp)]),
+    "mmm_lda_destroy": (C.c_int, [vp]),
+    "mmm_lda_get": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
+    "mmm_lda_set": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
+    "mmm_lda_update_gamma": (C.c_int, [vp]),
+    "mmm_lda_update_phi": (C.c_int, [vp]),
+    "mmm_lda_update_lambda": (C.c_int, [vp]),
+    "mmm_lda_update_beta": (C.c_int, [vp]),
+    "mmm_lda_update_theta": (C.c_int, [vp]),
+    "mmm_lda_loglik": (C.c_int, [vp, C.POINTER(C.c_double)]),
+    "mmm_lda_elbo": (C.c_int, [vp, C.POINTER(C.c_double), vp]),
+    "mmm_lda_iterate": (C.c_int, [vp, C.c_int]),
+    "mmm_lda_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "mmm_lda_fit": (C.c_int, [vp, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "mmm_solver_opts_default": (None, [C.POINTER(SolverOpts)]),
+    "mmm_ctm_create": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, f64p, i64p, vp, vp, vp, vp, vp, f64p, C.POINTER(SolverOpts), C.POINTER(vp)]),
+    "mmm_ctm_destroy": (C.c_int, [vp]),
+    "mmm_ctm_get": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
+    "mmm_ctm_set": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
+    "mmm_ctm_update_zeta": (C.c_int, [vp]),
+    "mmm_ctm_update_theta": (C.c_int, [vp]),
+    "mmm_ctm_update_nu": (C.c_int, [vp]),
+    "mmm_ctm_update_lambda": (C.c_int, [vp]),
+    "mmm_ctm_update_mu": (C.c_int, [vp]),
+    "mmm_ctm_update_Sigma": (C.c_int, [vp]),
+    "mmm_ctm_update_gamma": (C.c_int, [vp]),
+    "mmm_ctm_update_Elnphi": (C.c_int, [vp]),
+    "mmm_ctm_update_props": (C.c_int, [vp]),
+    "mmm_ctm_update_phi": (C.c_int, [vp]),
+    "mmm_ctm_loglik": (C.c_int, [vp, f64p]),
+    "mmm_ctm_elbo": (C.c_int, [vp, C.POINTER(C.c_double), vp]),
+    "mmm_ctm_objectives": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), f64p, C.POINTER(C.c_double), f64p]),
+    "mmm_ctm_solver_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]),
+    "mmm_ctm_iterate": (C.c_int, [vp, C.c_int, C.c_int]),
+    "mmm_ctm_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
+    "mmm_ctm_fit": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the shared library (raises MmmError if it has not been built)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MmmError("libmmmusig_hip.so is not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C multimodalmusig.jl_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)      # AttributeError here = the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(rc, ctx_handle=None, what=""):
+    if rc != 0:
+        msg = lib().mmm_last_error(ctx_handle)
+        raise MmmError("%s failed with status %d: %s" % (what or "libmmmusig_hip call", rc, (msg or b"").decode(errors="replace")))
+
+
+_ALL_CTX = []
+
+
+class Context:
+    """One GPU + one HIP stream (+ one RCCL rank).  Mirrors `mmm_ctx`."""
+
+    def __init__(self, device=0):
+        self.h = vp()
+        rc = lib().mmm_ctx_create(int(device), C.byref(self.h))
+        if rc != 0:
+            msg = lib().mmm_last_error(None)
+            raise MmmError("mmm_ctx_create(device=%d) failed with status %d: %s -- the HIP path is the only path; "
+                           "no CPU fallback exists" % (device, rc, (msg or b"").decode(errors="replace")))
+        self.device = int(device)
+        self.nranks, self.rank = 1, 0
+        _ALL_CTX.append(self)
+
+    def synchronize(self):
+        check(lib().mmm_ctx_synchronize(self.h), self.h, "mmm_ctx_synchronize")
+
+    @property
+    def stream(self):
+        return lib().mmm_ctx_stream(self.h)
+
+    def device_name(self):
+        b = C.create_string_buffer(64)
+        check(lib().mmm_ctx_device_name(self.h, b, 64), self.h)
+        return b.value.decode()
+
+    def init_comm(self, nranks, rank, unique_id):
+        check(lib().mmm_comm_init_rank(self.h, int(nranks), int(rank), unique_id), self.h, "mmm_comm_init_rank")
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def close(self):
+        if self.h:
+            lib().mmm_ctx_destroy(self.h)
+            self.h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    b = C.create_string_buffer(128)
+    check(lib().mmm_comm_unique_id(b), None, "mmm_comm_unique_id")
+    return b.raw
+
+
+_DEFAULT_CTX = {}
+_LIVE = None
+
+
+def track(model):
+    """Remember a live model handle so that it is destroyed (before its context) at interpreter exit, while the
+    HIP runtime is still up."""
+    global _LIVE
+    import atexit
+    import weakref
+    if _LIVE is None:
+        _LIVE = weakref.WeakSet()
+        atexit.register(_shutdown)
+    _LIVE.add(model)
+
+
+def _shutdown():
+    for m in list(_LIVE or ()):
+        try:
+            m.close()
+        except Exception:
+            pass
+    for c in list(_ALL_CTX):
+        try:
+            c.close()
+        except Exception:
+            pass
+
+
+def default_context(device=0):
+    c = _DEFAULT_CTX.get(device)
+    if c is None or not c.h:
+        c = _DEFAULT_CTX[device] = Context(device)
+    return c

@@ -1,0 +1,104 @@
+// ctx.hip -- context, stream and RCCL communicator management of libmmmusig_hip.so
+#include "mmm_internal.h"
+
+thread_local std::string g_mmm_create_error;
+
+extern "C" {
+
+int mmm_version(void) { return MMM_VERSION; }
+
+int mmm_ctx_create(int device_id, mmm_ctx** out)
+{
+    if (!out) return mmm_fail(nullptr, MMM_ERR_ARG, "mmm_ctx_create: out == NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return mmm_fail(nullptr, MMM_ERR_NO_DEVICE, "mmm_ctx_create: no HIP device visible (%s)",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        return mmm_fail(nullptr, MMM_ERR_ARG, "mmm_ctx_create: device %d out of range (0..%d)", device_id, ndev - 1);
+    mmm_ctx* ctx = new mmm_ctx();
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        int rc = mmm_fail(nullptr, MMM_ERR_HIP, "mmm_ctx_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = mmm_fail(nullptr, MMM_ERR_NO_DEVICE, "mmm_ctx_create: device %d is %s; this library holds gfx950 code only",
+                          device_id, prop.gcnArchName);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return MMM_OK;
+}
+
+int mmm_ctx_destroy(mmm_ctx* ctx)
+{
+    if (!ctx) return MMM_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+    return MMM_OK;
+}
+
+const char* mmm_last_error(const mmm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_mmm_create_error.c_str(); }
+
+int mmm_ctx_synchronize(mmm_ctx* ctx)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMM_OK;
+}
+
+void* mmm_ctx_stream(mmm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n)
+{
+    if (!ctx || !buf || n == 0) return MMM_ERR_ARG;
+    snprintf(buf, n, "%s", ctx->arch);
+    return MMM_OK;
+}
+
+int mmm_comm_unique_id(char out[MMM_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) <= MMM_UNIQUE_ID_BYTES, "ncclUniqueId larger than the ABI slot");
+    if (!out) return MMM_ERR_ARG;
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return mmm_fail(nullptr, MMM_ERR_RCCL, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memset(out, 0, MMM_UNIQUE_ID_BYTES);
+    memcpy(out, &id, sizeof id);
+    return MMM_OK;
+}
+
+int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id_bytes[MMM_UNIQUE_ID_BYTES])
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, nranks >= 1 && rank >= 0 && rank < nranks && id_bytes, "mmm_comm_init_rank: bad nranks/rank");
+    MMM_CHECK(ctx, ctx->comm == nullptr, "mmm_comm_init_rank: communicator already initialised");
+    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    MMM_NCCL(ctx, ncclCommInitRank(&ctx->comm, nranks, id, rank));
+    ctx->nranks = nranks; ctx->rank = rank;
+    return MMM_OK;
+}
+
+int mmm_comm_nranks(const mmm_ctx* ctx) { return ctx ? ctx->nranks : 0; }
+
+void mmm_solver_opts_default(mmm_solver_opts* o)
+{
+    if (!o) return;
+    o->xtol_rel = 1e-4; o->xtol_abs = 1e-4; o->nu_lower = 1e-7; o->xtol_rule = 0; o->max_eval = 2000;
+}
+
+} // extern "C"

@@ -1,0 +1,80 @@
+// mmm_internal.h -- host-side plumbing shared by the translation units of libmmmusig_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mmmusig.h"
+
+struct mmm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    int num_cu = 256;
+    std::string err;
+    char arch[64] = {0};
+};
+
+extern thread_local std::string g_mmm_create_error;
+
+inline int mmm_fail(mmm_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_mmm_create_error = buf;
+    return code;
+}
+
+#define MMM_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return mmm_fail((ctx), MMM_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call,      \
+                            hipGetErrorString(e_));                                                \
+    } while (0)
+
+#define MMM_NCCL(ctx, call)                                                                        \
+    do {                                                                                           \
+        ncclResult_t r_ = (call);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return mmm_fail((ctx), MMM_ERR_RCCL, "%s:%d %s -> %s", __FILE__, __LINE__, #call,     \
+                            ncclGetErrorString(r_));                                               \
+    } while (0)
+
+#define MMM_CHECK(ctx, cond, ...)                                                                  \
+    do { if (!(cond)) return mmm_fail((ctx), MMM_ERR_ARG, __VA_ARGS__); } while (0)
+
+#define MMM_LAUNCH_CHECK(ctx) MMM_HIP(ctx, hipGetLastError())
+
+// device buffer with RAII; all model state lives in these
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        return hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+    }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+};
+
+// sum-all-reduce of a packed double buffer across the ranks of ctx (no-op for a single rank)
+inline int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
+{
+    if (ctx->nranks <= 1 || !ctx->comm) return MMM_OK;
+    MMM_NCCL(ctx, ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    return MMM_OK;
+}

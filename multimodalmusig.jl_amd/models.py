@@ -1,0 +1,203 @@
+"""Host-side mirror of the MultiModalMuSig.jl model API over the HIP backend.
+
+Names, argument meaning and field names follow the reference (`LDA`, `MMCTM`, `IMMCTM`, `fit!`, `update_*!`,
+`calculate_*`; Julia's `!` suffix is dropped).  Model state lives in HBM inside the C-ABI handle; the
+reference's fields (`model.λ`, `model.ϕ`, `model.θ` ...) are properties that download on read and upload on
+assignment, so the parity tests read like the reference's own tests.  There is no CPU implementation here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MmmError, check, lib
+from .utils import pack_lda, pack_mm
+
+# field ids of include/mmmusig.h (ASCII keys: Python NFKC-normalises identifiers, so `ϕ` typed as a keyword
+# would not equal the string "ϕ")
+_F = {"lambda": 0, "Elnbeta": 1, "beta": 2, "gamma": 3, "Elntheta": 4, "theta": 5, "phi": 6}
+
+
+class _PerDocView:
+    """List-like view of a per-document field (model.ϕ[d] is K x W_d as in LDA.jl:16); item assignment writes
+    through to the device."""
+
+    def __init__(self, getter, setter, D):
+        self._get, self._set, self._D = getter, setter, D
+
+    def __len__(self):
+        return self._D
+
+    def __getitem__(self, d):
+        return self._get(d)
+
+    def __setitem__(self, d, value):
+        self._set(d, value)
+
+    def __iter__(self):
+        return (self._get(d) for d in range(self._D))
+
+
+class LDA:
+    """`LDA(k, α, η, X)` / `LDA(k, α, η, V, X)` -- LDA.jl:24-67.
+
+    X: list of (W_d x 2) integer matrices `[term(1-based) count]` as produced by `format_counts_lda`.
+    The random init `λ = rand(1:100, V, K)` (LDA.jl:36) is drawn with numpy (`seed`) unless `λ0` is given.
+    With a multi-rank Context, X is this rank's shard of the documents.
+    """
+
+    def __init__(self, k, α, η, *args, λ0=None, seed=None, ctx=None):
+        if len(args) == 1:
+            V, X = None, args[0]
+        elif len(args) == 2:
+            V, X = args
+        else:
+            raise TypeError("LDA(k, α, η, [V,] X)")
+        self.K, self.α, self.η, self.X = int(k), float(α), float(η), X
+        self.D = len(X)
+        self._doc_ptr, self._term, self._count = pack_lda(X)
+        if V is None:
+            V = int(self._term.max()) + 1 if self._term.size else 0     # LDA.jl:57-66
+        self.V = int(V)
+        self.N = np.array([int(self._count[self._doc_ptr[d]:self._doc_ptr[d + 1]].sum()) for d in range(self.D)], dtype=np.int64)
+        if λ0 is None:
+            λ0 = np.random.default_rng(seed).integers(1, 101, size=(self.V, self.K)).astype(np.float64)
+        λ0 = np.asarray(λ0, dtype=np.float64)
+        if λ0.shape != (self.V, self.K):
+            raise ValueError("λ0 must be V x K")
+        self.ctx = ctx or _lib.default_context()
+        self._h = C.c_void_p()
+        tp = self._term.ctypes.data if self._term.size else None
+        cp = self._count.ctypes.data if self._count.size else None
+        check(lib().mmm_lda_create(self.ctx.h, self.D, self.V, self.K, self.α, self.η, self._doc_ptr, tp, cp,
+                                   np.ascontiguousarray(λ0.ravel(order="F")), C.byref(self._h)), self.ctx.h, "mmm_lda_create")
+        _lib.track(self)
+        self.converged = False
+        self.elbo = float("nan")
+        self.ll = float("nan")
+
+    # ---- raw field transfer -------------------------------------------------------------------------------
+    def _size(self, name):
+        VK, KD = self.V * self.K, self.K * self.D
+        return {"lambda": VK, "Elnbeta": VK, "beta": VK, "gamma": KD, "Elntheta": KD, "theta": KD,
+                "phi": self.K * int(self._doc_ptr[-1])}[name]
+
+    def _get(self, name):
+        out = np.empty(self._size(name), dtype=np.float64)
+        check(lib().mmm_lda_get(self._h, _F[name], out, out.size), self.ctx.h, "mmm_lda_get(%s)" % name)
+        return out
+
+    def _set(self, name, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float64)
+        check(lib().mmm_lda_set(self._h, _F[name], flat, flat.size), self.ctx.h, "mmm_lda_set(%s)" % name)
+
+    def _mat(self, name, rows, cols):
+        return self._get(name).reshape(rows, cols, order="F")
+
+    # V x K fields
+    λ = property(lambda s: s._mat("lambda", s.V, s.K), lambda s, v: s._set("lambda", np.asarray(v, float).ravel(order="F")))
+    Elnβ = property(lambda s: s._mat("Elnbeta", s.V, s.K), lambda s, v: s._set("Elnbeta", np.asarray(v, float).ravel(order="F")))
+    β = property(lambda s: s._mat("beta", s.V, s.K), lambda s, v: s._set("beta", np.asarray(v, float).ravel(order="F")))
+    # K x D fields
+    γ = property(lambda s: s._mat("gamma", s.K, s.D), lambda s, v: s._set("gamma", np.asarray(v, float).ravel(order="F")))
+    Elnθ = property(lambda s: s._mat("Elntheta", s.K, s.D), lambda s, v: s._set("Elntheta", np.asarray(v, float).ravel(order="F")))
+    θ = property(lambda s: s._mat("theta", s.K, s.D), lambda s, v: s._set("theta", np.asarray(v, float).ravel(order="F")))
+
+    @property
+    def ϕ(self):
+        def get(d):
+            flat = self._get("phi")
+            a, b = int(self._doc_ptr[d]), int(self._doc_ptr[d + 1])
+            return flat[self.K * a:self.K * b].reshape(b - a, self.K).T.copy()
+
+        def put(d, value):
+            flat = self._get("phi")
+            a, b = int(self._doc_ptr[d]), int(self._doc_ptr[d + 1])
+            value = np.asarray(value, dtype=np.float64)
+            if value.shape != (self.K, b - a):
+                raise ValueError("ϕ[d] must be K x W_d")
+            flat[self.K * a:self.K * b] = value.T.ravel()
+            self._set("phi", flat)
+        return _PerDocView(get, put, self.D)
+
+    @ϕ.setter
+    def ϕ(self, docs):
+        flat = np.concatenate([np.asarray(p, dtype=np.float64).T.ravel() for p in docs]) if len(docs) else np.zeros(0)
+        self._set("phi", flat)
+
+    def phi_flat(self):
+        """ϕ as one [nnz, K] array (document blocks concatenated)."""
+        return self._get("phi").reshape(-1, self.K)
+
+    def close(self):
+        if self._h:
+            lib().mmm_lda_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- function API (the reference's free functions on a model) ------------------------------------------------
+def _call(model, fn, what):
+    check(getattr(lib(), fn)(model._h), model.ctx.h, what)
+
+
+def update_γ(model):   # LDA.jl:82-90
+    _call(model, "mmm_lda_update_gamma", "update_γ!")
+
+
+def update_ϕ(model):   # LDA.jl:69-76 ; MMCTM.jl:244-250
+    if isinstance(model, LDA):
+        _call(model, "mmm_lda_update_phi", "update_ϕ!")
+    else:
+        _call(model, "mmm_ctm_update_phi", "update_ϕ!")
+
+
+def update_λ(model, d=None):   # LDA.jl:100-108
+    _call(model, "mmm_lda_update_lambda", "update_λ!")
+
+
+def update_β(model):   # LDA.jl:110-112
+    _call(model, "mmm_lda_update_beta", "update_β!")
+
+
+def update_θ(model):   # LDA.jl:92-94
+    _call(model, "mmm_lda_update_theta", "update_θ!")
+
+
+def calculate_loglikelihood(model):   # LDA.jl:194-196
+    v = C.c_double()
+    check(lib().mmm_lda_loglik(model._h, C.byref(v)), model.ctx.h, "calculate_loglikelihood")
+    return v.value
+
+
+def calculate_elbo(model, terms=False):   # LDA.jl:162-172 / MMCTM.jl:372-382
+    v = C.c_double(); t = np.zeros(7)
+    fn = lib().mmm_lda_elbo if isinstance(model, LDA) else lib().mmm_ctm_elbo
+    check(fn(model._h, C.byref(v), t.ctypes.data), model.ctx.h, "calculate_elbo")
+    return (v.value, t) if terms else v.value
+
+
+def fit(model, maxiter=None, tol=1e-4, verbose=True, **kw):
+    """`fit!(model; maxiter, tol, verbose)` -- LDA.jl:198-224 (maxiter default 1000), MMCTM.jl:457-494 and
+    IMMCTM.jl:437-466 (default 100).  Returns the log-likelihood history and sets converged/elbo/ll."""
+    if isinstance(model, LDA):
+        maxiter = 1000 if maxiter is None else int(maxiter)
+        ll = np.zeros(maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
+        check(lib().mmm_lda_fit(model._h, maxiter, float(tol), ll.ctypes.data, C.byref(ni), C.byref(cv), C.byref(el)),
+              model.ctx.h, "fit!(::LDA)")
+        hist = ll[:ni.value].copy()
+        if verbose:
+            for i, v in enumerate(hist):
+                print("%d\tLog-likelihood: %r" % (i + 1, v))
+        model.converged = bool(cv.value); model.elbo = el.value; model.ll = float(hist[-1])
+        return hist
+    from .ctm import _fit_ctm
+    return _fit_ctm(model, maxiter, tol, verbose, **kw)
+
+
+fit_bang = fit   # `fit!`

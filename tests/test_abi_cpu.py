@@ -1,0 +1,39 @@
+"""CPU-side checks of the boundary: the C-ABI library builds for gfx950, loads, exports every symbol the header
+declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol(mmm):
+    mmm.build()
+    L = mmm.lib()
+    hdr = open(os.path.join(ROOT, "include", "mmmusig.h")).read()
+    declared = set(re.findall(r"\b(mmm_[a-z_A-Z0-9]+)\s*\(", hdr))
+    declared -= {"mmm_ctx", "mmm_lda", "mmm_ctm"}
+    assert len(declared) >= 40
+    for name in sorted(declared):
+        assert hasattr(L, name), "header declares %s but the library does not export it" % name
+    assert set(mmm._lib.declared_symbols()) == declared
+    assert L.mmm_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu(mmm):
+    import subprocess, sys
+    code = ("import mmm_pkg, sys; m = mmm_pkg.load()\n"
+            "try:\n    m.Context(0)\nexcept m.MmmError as e:\n    print('LOUD', e); sys.exit(7)\nsys.exit(0)\n")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert p.returncode == 7 and "no CPU fallback" in p.stdout, p.stdout + p.stderr
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multimodalmusig.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in txt.lower().replace("no oracle", ""), os.path.join(dirpath, f)

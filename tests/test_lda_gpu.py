@@ -1,0 +1,163 @@
+"""GPU parity tests for the LDA path: the HIP backend (through the C ABI / host mirror) against (i) the
+reference's own known-answer tests, (ii) the CPU oracle on seeded synthetic corpora, (iii) size-independent
+invariants at the BASELINE size.  Tolerances: 1e-11 relative for a single sweep (summation order differs),
+1e-5 relative (north-star bar) on phi/theta/ELBO after a fit -- both written where they are used."""
+import numpy as np
+import pytest
+
+import np_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def arr(x):
+    return np.asarray(x, dtype=np.float64)
+
+
+# ---------------------------------------------------------------------------------- reference KATs (test/lda.jl)
+def test_constructor(mmm, kats):
+    c = kats["corpora"]
+    X = [arr(x).astype(np.int64) for x in c["X_lda"]]
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], X, seed=0)
+    assert (model.K, model.D, model.V) == (2, 2, 2)
+    assert list(model.N) == kats["lda_ctor"]["N"]
+    assert model.λ.shape == (2, 2) and np.all(model.λ > 0)
+    assert model.γ.shape == (2, 2) and np.all(model.γ > 0)
+    np.testing.assert_allclose(model.ϕ[0].sum(axis=0), np.ones(2))
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], 3, X, seed=0)
+    assert model.V == 3 and model.λ.shape == (3, 2)
+
+
+def test_update_phi(mmm, kats):
+    c, k = kats["corpora"], kats["lda_update_phi"]
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], c["X_lda"], seed=0)
+    model.Elnθ = arr(k["Elntheta"])
+    model.Elnβ = arr(k["Elnbeta"])
+    mmm.update_ϕ(model)
+    np.testing.assert_allclose(model.ϕ[0], arr(k["phi_doc1"]), rtol=1e-13)
+
+
+def test_update_gamma(mmm, kats):
+    c, k = kats["corpora"], kats["lda_update_gamma"]
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], c["X_lda"], seed=0)
+    model.ϕ[0] = arr(k["phi_doc1"])
+    mmm.update_γ(model)
+    np.testing.assert_allclose(model.γ[:, 0], k["gamma_doc1"], rtol=1e-13)
+    np.testing.assert_allclose(model.Elnθ[:, 0], k["Elntheta_doc1"], rtol=1e-12)
+
+
+def test_update_lambda(mmm, kats):
+    c, k = kats["corpora"], kats["lda_update_lambda"]
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], c["X_lda"], seed=0)
+    model.ϕ = [arr(p) for p in k["phi"]]
+    mmm.update_λ(model)
+    np.testing.assert_allclose(model.λ, arr(k["lambda"]), rtol=1e-13)
+    np.testing.assert_allclose(model.Elnβ, arr(k["Elnbeta"]), rtol=1e-12)
+
+
+def test_calculate_elbo_negative_at_construction(mmm, kats):
+    c = kats["corpora"]
+    model = mmm.LDA(c["K_lda"], c["alpha_lda"], c["eta_lda"], c["X_lda"], seed=3)
+    e, t = mmm.calculate_elbo(model, terms=True)
+    assert e < 0.0 and np.all(np.isfinite(t))          # test/lda.jl:105-118
+
+
+# ---------------------------------------------------------------------------------- differential vs the oracle
+def _pair(mmm, oracle, D, V, K, seed, mean_n=400, alpha=0.1, eta=0.1, empty=()):
+    X, lam0 = np_ref.synth_lda(D, V, K, seed=seed, mean_n=mean_n)
+    for d in empty:
+        X[d] = np.zeros((0, 2), dtype=np.int64)
+    g = mmm.LDA(K, alpha, eta, V, X, λ0=lam0)
+    o = oracle.LdaOracle(K, alpha, eta, X, V=V, lambda0=lam0)
+    return X, g, o
+
+
+def _cmp_state(g, o, rtol, phi=True):
+    K, D, V = g.K, g.D, g.V
+    np.testing.assert_allclose(g.γ, o.gamma.reshape(D, K).T, rtol=rtol)
+    np.testing.assert_allclose(g.Elnθ, o.Elntheta.reshape(D, K).T, rtol=rtol, atol=1e-13)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(V, K, order="F"), rtol=rtol)
+    np.testing.assert_allclose(g.Elnβ, o.Elnbeta.reshape(V, K, order="F"), rtol=rtol, atol=1e-13)
+    if phi:
+        np.testing.assert_allclose(g.phi_flat(), o.phi.reshape(-1, K), rtol=rtol, atol=1e-300)
+
+
+@pytest.mark.parametrize("D,V,K", [(37, 24, 5), (64, 96, 7), (101, 96, 10), (9, 130, 3)])
+def test_single_sweep_matches_oracle(mmm, oracle, D, V, K):
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=100 + D, empty=(1, D - 1))
+    # stage API, one reference function at a time
+    mmm.update_γ(g); o.update_gamma()
+    mmm.update_ϕ(g); o.update_phi()
+    mmm.update_λ(g); o.update_lambda()
+    mmm.update_β(g); o.update_beta()
+    mmm.update_θ(g); o.update_theta()
+    _cmp_state(g, o, 1e-11)
+    np.testing.assert_allclose(g.β, o.beta.reshape(V, K, order="F"), rtol=1e-11)
+    np.testing.assert_allclose(g.θ, o.theta.reshape(D, K).T, rtol=1e-11)
+    assert mmm.calculate_loglikelihood(g) == pytest.approx(o.loglik(), rel=1e-11)
+    e, t = mmm.calculate_elbo(g, terms=True)
+    eo, to = o.elbo()
+    np.testing.assert_allclose(t, to, rtol=1e-10)
+    assert e == pytest.approx(eo, rel=1e-10)
+
+
+@pytest.mark.parametrize("D,V,K", [(50, 96, 10), (33, 40, 7)])
+def test_fused_iterations_equal_stage_sequence_and_oracle(mmm, oracle, D, V, K):
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=7, empty=(0,))
+    n = 11
+    check = mmm._lib.check
+    check(mmm.lib().mmm_lda_iterate(g._h, n), g.ctx.h, "iterate")
+    for _ in range(n):
+        o.update_gamma(); o.update_phi(); o.update_lambda(); o.update_beta(); o.update_theta()
+    _cmp_state(g, o, 1e-9)
+    assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-9)
+    # continue with the stage API from the fused state: must stay on the oracle's trajectory
+    mmm.update_γ(g); o.update_gamma()
+    mmm.update_ϕ(g); o.update_phi()
+    mmm.update_λ(g); o.update_lambda()
+    _cmp_state(g, o, 1e-9)
+
+
+def test_fit_matches_oracle(mmm, oracle):
+    """fit! with the reference's stopping rule (>10 passes, |dll|/|ll| < tol): same number of passes, same
+    ll history, phi/theta/ELBO within the north-star 1e-5 relative bar."""
+    X, g, o = _pair(mmm, oracle, 120, 96, 10, seed=2026, mean_n=3000)
+    ll_g = mmm.fit(g, maxiter=200, tol=1e-4, verbose=False)
+    ll_o = o.fit(maxiter=200, tol=1e-4)
+    assert len(ll_g) == len(ll_o) and g.converged == o.converged
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    np.testing.assert_allclose(g.phi_flat(), o.phi.reshape(-1, 10), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(g.θ, o.theta.reshape(120, 10).T, rtol=1e-5)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-5)
+    assert g.ll == pytest.approx(ll_o[-1], rel=1e-9)
+
+
+def test_brca_like_counts_k7(mmm, oracle):
+    """BASELINE config 1 shape (K=7, alpha=eta=0.1, 96 terms, heavy-tailed N) on synthetic counts."""
+    X, g, o = _pair(mmm, oracle, 80, 96, 7, seed=1, mean_n=20000)
+    ll_g = mmm.fit(g, maxiter=15, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=15, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-7)
+
+
+# ---------------------------------------------------------------------------------- invariants at BASELINE size
+def test_invariants_at_full_size(mmm):
+    D, V, K = 10000, 96, 10
+    X, lam0 = np_ref.synth_lda(D, V, K, seed=20261004)
+    g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+    ll = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
+    assert len(ll) == 12 and np.all(np.isfinite(ll)) and ll[-1] > ll[0]
+    N = np.array([x[:, 1].sum() for x in X], dtype=np.float64)
+    # mass conservation: sum_k gamma[k,d] = K*alpha + N_d ; sum_{v,k} lambda = V*K*eta + sum N
+    np.testing.assert_allclose(g.γ.sum(axis=0), K * 0.1 + N, rtol=1e-12)
+    assert g.λ.sum() == pytest.approx(V * K * 0.1 + N.sum(), rel=1e-12)
+    phi = g.phi_flat()
+    np.testing.assert_allclose(phi.sum(axis=1), 1.0, rtol=1e-13)
+    np.testing.assert_allclose(g.β.sum(axis=0), 1.0, rtol=1e-13)
+    np.testing.assert_allclose(g.θ.sum(axis=0), 1.0, rtol=1e-13)
+    # idempotence of materialisation and determinism of the fused path (fixed-order reductions)
+    g2 = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+    ll2 = mmm.fit(g2, maxiter=12, tol=0.0, verbose=False)
+    np.testing.assert_array_equal(ll, ll2)
+    np.testing.assert_array_equal(g.λ, g2.λ)
