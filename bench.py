@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- E-step docs/sec of the MI355X backend on BASELINE.json's configuration.
+
+A "step" = one outer EM iteration (the body of fit!, LDA.jl:201-209: E-step over every document, M-step
+reduction, log-likelihood) over one batch of synthetic documents resident in HBM.
+N = 1: BASELINE configs[1] -- LDA K=10, alpha=eta=0.1, D=10,000 documents x 96 SNV terms (SURVEY §8d generator).
+N > 1: weak scaling -- every rank holds its own 10,000-document shard (global corpus 10,000 x N), one RCCL
+all-reduce of the packed lambda statistics (+ one of the ll numerator) per iteration.
+
+Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both
+sides; MAX over ranks; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def synth(D, V, K, seed):
+    import np_ref
+    return np_ref.synth_lda(D, V, K, seed=seed)
+
+
+def cpu_baseline(X, lam0, K, alpha, eta, target_s=12.0):
+    """The CPU oracle (a compiled, allocation-free C port of the reference's Julia loop; 1 thread like the
+    reference) timed on a bounded number of passes over the SAME 10k-document corpus."""
+    from oracle import oracle as orc
+    V = lam0.shape[0]
+    o = orc.LdaOracle(K, alpha, eta, X, V=V, lambda0=lam0)
+
+    def one_pass():
+        o.update_gamma(); o.update_phi(); o.update_lambda(); o.update_beta(); o.update_theta()
+        return o.loglik()
+
+    t0 = time.perf_counter(); one_pass(); t1 = time.perf_counter() - t0
+    n = max(2, min(40, int(target_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_pass()
+    dt = time.perf_counter() - t0
+    return {"value": len(X) * n / dt, "unit": "docs/s", "cores": 1, "kind": "port",
+            "sample": "%d passes over the same %d-doc corpus, %.1f s, single thread (C oracle; the Julia reference "
+                      "cannot run on this box)" % (n, len(X), dt)}
+
+
+def parity_probe(pkg, K, alpha, eta, V, seed):
+    """ELBO / phi relative error GPU vs oracle on a bounded sample (200 docs, 12 passes)."""
+    import numpy as np
+    from oracle import oracle as orc
+    X, lam0 = synth(200, V, K, seed)
+    g = pkg.LDA(K, alpha, eta, V, X, λ0=lam0)
+    pkg.fit(g, maxiter=12, tol=0.0, verbose=False)
+    o = orc.LdaOracle(K, alpha, eta, X, V=V, lambda0=lam0)
+    o.fit(maxiter=12, tol=0.0)
+    phi_g, phi_o = g.phi_flat(), o.phi.reshape(-1, K)
+    rel_phi = float(np.max(np.abs(phi_g - phi_o) / np.maximum(np.abs(phi_o), 1e-12)))
+    rel_elbo = abs(g.elbo - o.elbo_value) / abs(o.elbo_value)
+    g.close()
+    return {"elbo_rel_err_vs_oracle": rel_elbo, "phi_max_rel_err_vs_oracle": rel_phi}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--docs", type=int, default=10000, help="documents per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                       # first: the library then binds to the HIP runtime torch has loaded
+    import torch.distributed as dist
+    import mmm_pkg
+    pkg = mmm_pkg.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    ctx = pkg.Context(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        ctx.init_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    K, V, alpha, eta, D = 10, 96, 0.1, 0.1, args.docs
+    seed = 20261003 + 1                                   # corpus seed = 20261003 + config index
+    X, lam0 = synth(D, V, K, seed + 1000 * rank)          # every rank its own shard; lambda0 identical
+    if world > 1:                                          # same lambda0 everywhere: take rank 0's
+        t = torch.from_numpy(np.ascontiguousarray(lam0)).cuda()
+        dist.broadcast(t, 0)
+        lam0 = t.cpu().numpy()
+    model = pkg.LDA(K, alpha, eta, V, X, λ0=lam0, ctx=ctx)
+    nnz = int(model._doc_ptr[-1])
+    lib = pkg.lib()
+
+    def steps(n):
+        pkg._lib.check(lib.mmm_lda_iterate(model._h, n), ctx.h, "mmm_lda_iterate")
+
+    steps(args.warmup)
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    n_launch, k_ms = ctx.profile_end()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ll = np.zeros(1); n = pkg._lib.C.c_int()
+    pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
+
+    if rank == 0:
+        docs_total = D * world * args.steps
+        # dominant kernel: k_lda_estep (fused E-step).  Algorithmic bytes per launch: 8 B per nonzero (term,count)
+        # + gamma read + Elntheta write + gamma_next write (3 x 8 B x K per document) -- phi stays in registers.
+        algo_bytes = 8.0 * nnz + 24.0 * K * D
+        avg_s = (k_ms / max(n_launch, 1)) * 1e-3
+        achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        res = {
+            "metric": "E-step docs/sec", "value": docs_total / dt, "unit": "docs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "LDA K=10 alpha=eta=0.1, %d docs x 96 SNV terms per GPU (BASELINE configs[1]), "
+                                   "nnz/GPU=%d, one EM iteration per step" % (D, nnz),
+                       "docs_per_gpu": D, "terms": V, "topics": K, "sharding": "docs x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_lda_estep<10,FUSED>", "launches": n_launch, "avg_us": avg_s * 1e6,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "ll_last": float(ll[0]),
+        }
+        if world == 1:
+            res.update(parity_probe(pkg, K, alpha, eta, V, seed + 7))
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(X, lam0, K, alpha, eta)
+                res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,8 +62,12 @@ const char* mmm_last_error(const mmm_ctx* ctx);
 int mmm_ctx_synchronize(mmm_ctx* ctx);
 /* The hipStream_t every kernel of this ctx is launched on (for event timing by the caller). */
 void* mmm_ctx_stream(mmm_ctx* ctx);
-/* Average duration [ms] of the kernels launched between two marks on the ctx stream (HIP events). */
 int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n);
+/* HIP-event timing of the dominant kernel of the hot path (the fused E-step kernel) on the ctx stream: between
+ * begin and end every launch of it is bracketed by an event pair; end synchronises and returns the number of
+ * launches and the sum of their durations in milliseconds. */
+int mmm_ctx_profile_begin(mmm_ctx* ctx);
+int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 
 /* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------
  * (no counterpart in the reference, which is single-threaded; replaces the doc loops' cross-document sums

@@ -47,6 +47,8 @@ _SIGS = {
     "mmm_ctx_synchronize": (C.c_int, [vp]),
     "mmm_ctx_stream": (vp, [vp]),
     "mmm_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "mmm_ctx_profile_begin": (C.c_int, [vp]),
+    "mmm_ctx_profile_end": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
     "mmm_comm_nranks": (C.c_int, [vp]),
@@ -144,6 +146,15 @@ class Context:
         b = C.create_string_buffer(64)
         check(lib().mmm_ctx_device_name(self.h, b, 64), self.h)
         return b.value.decode()
+
+    def profile_begin(self):
+        check(lib().mmm_ctx_profile_begin(self.h), self.h, "mmm_ctx_profile_begin")
+
+    def profile_end(self):
+        """-> (number of dominant-kernel launches, sum of their HIP-event durations in ms)"""
+        n = C.c_int(); ms = C.c_double()
+        check(lib().mmm_ctx_profile_end(self.h, C.byref(n), C.byref(ms)), self.h, "mmm_ctx_profile_end")
+        return n.value, ms.value
 
     def init_comm(self, nranks, rank, unique_id):
         check(lib().mmm_comm_init_rank(self.h, int(nranks), int(rank), unique_id), self.h, "mmm_comm_init_rank")

@@ -44,6 +44,7 @@ int mmm_ctx_destroy(mmm_ctx* ctx)
 {
     if (!ctx) return MMM_OK;
     (void)hipSetDevice(ctx->device);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
@@ -65,6 +66,32 @@ int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n)
 {
     if (!ctx || !buf || n == 0) return MMM_ERR_ARG;
     snprintf(buf, n, "%s", ctx->arch);
+    return MMM_OK;
+}
+
+int mmm_ctx_profile_begin(mmm_ctx* ctx)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ev_used = 0;
+    ctx->profiling = true;
+    return MMM_OK;
+}
+
+int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms)
+{
+    if (!ctx || !n_launches || !total_ms) return MMM_ERR_ARG;
+    ctx->profiling = false;
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        MMM_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        tot += ms;
+    }
+    *n_launches = (int)(ctx->ev_used / 2);
+    *total_ms = tot;
+    ctx->ev_used = 0;
     return MMM_OK;
 }
 

@@ -697,7 +697,8 @@ int mmm_lda_iterate(mmm_lda* m, int n_iter)
         }
         // update_ϕ! + the document loop of update_λ! + next pass's update_γ!, fused (LDA.jl:69-76,103-105,85-87)
         EstepArgs a{m->dev(), m->gamma.p, m->Elntheta.p, m->gamma_next.p, m->expElnbeta.p, m->partial.p, nullptr};
-        if ((rc = launch_estep<MODE_FUSED>(m, a, m->lds_e))) return rc;
+        { ProfSpan span(ctx); rc = launch_estep<MODE_FUSED>(m, a, m->lds_e); }
+        if (rc) return rc;
         m->phi_valid = false; m->gnext_valid = true;
         hipLaunchKernelGGL(k_reduce_slabs, dim3((VK + 63) / 64), dim3(64, 16), 0, ctx->stream, m->partial.p, m->grid_e, VK, m->stats.p);
         MMM_LAUNCH_CHECK(ctx);

@@ -23,6 +23,23 @@ struct mmm_ctx {
     int num_cu = 256;
     std::string err;
     char arch[64] = {0};
+    // HIP-event spans around the dominant kernel (mmm_ctx_profile_begin/end)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;   // pairs: ev[2i] start, ev[2i+1] stop
+    size_t ev_used = 0;
+};
+
+// RAII span: records an event pair around a launch while profiling is on
+struct ProfSpan {
+    mmm_ctx* ctx; bool on;
+    explicit ProfSpan(mmm_ctx* c) : ctx(c), on(c->profiling) {
+        if (!on) return;
+        if (ctx->ev_used + 2 > ctx->ev.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } ctx->ev.push_back(e); }
+        }
+        (void)hipEventRecord(ctx->ev[ctx->ev_used], ctx->stream);
+    }
+    ~ProfSpan() { if (on) { (void)hipEventRecord(ctx->ev[ctx->ev_used + 1], ctx->stream); ctx->ev_used += 2; } }
 };
 
 extern thread_local std::string g_mmm_create_error;
