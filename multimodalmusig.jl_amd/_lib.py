@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmmmusig_hip.so")
+LIB_PATH = os.environ.get("MMM_LIB_PATH") or os.path.join(_HERE, "lib", "libmmmusig_hip.so")
 _LIB = None
 
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")

@@ -4,24 +4,12 @@
 
 #define MMM_WAVE 64
 
-// digamma, same algorithm as SpecialFunctions.jl (reflection for x <= 0, recurrence to x >= 7, 8-term
-// asymptotic series); call sites it replaces: LDA.jl:79,97; MMCTM.jl:218; IMMCTM.jl:192-193.
-__device__ __forceinline__ double dev_digamma(double x)
+// digamma for any real x, same algorithm as SpecialFunctions.jl (reflection for x <= 0, recurrence to x >= 7,
+// 8-term asymptotic series); call sites it replaces: LDA.jl:79,97; MMCTM.jl:218; IMMCTM.jl:192-193.
+__device__ __forceinline__ double dev_digamma_series(double x)   // x >= 7
 {
-    double psi = 0.0;
-    if (x <= 0.0) {
-        psi -= M_PI / tan(M_PI * x);
-        x = 1.0 - x;
-    }
-    if (x < 7.0) {
-        // psi(x) = psi(x+n) - sum_{v=0}^{n-1} 1/(x+v); pair the terms to halve the divisions
-        int n = 7 - (int)floor(x);
-        for (int v = 1; v < n; ++v) psi -= 1.0 / (x + (double)v);
-        psi -= 1.0 / x;
-        x += (double)n;
-    }
     double t = 1.0 / x;
-    psi += log(x) - 0.5 * t;
+    double psi = log(x) - 0.5 * t;
     t *= t;
     double p = -0.4432598039215686;
     p = fma(p, t, 0.08333333333333333);
@@ -31,13 +19,42 @@ __device__ __forceinline__ double dev_digamma(double x)
     p = fma(p, t, 0.003968253968253968);
     p = fma(p, t, -0.008333333333333333);
     p = fma(p, t, 0.08333333333333333);
-    psi -= t * p;
-    return psi;
+    return psi - t * p;
+}
+
+// x > 0 (every argument on the hot path is a Dirichlet parameter).  Branch-free form of the same recurrence:
+// psi(x) = psi(x+7) - sum_{v=0}^{6} 1/(x+v), with the sum evaluated as Q'(x)/Q(x), Q = prod (x+v): one division
+// instead of up to seven, no data-dependent trip count (lanes of a wave hold very different x).
+__device__ __forceinline__ double dev_digamma_pos(double x)
+{
+    double q = x, dq = 1.0;
+#pragma unroll
+    for (int v = 1; v < 7; ++v) {
+        const double f = x + (double)v;
+        dq = fma(dq, f, q);
+        q *= f;
+    }
+    return dev_digamma_series(x + 7.0) - dq / q;
+}
+
+__device__ __forceinline__ double dev_digamma(double x)
+{
+    if (x > 0.0 && x < 1e40) return dev_digamma_pos(x);
+    double psi = 0.0;
+    if (x <= 0.0) { psi -= M_PI / tan(M_PI * x); x = 1.0 - x; }
+    if (x < 7.0) {
+        int n = 7 - (int)floor(x);
+        for (int v = 1; v < n; ++v) psi -= 1.0 / (x + (double)v);
+        psi -= 1.0 / x;
+        x += (double)n;
+    }
+    return psi + dev_digamma_series(x);
 }
 
 // x*log(x) with the reference's 0^0 = 1 convention of log(x^x) (LDA.jl:157; MMCTM.jl:365)
 __device__ __forceinline__ double dev_xlogx(double x) { return x > 0.0 ? x * log(x) : 0.0; }
 
+// ---- cross-lane ---------------------------------------------------------------------------------------
 // full-wave (64 lanes) butterfly sum: every lane ends with the total
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -52,3 +69,28 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 __device__ __forceinline__ double wave_bcast(double v, int lane) { return __shfl(v, lane, MMM_WAVE); }
+
+// DPP move of a double (two 32-bit halves); CTRL is a DPP control word (quad_perm 0x00-0xFF, row_shr 0x110+n,
+// row_mirror 0x140, row_half_mirror 0x141)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over each aligned group of L lanes (L = 16, 32 or 64); every lane of the group ends with the group total.
+// The 16-lane part stays inside a DPP row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
+template <int L>
+__device__ __forceinline__ double group_sum(double v)
+{
+    v += dpp_mov_f64<0xB1>(v);
+    v += dpp_mov_f64<0x4E>(v);
+    v += dpp_mov_f64<0x141>(v);
+    v += dpp_mov_f64<0x140>(v);
+    if (L >= 32) v += __shfl_xor(v, 16, MMM_WAVE);
+    if (L >= 64) v += __shfl_xor(v, 32, MMM_WAVE);
+    return v;
+}

@@ -1,29 +1,41 @@
 // lda.hip -- LDA variational EM on gfx950 (replaces the hot path of src/LDA.jl)
 //
-// Data layout in HBM (per context / model handle)
+// Data layout in HBM (per model handle)
 //   corpus     doc_ptr int64[D+1]; tc int2[nnz] = (term0, count) interleaved -> one 8-byte load per nonzero
-//   topics     lambda, Elnbeta, beta, expElnbeta: [k][v] (= the reference's V x K column-major), V*K doubles
-//   documents  gamma, gamma_next, Elntheta, theta: [d][k] (= K x D column-major)
-//   phi        [nnz][K] (= per-doc K x W_d blocks, k fastest); written only when asked for (see below)
+//   topics     lambda, Elnbeta, expElnbeta, beta: [k][v] (= the reference's V x K column-major), V*K doubles,
+//              each a ring of 3 slots indexed by (iteration mod 3)
+//   documents  gamma, Elntheta: [d][k] (= K x D column-major), rings of 3; theta [d][k] on demand
+//   phi        [nnz][K] (= per-doc K x W_d blocks, k fastest); materialised only when asked for
+//   ctl        device control block: ticket, stop flag, iteration counter t, ll-history length
 //
-// Hot path = k_lda_estep<KP, FUSED>: one wavefront per document, lanes over the document's nonzero terms.
-//   * Elntheta_k = psi(gamma_k) - psi(sum gamma) on lanes 0..K (LDA.jl:78-80)
-//   * phi_kw  = a_k * B_vk / sum_k a_k B_vk with a_k = exp(Elntheta_k) (K exps per document) and
-//     B = exp(Elnbeta) (V*K exps per iteration, staged in LDS): algebraically exp(Elntheta_k + Elnbeta_vk) of
-//     LDA.jl:71-74 without one exp per (term, topic)
-//   * lambda scatter (LDA.jl:103-105): term ids are unique inside a document, so a wave adds into its private
-//     LDS slab [K][V] with plain read-modify-write (no atomics, deterministic); slabs are reduced per block and
-//     written as one partial per block; k_reduce_slabs sums the partials in fixed order
-//   * gamma of the NEXT iteration (LDA.jl:85-87 uses the previous phi) = alpha + sum_w phi_kw n_w is formed in
-//     the same pass, so phi never round-trips through HBM inside the loop.  phi is materialised on demand
-//     (mmm_lda_get(PHI), ELBO) from (Elntheta, previous Elnbeta), which reproduces the stored phi exactly.
+// One outer iteration t (the body of fit!, LDA.jl:201-209) = TWO kernels on one GPU:
+//
+// k_lda_estep<KP, L> (dominant): a wave handles 64/L documents at a time, L lanes per document (L = 16 for
+//   K <= 15), lanes over the document's nonzero terms.
+//   * Elntheta_k = psi(gamma_k) - psi(sum gamma) on the first K+1 lanes of the group (LDA.jl:78-80)
+//   * phi_kw = a_k B_vk / sum_k a_k B_vk with a_k = exp(Elntheta_k) (K exps per document) and B = exp(Elnbeta)
+//     (V*K exps per iteration, staged in LDS): algebraically exp(Elntheta_k + Elnbeta_vk) of LDA.jl:71-74
+//     without one exp per (term, topic)
+//   * lambda scatter (LDA.jl:103-105) into the wave's private LDS slab [K][V] with ds_add_f64; slabs are summed
+//     per block in fixed order and written as one partial per block
+//   * gamma of iteration t+1 (LDA.jl:85-87 uses the previous phi) = alpha + sum_w phi_kw n_w is formed in the
+//     same pass with DPP row reductions, so phi never round-trips through HBM inside the loop; phi is
+//     materialised on demand from (Elntheta_t, Elnbeta_{t-1}), which reproduces the stored phi
+//   * the log-likelihood of iteration t-1 (LDA.jl:174-188: needs beta_{t-1}, only known after M-step t-1) is
+//     evaluated in the same sweep from gamma_{t-1} and beta_{t-1} ("lagged ll"): one pass over X per
+//     iteration instead of two, and on several GPUs its numerator rides in the same all-reduce as lambda
+// k_lda_reduce_mstep: sums the per-block partials in fixed order (deterministic); the last block to arrive
+//   (agent-scope release/acquire + ticket) runs the M-step tail: lambda = eta + sums, Elnbeta, exp table, beta
+//   (LDA.jl:96-112), ll_{t-1}, the convergence test of common.jl:53-56 (device-side stop flag) and t += 1.
+//   With an RCCL communicator the tail is a third, one-block kernel after the all-reduce.
 #include "dev_math.h"
 #include "mmm_internal.h"
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;                    // stage kernels
 constexpr int kBlock = kWavesPerBlock * MMM_WAVE;
+constexpr int kMaxWavesE = 8;                        // fused E-step kernel: up to 512 threads
 
 struct LdaDev {
     int D, V, K;
@@ -32,112 +44,366 @@ struct LdaDev {
     double alpha, eta;
 };
 
-enum { MODE_FUSED = 0, MODE_PHI = 1 };
+struct LdaCtl {
+    unsigned int ticket;
+    int stop;        // 1 once the convergence criterion was met (later launches exit at once)
+    int stop_iter;   // iteration at which it was met
+    int t;           // completed iterations
+    int n_hist;      // ll values written
+    int pad[3];
+};
+
+struct Ring { double* s[3]; };
 
 struct EstepArgs {
     LdaDev c;
-    const double* gamma;      // FUSED: in
-    double* Elntheta;         // FUSED: out, PHI: in
-    double* gamma_next;       // FUSED: out
-    const double* expElnbeta; // [K][V]
-    double* partial;          // FUSED: [gridDim][K*V]
-    double* phi;              // PHI: out
+    const LdaCtl* ctl;
+    Ring gamma, Elntheta, expElnbeta, beta;
+    double* partial;   // [gridDim][K*V]
+    double* llpart;    // [gridDim]
+    int do_ll;
+    int t;             // this pass (1-based); the host's count, valid unless ctl->stop is set
 };
 
-template <int KP, int MODE>
-__global__ __launch_bounds__(kBlock) void k_lda_estep(EstepArgs a)
+#ifdef MMM_DIAG_STAMPS
+// diagnostic build only (make diag): s_memtime stamps of block 0 / wave 0 through the fused E-step kernel.
+__device__ unsigned long long g_lda_stamps[16];
+#define MMM_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        unsigned long long t_;                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_lda_stamps[i] = t_;                                       \
+    } while (0)
+#else
+#define MMM_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void lds_wave_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int K = a.c.K, V = a.c.V, D = a.c.D;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    double* sB = smem;                                  // [KP][V]
-    double* sSlab = smem + (size_t)KP * V;              // [waves][KP][V] (FUSED only)
-    for (int i = tid; i < KP * V; i += kBlock) sB[i] = (i < K * V) ? a.expElnbeta[i] : 0.0;
-    if (MODE == MODE_FUSED)
-        for (int i = tid; i < kWavesPerBlock * KP * V; i += kBlock) sSlab[i] = 0.0;
-    __syncthreads();
-    double* slab = sSlab + (size_t)wid * KP * V;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-    for (int d = blockIdx.x * kWavesPerBlock + wid; d < D; d += gridDim.x * kWavesPerBlock) {
-        double el;
-        if (MODE == MODE_FUSED) {
-            const double g = (lane < K) ? a.gamma[(size_t)d * K + lane] : 0.0;
-            const double S = wave_sum(g);
-            const double ps = dev_digamma(lane < K ? g : S);          // lane K (and above) holds psi(S)
-            el = ps - wave_bcast(ps, K);
-            if (lane < K) a.Elntheta[(size_t)d * K + lane] = el;
-        } else {
-            el = (lane < K) ? a.Elntheta[(size_t)d * K + lane] : 0.0;
-        }
-        const double ak = (lane < K) ? exp(el) : 0.0;
-        double av[KP];
+// one chunk of L terms of a document group: phi_kw n_w into the accumulators and the wave's slab, and (LL) the
+// log-likelihood numerator of the previous iteration.  __restrict__ tells the compiler that the slab atomics do not
+// alias the table reads, so the reads of the following chunk can be issued ahead of them.
+template <int KP, bool LL>
+__device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const int V, const double (&av)[KP], double (&acc)[KP],
+                                          const double* __restrict__ sB, const double* __restrict__ sBeta,
+                                          const double* __restrict__ myT, double* __restrict__ slab, double& ll_acc)
+{
+    const double* bcol = sB + tcv.x;
+    double b[KP], s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) av[k] = wave_bcast(ak, k);
-
-        double acc[KP];
+    for (int k = 0; k < KP; ++k) b[k] = av[k] * bcol[k * V];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) acc[k] = 0.0;
-        const int64_t start = a.c.doc_ptr[d];
-        const int W = (int)(a.c.doc_ptr[d + 1] - start);
-        for (int w0 = 0; w0 < W; w0 += MMM_WAVE) {
-            const int w = w0 + lane;
-            const bool act = w < W;
-            int2 t = act ? a.c.tc[start + w] : make_int2(0, 0);
-            const int v = t.x;
-            double e[KP], s = 0.0;
+    for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
+    if (KP & 1) s0 += b[KP - 1];
+    const double n = (double)tcv.y;
+    const double r = act ? n / (s0 + s1) : 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) { e[k] = av[k] * sB[k * V + v]; s += e[k]; }
-            if (MODE == MODE_FUSED) {
-                const double r = act ? (double)t.y / s : 0.0;
+    for (int k = 0; k < KP; ++k) { b[k] *= r; acc[k] += b[k]; }        // phi_kw * n_w (padded topics: exact zeros)
+    if (act) {
+        double* scol = slab + tcv.x;
 #pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    if (k < K) {
-                        const double pn = e[k] * r;
-                        acc[k] += pn;
-                        if (act) slab[k * V + v] += pn;
-                    }
-                }
-            } else if (act) {
-                double* ph = a.phi + (size_t)(start + w) * K;
-#pragma unroll
-                for (int k = 0; k < KP; ++k) if (k < K) ph[k] = e[k] / s;
-            }
-        }
-        if (MODE == MODE_FUSED) {
-            double mine = 0.0;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                if (k < K) { const double tot = wave_sum(acc[k]); if (lane == k) mine = tot; }
-            }
-            if (lane < K) a.gamma_next[(size_t)d * K + lane] = a.c.alpha + mine;
-        }
+#if defined(MMM_DIAG_NOATOMIC)
+        for (int k = 0; k < KP; ++k) asm volatile("" ::"v"(b[k]), "v"(scol));   // timing experiment only: no slab update
+#elif defined(MMM_DIAG_PLAINRMW)
+        for (int k = 0; k < KP; ++k) scol[k * V] += b[k];                        // timing experiment only: racy
+#else
+        for (int k = 0; k < KP; ++k) unsafeAtomicAdd(&scol[k * V], b[k]);
+#endif
     }
-    if (MODE == MODE_FUSED) {
-        __syncthreads();
-        double* out = a.partial + (size_t)blockIdx.x * K * V;
-        for (int i = tid; i < K * V; i += kBlock) {
-            double s = 0.0;
+    if (LL) {
+        const double* bc = sBeta + tcv.x;
+        double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < kWavesPerBlock; ++w) s += sSlab[(size_t)w * KP * V + i];
-            out[i] = s;
-        }
+        for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(myT[k], bc[k * V], p0); p1 = fma(myT[k + 1], bc[(k + 1) * V], p1); }
+        if (KP & 1) p0 = fma(myT[KP - 1], bc[(KP - 1) * V], p0);
+        ll_acc += n * log(p0 + p1);                                      // inactive lanes: n = 0
     }
 }
 
-// partial[nslab][n] -> out[n], fixed summation order (deterministic)
-__global__ __launch_bounds__(1024) void k_reduce_slabs(const double* __restrict__ part, int nslab, int n, double* __restrict__ out)
+template <int KP, int L, bool LL, int VT>
+__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, 3) void k_lda_estep(EstepArgs a)
 {
-    __shared__ double s[16][64];
-    const int e = blockIdx.x * 64 + threadIdx.x, y = threadIdx.y;
-    double acc = 0.0;
-    if (e < n) for (int sl = y; sl < nslab; sl += 16) acc += part[(size_t)sl * n + e];
-    s[y][threadIdx.x] = acc;
-    __syncthreads();
-    if (y == 0 && e < n) {
-        double t = 0.0;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int G = MMM_WAVE / L;                   // documents per wave step
+    constexpr int PRE = (96 + L - 1) / L;             // chunks whose (term,count) pairs are prefetched into registers
+    MMM_STAMP(0);
+    const int t = a.t;
+    const int stop = a.ctl->stop;                     // consumed after the first prologue (its latency is hidden)
+    const double* __restrict__ gam = a.gamma.s[t % 3];
+    const double* __restrict__ gprev = a.gamma.s[(t + 2) % 3];
+    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
+    double* __restrict__ Eln = a.Elntheta.s[t % 3];
+    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
+    const double* __restrict__ bprev = a.beta.s[(t + 2) % 3];
+
+    const int K = a.c.K, D = a.c.D;
+    const int V = VT ? VT : a.c.V;                    // VT != 0: row stride known at compile time (immediate LDS offsets)
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
+    double* sB = smem;                                   // [KP][V] exp(Elnbeta_{t-1})
+    double* sBeta = sB + (size_t)KP * V;                 // [KP][V] beta_{t-1}
+    double* sSlab = sBeta + (size_t)KP * V;              // [NW][KP][V]
+    double* sA = sSlab + (size_t)NW * KP * V;            // [NW][G][KP]
+    double* sT = sA + (size_t)NW * G * KP;               // [NW][G][KP]
+    double* slab = sSlab + (size_t)wid * KP * V;
+    double* myA = sA + ((size_t)wid * G + g) * KP;
+    double* myT = sT + ((size_t)wid * G + g) * KP;
+    const int stride = gridDim.x * NW * G;
+    int base = (blockIdx.x * NW + wid) * G;
+    double ll_acc = 0.0;
+
+    // ---- document loads of the first step are issued before the tables are staged (latency overlap) -------------
+    int d = base + g;
+    bool valid = d < D;
+    double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+    double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+    int64_t start = valid ? a.c.doc_ptr[d] : 0;
+    int W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+    for (int i = tid; i < KP * V; i += blockDim.x) {
+        sB[i] = (i < K * V) ? eB[i] : 0.0;
+        sBeta[i] = (LL && i < K * V) ? bprev[i] : 0.0;
+    }
+    for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
+    MMM_STAMP(1);
+
+    bool first = true;
+    for (;;) {
+        // ---- prefetch the document's (term,count) pairs; groups start at rotated chunks so that the G documents of
+        //      a wave instruction touch different term ranges of the slab ----------------------------------------
+        const int nch = (W + L - 1) / L;
+        const int rot = nch > 0 ? g % nch : 0;
+        const int2* __restrict__ tcd = a.c.tc + start;
+        int2 tcp[PRE];
+        bool actp[PRE];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t += s[j][threadIdx.x];
-        out[e] = t;
+        for (int j = 0; j < PRE; ++j) {
+            int c = j + rot; if (c >= nch) c -= nch;
+            const int w = c * L + l;
+            actp[j] = (j < nch) && (w < W);
+            tcp[j] = actp[j] ? tcd[w] : make_int2(0, 0);
+        }
+        // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k), theta_{t-1} (LDA.jl:92-94) ------------------------------
+        const double S = group_sum<L>(gk);
+        const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
+        const double psS = __shfl(ps, g * L + K, MMM_WAVE);
+        const double el = ps - psS;
+        if (l < KP) myA[l] = (l < K) ? exp(el) : 0.0;
+        if (LL) {
+            const double Sp = group_sum<L>(gp);
+            if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+        }
+        if (first) {
+            if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
+            __syncthreads();
+            first = false;
+            MMM_STAMP(2);
+        } else lds_wave_sync();
+        if (valid && l < K) Eln[(size_t)d * K + l] = el;
+        MMM_STAMP(3);
+        {
+            double av[KP], acc[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < PRE; ++j)
+                if (__any(j < nch)) lda_chunk<KP, LL>(tcp[j], actp[j], V, av, acc, sB, sBeta, myT, slab, ll_acc);
+            for (int j = PRE; __any(j < nch); ++j) {
+                int c = j + rot; if (c >= nch) c -= nch;
+                const int w = c * L + l;
+                const bool act = (j < nch) && (w < W);
+                const int2 tcv = act ? tcd[w] : make_int2(0, 0);
+                lda_chunk<KP, LL>(tcv, act, V, av, acc, sB, sBeta, myT, slab, ll_acc);
+            }
+            MMM_STAMP(4);
+            // ---- gamma_{t+1} = alpha + sum_w phi_kw n_w (LDA.jl:83-87 of the next pass) ---------------------------
+            double mine = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { const double tot = group_sum<L>(acc[k]); if (l == k) mine = tot; }
+            if (valid && l < K) gnext[(size_t)d * K + l] = a.c.alpha + mine;
+        }
+        MMM_STAMP(5);
+        base += stride;
+        if (base >= D) break;
+        // ---- loads of the next step ------------------------------------------------------------------------------
+        d = base + g; valid = d < D;
+        gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+        gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+        start = valid ? a.c.doc_ptr[d] : 0;
+        W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+        lds_wave_sync();
+    }
+    MMM_STAMP(6);
+    // ---- block epilogue: slabs -> one partial; ll partial ------------------------------------------------------
+    ll_acc = wave_sum(ll_acc);
+    __syncthreads();
+    if (lane == 0) sA[wid] = ll_acc;      // sA is free now
+    double* out = a.partial + (size_t)blockIdx.x * K * V;
+    for (int i = tid; i < K * V; i += blockDim.x) {
+        double v8[kMaxWavesE];
+#pragma unroll
+        for (int w = 0; w < kMaxWavesE; ++w) v8[w] = (w < NW) ? sSlab[(size_t)w * KP * V + i] : 0.0;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kMaxWavesE; ++w) s += v8[w];
+        out[i] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += sA[w];
+        a.llpart[blockIdx.x] = s;
+    }
+    MMM_STAMP(7);
+}
+
+// ---- M-step tail (one block of 1024 threads): LDA.jl:96-112 + ll + convergence (common.jl:53-56) ---------------
+struct TailArgs {
+    int V, K;
+    double eta, Nglobal, tol;
+    LdaCtl* ctl;
+    int t;                 // this pass (host count)
+    Ring lambda, Elnbeta, expElnbeta, beta;
+    const double* stats;   // [V*K] summed lambda statistics, [V*K] ll numerator
+    double* ll_hist;
+    int do_ll, conv_base;
+};
+
+__device__ void lda_mstep_tail(const TailArgs& r, double* sh /* V*K + 2*K doubles */)
+{
+    const int V = r.V, K = r.K, VK = V * K;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
+    const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    const int t = r.t;
+    double* lam = r.lambda.s[t % 3];
+    double* Elnb = r.Elnbeta.s[t % 3];
+    double* eB = r.expElnbeta.s[t % 3];
+    double* bet = r.beta.s[t % 3];
+    double* sLam = sh; double* sCol = sh + VK; double* sPsi = sCol + K;
+    for (int e = tid; e < VK; e += nthr) { const double l = r.eta + r.stats[e]; lam[e] = l; sLam[e] = l; }
+    __syncthreads();
+    for (int k = wid; k < K; k += nw) {
+        double part = 0.0;
+        for (int v = lane; v < V; v += 64) part += sLam[k * V + v];
+        part = wave_sum(part);
+        if (lane == 0) { sCol[k] = part; sPsi[k] = dev_digamma_pos(part); }
+    }
+    __syncthreads();
+    for (int e = tid; e < VK; e += nthr) {
+        const int k = e / V;
+        const double l = sLam[e];
+        const double el = dev_digamma_pos(l) - sPsi[k];
+        Elnb[e] = el; eB[e] = exp(el); bet[e] = l / sCol[k];
+    }
+    if (tid == 0) {
+        int stop = 0;
+        if (r.do_ll) {
+            const int n = r.ctl->n_hist;
+            const double ll = r.stats[VK] / r.Nglobal;
+            r.ll_hist[n] = ll;
+            r.ctl->n_hist = n + 1;
+            if (n + 1 - r.conv_base > 10) {                      // common.jl:53-56 after > 10 values (LDA.jl:215)
+                const double prev = r.ll_hist[n - 1];
+                if (fabs(prev - ll) / fabs(ll) < r.tol) { stop = 1; r.ctl->stop = 1; r.ctl->stop_iter = t - 1; }
+            }
+        }
+        if (!stop) r.ctl->t = t;     // on convergence at t-1 the state of iteration t is discarded
+        r.ctl->ticket = 0;
+    }
+}
+
+struct ReduceArgs {
+    const double* partial; const double* llpart; int nslab;
+    double* stats;
+    int run_tail;
+    TailArgs tail;
+};
+
+// grid = ceil(V*K/64) blocks of (64,16): fixed-order sum of the per-block partials; the last block to arrive sums
+// the ll partials and (single GPU) runs the M-step tail.
+__global__ __launch_bounds__(1024) void k_lda_reduce_mstep(ReduceArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_last;
+    if (r.tail.ctl->stop) return;
+    const int VK = r.tail.V * r.tail.K;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    const int e = blockIdx.x * 64 + tx;
+    double acc = 0.0;
+    if (e < VK) for (int sl = ty; sl < r.nslab; sl += 16) acc += r.partial[(size_t)sl * VK + e];
+    smem[ty * 64 + tx] = acc;
+    __syncthreads();
+    if (ty == 0 && e < VK) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tsum += smem[j * 64 + tx];
+        r.stats[e] = tsum;
+    }
+    // publish (agent-scope release) and take a ticket; the last arriver acquires and continues
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(&r.tail.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1);
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 64) {
+        double s = 0.0;
+        for (int i = tid; i < r.nslab; i += 64) s += r.llpart[i];
+        s = wave_sum(s);
+        if (tid == 0) r.stats[VK] = s;
+    }
+    __syncthreads();
+    if (r.run_tail) lda_mstep_tail(r.tail, smem);
+    else if (tid == 0) r.tail.ctl->ticket = 0;
+}
+
+__global__ __launch_bounds__(1024) void k_lda_tail(TailArgs t)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (t.ctl->stop) return;
+    lda_mstep_tail(t, smem);
+}
+
+// ---- on-demand / stage kernels (reference-granularity entry points; not on the fused path) -----------------------
+// phi = softmax_k(Elntheta + Elnbeta[v]) written to HBM (update_ϕ!, LDA.jl:69-76); one wave per document
+template <int KP>
+__global__ __launch_bounds__(kBlock) void k_lda_phi(LdaDev c, const double* Elntheta, const double* expElnbeta, double* phi)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int K = c.K, V = c.V;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < KP * V; i += kBlock) smem[i] = (i < K * V) ? expElnbeta[i] : 0.0;
+    __syncthreads();
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        const double ak = (lane < K) ? exp(Elntheta[(size_t)d * K + lane]) : 0.0;
+        double av[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) av[k] = wave_bcast(ak, k);
+        const int64_t start = c.doc_ptr[d];
+        const int W = (int)(c.doc_ptr[d + 1] - start);
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int v = c.tc[start + w].x;
+            double e[KP], s = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { e[k] = av[k] * smem[k * V + v]; s += e[k]; }
+            double* ph = phi + (size_t)(start + w) * K;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) if (k < K) ph[k] = e[k] / s;
+        }
     }
 }
 
@@ -152,9 +418,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh)
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// M-step per topic k (one block per topic): lambda = eta + sums (LDA.jl:101-105), Elnbeta (LDA.jl:96-98),
-// beta (LDA.jl:110-112), and the exp(Elnbeta) table of the next E-step.
-__global__ __launch_bounds__(256) void k_lda_mstep(int V, double eta, const double* sums, double* lambda, double* Elnbeta,
+// per topic k (one block per topic): lambda = eta + sums (if sums), Elnbeta / exp table (if Elnbeta), beta (if write_beta)
+__global__ __launch_bounds__(256) void k_lda_topic(int V, double eta, const double* sums, double* lambda, double* Elnbeta,
                                                    double* expElnbeta, double* beta, int write_beta)
 {
     __shared__ double sh[4];
@@ -184,8 +449,7 @@ __global__ void k_exp_table(int n, const double* in, double* out)
     if (i < n) out[i] = exp(in[i]);
 }
 
-// theta = gamma / sum gamma (LDA.jl:92-94) and the per-iteration log-likelihood numerator (LDA.jl:174-188)
-// one wave per document; beta staged in LDS.  llpart[blockIdx] = sum over the block's documents.
+// theta = gamma / sum gamma (LDA.jl:92-94) and the log-likelihood numerator (LDA.jl:174-188), wave per document
 template <int KP>
 __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* gamma, const double* beta, double* theta,
                                                        double* llpart, int compute_ll)
@@ -203,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
         const double g = (lane < K) ? gamma[(size_t)d * K + lane] : 0.0;
         const double S = wave_sum(g);
         const double th = g / S;
-        if (lane < K) theta[(size_t)d * K + lane] = th;
+        if (lane < K && theta) theta[(size_t)d * K + lane] = th;
         if (!compute_ll) continue;
         double tv[KP];
 #pragma unroll
@@ -215,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
             const int2 t = c.tc[start + w];
             double p = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) p += tv[k] * smem[k * V + t.x];
+            for (int k = 0; k < KP; ++k) p = fma(tv[k], smem[k * V + t.x], p);
             acc += (double)t.y * log(p);
         }
         wave_ll += wave_sum(acc);
@@ -227,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
     }
 }
 
-// out[j] = sum_i part[i*stride + j], j < nvals  (one wave per j)
+// out[j] = sum_i part[i*stride + j], j < gridDim.x  (one wave per j)
 __global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, int stride, double* out)
 {
     const int j = blockIdx.x;
@@ -237,10 +501,17 @@ __global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, i
     if (threadIdx.x == 0) out[j] = acc;
 }
 
-__global__ void k_ll_store(const double* num, double N, double* dst) { *dst = *num / N; }
+// push ll = num/N onto the device history (standalone ll of the last pass)
+__global__ void k_ll_push(LdaCtl* ctl, const double* num, double N, double* hist, double* also)
+{
+    const double ll = *num / N;
+    if (hist) { hist[ctl->n_hist] = ll; ctl->n_hist += 1; }
+    if (also) *also = ll;
+}
 
-// ---- stage kernels (reference-granularity entry points; not on the fused path) ----------------------------
-// gamma[:,d] = alpha + phi[d] * n_d (LDA.jl:83-87) from a resident phi, then Elntheta
+__global__ void k_ctl_clear_stop(LdaCtl* ctl) { ctl->stop = 0; ctl->stop_iter = 0; ctl->ticket = 0; }
+
+// gamma[:,d] = alpha + phi[d] * n_d (LDA.jl:83-87) from a resident phi, then Elntheta (if asked)
 __global__ __launch_bounds__(kBlock) void k_lda_gamma_from_phi(LdaDev c, const double* phi, double* gamma, double* Elntheta)
 {
     const int K = c.K;
@@ -256,10 +527,13 @@ __global__ __launch_bounds__(kBlock) void k_lda_gamma_from_phi(LdaDev c, const d
             if (lane == k) mine = acc;
         }
         const double g = (lane < K) ? c.alpha + mine : 0.0;
-        const double S = wave_sum(g);
-        const double ps = dev_digamma(lane < K ? g : S);
-        const double el = ps - wave_bcast(ps, K);
-        if (lane < K) { gamma[(size_t)d * K + lane] = g; Elntheta[(size_t)d * K + lane] = el; }
+        if (lane < K) gamma[(size_t)d * K + lane] = g;
+        if (Elntheta) {
+            const double S = wave_sum(g);
+            const double ps = dev_digamma(lane < K ? g : S);
+            const double el = ps - wave_bcast(ps, K);
+            if (lane < K) Elntheta[(size_t)d * K + lane] = el;
+        }
     }
 }
 
@@ -348,7 +622,7 @@ __global__ void k_fill(double* p, size_t n, double v)
     if (i < n) p[i] = v;
 }
 
-__global__ void k_doc_counts(LdaDev c, double* out)   // out[0] += sum of counts (via per-thread partials)
+__global__ void k_doc_counts(LdaDev c, double* out)
 {
     double acc = 0.0;
     const int64_t nnz = c.doc_ptr[c.D];
@@ -362,19 +636,30 @@ __global__ void k_doc_counts(LdaDev c, double* out)   // out[0] += sum of counts
 // ---------------------------------------------------------------------------------------------------------
 struct mmm_lda {
     mmm_ctx* ctx = nullptr;
-    int D = 0, V = 0, K = 0, KP = 0;
+    int D = 0, V = 0, K = 0, KP = 0, L = 16;
     int64_t nnz = 0;
     double alpha = 0, eta = 0;
     double Nglobal = 0, Dglobal = 0;
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc;
-    DevBuf<double> lambda, Elnbeta, Elnbeta_prev, expElnbeta, expElnbeta_prev, beta;
-    DevBuf<double> gamma, gamma_next, Elntheta, theta, phi;
+    DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
+    DevBuf<double> theta, phi;
     DevBuf<double> partial, stats, llpart, elbopart, ll_hist;
-    bool phi_valid = false, gnext_valid = false;
-    int n_hist = 0, cap_hist = 0;
-    int grid_e = 1;
-    size_t lds_e = 0, lds_ll = 0;
+    DevBuf<LdaCtl> ctl;
+    // host mirror of the device control block (exact after sync_ctl)
+    int t = 0, n_hist = 0, cap_hist = 0;
+    bool inflight = false;      // fused passes enqueued since the last sync_ctl
+    bool phi_valid = false;     // phi buffer == phi of the current state
+    bool phi_from_prev = false; // current phi is implied by (Elntheta_t, Elnbeta_{t-1}) (after fused passes)
+    bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
+    bool ll_pending = false;    // the ll of pass t has not been recorded yet
+    bool theta_valid = false;
+    bool attr_e[2] = {false, false}, attr_tail = false;
+    bool stop_seen = false;     // the device stop flag may be set
+    int grid_e = 1, waves_e = 8, grid_s = 1;
+    size_t lds_e = 0, lds_tab = 0;
     LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta}; }
+    int cur() const { return t % 3; }
+    Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
 
 namespace {
@@ -386,98 +671,119 @@ int pick_kp(int K)
     return -1;
 }
 
-template <int MODE>
-int launch_estep(mmm_lda* m, const EstepArgs& a, size_t lds)
+#define MMM_KP_SWITCH(m, ...)                                                                                   \
+    switch ((m)->KP) {                                                                                          \
+        case 2: { constexpr int KPV = 2; __VA_ARGS__ } break;                                                          \
+        case 4: { constexpr int KPV = 4; __VA_ARGS__ } break;                                                          \
+        case 6: { constexpr int KPV = 6; __VA_ARGS__ } break;                                                          \
+        case 8: { constexpr int KPV = 8; __VA_ARGS__ } break;                                                          \
+        case 10: { constexpr int KPV = 10; __VA_ARGS__ } break;                                                        \
+        case 12: { constexpr int KPV = 12; __VA_ARGS__ } break;                                                        \
+        case 16: { constexpr int KPV = 16; __VA_ARGS__ } break;                                                        \
+        case 20: { constexpr int KPV = 20; __VA_ARGS__ } break;                                                        \
+        case 24: { constexpr int KPV = 24; __VA_ARGS__ } break;                                                        \
+        case 32: { constexpr int KPV = 32; __VA_ARGS__ } break;                                                        \
+        default: return mmm_fail((m)->ctx, MMM_ERR_UNSUPPORTED, "LDA: K=%d not supported (max 32)", (m)->K);    \
+    }
+
+template <typename Kern>
+int set_lds(mmm_ctx* ctx, Kern kern, size_t lds)
+{
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MMM_OK;
+}
+
+template <int KPV, int LV, bool LLV, int VT>
+int go_estep2(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
-#define MMM_CASE(KPV)                                                                                          \
-    case KPV: {                                                                                                \
-        auto kern = k_lda_estep<KPV, MODE>;                                                                    \
-        if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(m->grid_e), dim3(kBlock), lds, ctx->stream, a);                           \
-        break;                                                                                                 \
-    }
-    switch (m->KP) {
-        MMM_CASE(2) MMM_CASE(4) MMM_CASE(6) MMM_CASE(8) MMM_CASE(10) MMM_CASE(12) MMM_CASE(16) MMM_CASE(20) MMM_CASE(24) MMM_CASE(32)
-        default: return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: K=%d not supported (max 32)", m->K);
-    }
-#undef MMM_CASE
+    auto k = k_lda_estep<KPV, LV, LLV, VT>;
+    if (!m->attr_e[LLV]) { int rc = set_lds(ctx, k, m->lds_e); if (rc) return rc; m->attr_e[LLV] = true; }
+    hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_e, ctx->stream, a);
+    return MMM_OK;
+}
+
+template <int KPV, int LV, bool LLV>
+int go_estep(mmm_lda* m, const EstepArgs& a)
+{
+    // the 96-term SNV vocabulary (data/brca-eu_snv_counts.tsv; every BASELINE config) gets compile-time strides
+    if constexpr (LV == 16 && (KPV == 8 || KPV == 10)) { if (m->V == 96) return go_estep2<KPV, LV, LLV, 96>(m, a); }
+    return go_estep2<KPV, LV, LLV, 0>(m, a);
+}
+
+int launch_estep(mmm_lda* m, const EstepArgs& a)
+{
+    mmm_ctx* ctx = m->ctx;
+    int rc = MMM_OK;
+    MMM_KP_SWITCH(m, {
+        if (m->L == 16) { if constexpr (KPV <= 16) rc = a.do_ll ? go_estep<KPV, 16, true>(m, a) : go_estep<KPV, 16, false>(m, a); }
+        else if (m->L == 32) { if constexpr (KPV >= 16) rc = a.do_ll ? go_estep<KPV, 32, true>(m, a) : go_estep<KPV, 32, false>(m, a); }
+        else { if constexpr (KPV == 32) rc = a.do_ll ? go_estep<KPV, 64, true>(m, a) : go_estep<KPV, 64, false>(m, a); }
+    })
+    if (rc) return rc;
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
-int launch_loglik(mmm_lda* m, int compute_ll)
+int launch_phi(mmm_lda* m, const double* Elntheta, const double* expElnbeta)
 {
     mmm_ctx* ctx = m->ctx;
-    size_t lds = compute_ll ? m->lds_ll : 0;
-#define MMM_CASE(KPV)                                                                                          \
-    case KPV: {                                                                                                \
-        auto kern = k_lda_loglik<KPV>;                                                                         \
-        if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(m->grid_e), dim3(kBlock), lds, ctx->stream, m->dev(), m->gamma.p, m->beta.p, m->theta.p, m->llpart.p, compute_ll); \
-        break;                                                                                                 \
-    }
-    switch (m->KP) {
-        MMM_CASE(2) MMM_CASE(4) MMM_CASE(6) MMM_CASE(8) MMM_CASE(10) MMM_CASE(12) MMM_CASE(16) MMM_CASE(20) MMM_CASE(24) MMM_CASE(32)
-        default: return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: K=%d not supported (max 32)", m->K);
-    }
-#undef MMM_CASE
+    MMM_KP_SWITCH(m, {
+        auto k = k_lda_phi<KPV>; int rc;
+        if ((rc = set_lds(ctx, k, m->lds_tab))) return rc;
+        hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), m->lds_tab, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+    })
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
-// lambda = eta + all-reduced sums; Elnbeta (previous one kept for phi materialisation); beta; exp table
-int run_mstep(mmm_lda* m, bool from_sums)
+int launch_loglik(mmm_lda* m, const double* gamma, const double* beta, double* theta, int compute_ll)
 {
     mmm_ctx* ctx = m->ctx;
-    if (from_sums) {
-        int rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)m->V * m->K);
-        if (rc) return rc;
-    }
-    m->Elnbeta.swap(m->Elnbeta_prev);
-    m->expElnbeta.swap(m->expElnbeta_prev);
-    hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(256), 0, ctx->stream, m->V, m->eta, from_sums ? m->stats.p : nullptr,
-                       m->lambda.p, m->Elnbeta.p, m->expElnbeta.p, m->beta.p, 0);
+    const size_t lds = compute_ll ? m->lds_tab : 0;
+    MMM_KP_SWITCH(m, {
+        auto k = k_lda_loglik<KPV>; int rc;
+        if ((rc = set_lds(ctx, k, lds))) return rc;
+        hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), lds, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+    })
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
-int run_beta(mmm_lda* m)
+// bring the host mirror of the control block up to date (needed after fused passes that may have stopped early)
+int sync_ctl(mmm_lda* m)
 {
-    hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(256), 0, m->ctx->stream, m->V, m->eta, (const double*)nullptr, m->lambda.p,
-                       (double*)nullptr, (double*)nullptr, m->beta.p, 1);
-    MMM_LAUNCH_CHECK(m->ctx);
+    if (!m->inflight) return MMM_OK;
+    mmm_ctx* ctx = m->ctx;
+    LdaCtl h;
+    MMM_HIP(ctx, hipMemcpyAsync(&h, m->ctl.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool stopped = h.stop != 0;
+    if (stopped) m->stop_seen = true;
+    m->t = h.t; m->n_hist = h.n_hist;
+    m->inflight = false;
+    m->ll_pending = !stopped;          // after a stop the ll of the kept iteration is already recorded
     return MMM_OK;
 }
 
-// materialise phi of the last fused iteration: softmax_k(Elntheta + previous Elnbeta) (LDA.jl:69-76)
+// phi of the current state: after fused passes it is softmax_k(Elntheta_t + Elnbeta_{t-1}) (LDA.jl:69-76)
 int materialise_phi(mmm_lda* m)
 {
+    int rc = sync_ctl(m);
+    if (rc) return rc;
     if (m->phi_valid) return MMM_OK;
-    EstepArgs a{m->dev(), nullptr, m->Elntheta.p, nullptr, m->expElnbeta_prev.p, nullptr, m->phi.p};
-    int rc = launch_estep<MODE_PHI>(m, a, (size_t)m->KP * m->V * sizeof(double));
-    if (rc) return rc;
+    const int c = m->cur(), p = (m->t + 2) % 3;
+    if ((rc = launch_phi(m, m->Elntheta[c].p, m->phi_from_prev ? m->expElnbeta[p].p : m->expElnbeta[c].p))) return rc;
     m->phi_valid = true;
-    return MMM_OK;
-}
-
-int ll_to_history(mmm_lda* m, double* dst_dev)
-{
-    mmm_ctx* ctx = m->ctx;
-    double* num = m->stats.p + (size_t)m->V * m->K;
-    hipLaunchKernelGGL(k_sum_columns, dim3(1), dim3(64), 0, ctx->stream, m->llpart.p, m->grid_e, 1, num);
-    MMM_LAUNCH_CHECK(ctx);
-    int rc = mmm_allreduce_sum(ctx, num, 1);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ll_store, dim3(1), dim3(1), 0, ctx->stream, num, m->Nglobal, dst_dev);
-    MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
 int ensure_hist(mmm_lda* m, int extra)
 {
-    if (m->n_hist + extra <= m->cap_hist) return MMM_OK;
-    int cap = std::max(2 * m->cap_hist, m->n_hist + extra + 64);
+    if (m->n_hist + extra + 2 <= m->cap_hist) return MMM_OK;
+    int rc = sync_ctl(m);
+    if (rc) return rc;
+    const int cap = std::max(2 * m->cap_hist, m->n_hist + extra + 66);
     DevBuf<double> nb;
     MMM_HIP(m->ctx, nb.alloc(cap));
     if (m->n_hist) MMM_HIP(m->ctx, hipMemcpyAsync(nb.p, m->ll_hist.p, sizeof(double) * m->n_hist, hipMemcpyDeviceToDevice, m->ctx->stream));
@@ -487,7 +793,101 @@ int ensure_hist(mmm_lda* m, int extra)
     return MMM_OK;
 }
 
+// record the ll of the current state (LDA.jl:174-188, 209) when the lagged evaluation has not covered it yet
+int flush_ll(mmm_lda* m, double* also_dev)
+{
+    int rc = sync_ctl(m);
+    if (rc) return rc;
+    if (!m->ll_pending && !also_dev) return MMM_OK;
+    mmm_ctx* ctx = m->ctx;
+    const int c = m->cur();
+    if ((rc = ensure_hist(m, 1))) return rc;
+    if ((rc = launch_loglik(m, m->gamma[c].p, m->beta[c].p, m->theta.p, 1))) return rc;
+    m->theta_valid = true;
+    double* num = m->stats.p + (size_t)m->V * m->K;
+    hipLaunchKernelGGL(k_sum_columns, dim3(1), dim3(64), 0, ctx->stream, m->llpart.p, m->grid_s, 1, num);
+    MMM_LAUNCH_CHECK(ctx);
+    if ((rc = mmm_allreduce_sum(ctx, num, 1))) return rc;
+    const bool push = m->ll_pending;
+    hipLaunchKernelGGL(k_ll_push, dim3(1), dim3(1), 0, ctx->stream, m->ctl.p, num, m->Nglobal, push ? m->ll_hist.p : nullptr, also_dev);
+    MMM_LAUNCH_CHECK(ctx);
+    if (push) { m->n_hist++; m->ll_pending = false; }
+    return MMM_OK;
+}
+
+// lambda[c] = eta + all-reduced sums; Elnbeta[c], exp table (stage path, in place on the current slot)
+int run_topic_update(mmm_lda* m, bool from_sums)
+{
+    mmm_ctx* ctx = m->ctx;
+    const int c = m->cur();
+    if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)m->V * m->K); if (rc) return rc; }
+    hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, ctx->stream, m->V, m->eta, from_sums ? m->stats.p : nullptr,
+                       m->lambda[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, 0);
+    MMM_LAUNCH_CHECK(ctx);
+    return MMM_OK;
+}
+
+int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
+{
+    mmm_ctx* ctx = m->ctx;
+    int rc;
+    if ((rc = ensure_hist(m, n_iter))) return rc;
+    if (!m->gnext_valid) {
+        // update_γ! for the first pass (LDA.jl:82-90) from the resident phi
+        if ((rc = materialise_phi(m))) return rc;
+        hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
+        MMM_LAUNCH_CHECK(ctx);
+        m->gnext_valid = true;
+    }
+    const int VK = m->V * m->K;
+    const size_t lds_tail = sizeof(double) * std::max<size_t>(1024, (size_t)VK + 2 * m->K);
+    if (!m->attr_tail) {
+        if ((rc = set_lds(ctx, k_lda_reduce_mstep, lds_tail))) return rc;
+        if ((rc = set_lds(ctx, k_lda_tail, lds_tail))) return rc;
+        m->attr_tail = true;
+    }
+    for (int it = 0; it < n_iter; ++it) {
+        const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
+        EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
+                    m->partial.p, m->llpart.p, do_ll, m->t + 1};
+        { ProfSpan span(ctx); rc = launch_estep(m, a); }
+        if (rc) return rc;
+        TailArgs tl{m->V, m->K, m->eta, m->Nglobal, tol, m->ctl.p, m->t + 1, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta),
+                    m->ring(m->beta), m->stats.p, m->ll_hist.p, do_ll, conv_base};
+        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, m->stats.p, ctx->nranks <= 1 ? 1 : 0, tl};
+        hipLaunchKernelGGL(k_lda_reduce_mstep, dim3((VK + 63) / 64), dim3(64, 16), lds_tail, ctx->stream, r);
+        MMM_LAUNCH_CHECK(ctx);
+        if (ctx->nranks > 1) {
+            if ((rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)VK + 1))) return rc;
+            hipLaunchKernelGGL(k_lda_tail, dim3(1), dim3(1024), lds_tail, ctx->stream, tl);
+            MMM_LAUNCH_CHECK(ctx);
+        }
+        // host mirror, assuming no early stop (sync_ctl corrects it)
+        if (do_ll) m->n_hist++;
+        m->t++;
+        m->ll_pending = true;
+    }
+    if (n_iter > 0) {
+        m->inflight = true;
+        m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
+    }
+    return MMM_OK;
+}
+
+int prepare_call(mmm_lda* m)
+{
+    MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    return sync_ctl(m);
+}
+
 } // namespace
+
+#ifdef MMM_DIAG_STAMPS
+extern "C" int mmm_diag_lda_stamps(unsigned long long out[16])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lda_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" {
 
@@ -497,7 +897,6 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     if (!ctx) return MMM_ERR_ARG;
     MMM_CHECK(ctx, out && doc_ptr && lambda0, "mmm_lda_create: NULL argument");
     MMM_CHECK(ctx, D >= 0 && V >= 1 && K >= 1, "mmm_lda_create: bad sizes D=%d V=%d K=%d", D, V, K);
-    MMM_CHECK(ctx, K < 64, "mmm_lda_create: K=%d must be < 64", K);
     *out = nullptr;
     const int KP = pick_kp(K);
     if (KP < 0) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K=%d not supported (max 32)", K);
@@ -509,35 +908,48 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
         MMM_CHECK(ctx, term[e] >= 0 && term[e] < V && count[e] >= 0, "mmm_lda_create: entry %lld out of range (term %d, count %d)", (long long)e, term[e], count[e]);
         tc[(size_t)e] = make_int2(term[e], count[e]);
     }
-    const size_t lds_e = (size_t)KP * V * (1 + kWavesPerBlock) * sizeof(double);
-    if (lds_e > 160 * 1024)
-        return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K*V = %d*%d needs %zu B of LDS (> 160 KiB)", K, V, lds_e);
+    const int L = (K <= 15) ? 16 : (K <= 31 ? 32 : 64);
+    const int G = MMM_WAVE / L;
+    // waves per block of the fused kernel: as many as fit 160 KiB of LDS next to the two tables, at most 8
+    const size_t tabB = (size_t)KP * V * sizeof(double);
+    // 6 waves per block: the kernel is built for 3 waves per SIMD (<= 168 VGPRs), so two 6-wave blocks fill a CU
+    int waves = 6;
+    auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
+    while (waves > 1 && lds_for(waves) > 80 * 1024) --waves;
+    if (lds_for(waves) > 160 * 1024)
+        return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K*V = %d*%d needs %zu B of LDS (> 160 KiB)", K, V, lds_for(waves));
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_lda* m = new mmm_lda();
-    m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
-    m->lds_e = lds_e; m->lds_ll = (size_t)KP * V * sizeof(double);
+    m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
+    m->waves_e = waves; m->lds_e = lds_for(waves); m->lds_tab = tabB;
+    if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= kMaxWavesE && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
-    const int max_blocks_lds = (int)std::max<size_t>(1, (160 * 1024) / lds_e);
-    const int per_cu = std::min(2, max_blocks_lds);
-    m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * per_cu));
-    if (const char* g = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(g));
+    const int docs_per_block = m->waves_e * G;
+    const int blocks_per_cu = std::max(1, std::min<int>(12 / m->waves_e, (int)((160 * 1024) / m->lds_e)));
+    m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
+    if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
+    m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
+    const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
-    A(lambda, VK); A(Elnbeta, VK); A(Elnbeta_prev, VK); A(expElnbeta, VK); A(expElnbeta_prev, VK); A(beta, VK);
-    A(gamma, KD); A(gamma_next, KD); A(Elntheta, KD); A(theta, KD); A(phi, (size_t)K * nnz);
-    A(partial, (size_t)m->grid_e * VK); A(stats, VK + 16); A(llpart, (size_t)m->grid_e); A(elbopart, (size_t)m->grid_e * 5 + 8);
+    for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
+    A(theta, KD); A(phi, (size_t)K * nnz);
+    A(partial, (size_t)m->grid_e * VK); A(stats, VK + 16); A(llpart, (size_t)grid_max); A(elbopart, (size_t)m->grid_s * 5 + 8);
+    A(ctl, 1);
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * (D + 1), hipMemcpyHostToDevice, st));
     if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->lambda.p, lambda0, sizeof(double) * VK, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->lambda[0].p, lambda0, sizeof(double) * VK, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemsetAsync(m->ctl.p, 0, sizeof(LdaCtl), st));
+    if (KD) MMM_HIP(ctx, hipMemsetAsync(m->theta.p, 0, sizeof(double) * KD, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
-    hipLaunchKernelGGL(k_lda_mstep, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda.p, m->Elnbeta.p, m->expElnbeta.p, m->beta.p, 0);
+    hipLaunchKernelGGL(k_lda_topic, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda[0].p, m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, 0);
     if (KD) {
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma.p, KD, 1.0);
-        hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_e), dim3(kBlock), 0, st, m->dev(), m->gamma.p, m->Elntheta.p);
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma[0].p, KD, 1.0);
+        hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
     }
     if (nnz) hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)K * nnz + 255) / 256)), dim3(256), 0, st, m->phi.p, (size_t)K * nnz, 1.0 / K);
     MMM_HIP(ctx, hipMemsetAsync(m->stats.p, 0, sizeof(double) * (VK + 16), st));
@@ -556,7 +968,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
         MMM_HIP(ctx, hipStreamSynchronize(st));
     }
     m->Nglobal = hd[0]; m->Dglobal = hd[1];
-    m->phi_valid = true; m->gnext_valid = false;
+    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false; m->ll_pending = false; m->theta_valid = false;
     *out = m;
     return MMM_OK;
 }
@@ -573,12 +985,13 @@ int mmm_lda_destroy(mmm_lda* m)
 static int lda_field(mmm_lda* m, int field, double** p, size_t* n)
 {
     const size_t VK = (size_t)m->V * m->K, KD = (size_t)m->K * m->D;
+    const int c = m->cur();
     switch (field) {
-        case MMM_LDA_LAMBDA: *p = m->lambda.p; *n = VK; break;
-        case MMM_LDA_ELNBETA: *p = m->Elnbeta.p; *n = VK; break;
-        case MMM_LDA_BETA: *p = m->beta.p; *n = VK; break;
-        case MMM_LDA_GAMMA: *p = m->gamma.p; *n = KD; break;
-        case MMM_LDA_ELNTHETA: *p = m->Elntheta.p; *n = KD; break;
+        case MMM_LDA_LAMBDA: *p = m->lambda[c].p; *n = VK; break;
+        case MMM_LDA_ELNBETA: *p = m->Elnbeta[c].p; *n = VK; break;
+        case MMM_LDA_BETA: *p = m->beta[c].p; *n = VK; break;
+        case MMM_LDA_GAMMA: *p = m->gamma[c].p; *n = KD; break;
+        case MMM_LDA_ELNTHETA: *p = m->Elntheta[c].p; *n = KD; break;
         case MMM_LDA_THETA: *p = m->theta.p; *n = KD; break;
         case MMM_LDA_PHI: *p = m->phi.p; *n = (size_t)m->K * m->nnz; break;
         default: return mmm_fail(m->ctx, MMM_ERR_ARG, "unknown LDA field %d", field);
@@ -590,12 +1003,16 @@ int mmm_lda_get(mmm_lda* m, int field, double* host, size_t n)
 {
     if (!m) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
-    double* p; size_t cnt;
-    int rc = lda_field(m, field, &p, &cnt);
+    int rc = prepare_call(m);
     if (rc) return rc;
+    double* p; size_t cnt;
+    if ((rc = lda_field(m, field, &p, &cnt))) return rc;
     MMM_CHECK(ctx, host && n == cnt, "mmm_lda_get(field %d): expected %zu doubles, got %zu", field, cnt, n);
     if (field == MMM_LDA_PHI && (rc = materialise_phi(m))) return rc;
+    if (field == MMM_LDA_THETA && !m->theta_valid && m->t > 0) {       // fit! leaves theta = gamma/sum (LDA.jl:207)
+        if ((rc = launch_loglik(m, m->gamma[m->cur()].p, nullptr, m->theta.p, 0))) return rc;
+        m->theta_valid = true;
+    }
     if (n) MMM_HIP(ctx, hipMemcpyAsync(host, p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
@@ -605,16 +1022,19 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
 {
     if (!m) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
-    double* p; size_t cnt;
-    int rc = lda_field(m, field, &p, &cnt);
+    int rc = prepare_call(m);
     if (rc) return rc;
+    double* p; size_t cnt;
+    if ((rc = lda_field(m, field, &p, &cnt))) return rc;
     MMM_CHECK(ctx, host && n == cnt, "mmm_lda_set(field %d): expected %zu doubles, got %zu", field, cnt, n);
     if ((rc = materialise_phi(m))) return rc;     // make the implicit phi explicit before state is overwritten
-    m->gnext_valid = false;
+    if ((rc = flush_ll(m, nullptr))) return rc;
+    m->gnext_valid = false; m->phi_from_prev = false;
+    if (field == MMM_LDA_THETA) m->theta_valid = true;
+    if (field == MMM_LDA_GAMMA) m->theta_valid = false;
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (field == MMM_LDA_ELNBETA && n) {
-        hipLaunchKernelGGL(k_exp_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, m->Elnbeta.p, m->expElnbeta.p);
+        hipLaunchKernelGGL(k_exp_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, m->Elnbeta[m->cur()].p, m->expElnbeta[m->cur()].p);
         MMM_LAUNCH_CHECK(ctx);
     }
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -624,23 +1044,23 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
 int mmm_lda_update_gamma(mmm_lda* m)
 {
     if (!m) return MMM_ERR_ARG;
-    MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
-    int rc = materialise_phi(m);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_e), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma.p, m->Elntheta.p);
+    int rc = prepare_call(m);
+    if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
+    const int c = m->cur();
+    hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p);
     MMM_LAUNCH_CHECK(m->ctx);
-    m->gnext_valid = false;
+    m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false;
     return MMM_OK;
 }
 
 int mmm_lda_update_phi(mmm_lda* m)
 {
     if (!m) return MMM_ERR_ARG;
-    MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
-    EstepArgs a{m->dev(), nullptr, m->Elntheta.p, nullptr, m->expElnbeta.p, nullptr, m->phi.p};
-    int rc = launch_estep<MODE_PHI>(m, a, (size_t)m->KP * m->V * sizeof(double));
-    if (rc) return rc;
-    m->phi_valid = true; m->gnext_valid = false;
+    int rc = prepare_call(m);
+    if (rc || (rc = flush_ll(m, nullptr))) return rc;
+    const int c = m->cur();
+    if ((rc = launch_phi(m, m->Elntheta[c].p, m->expElnbeta[c].p))) return rc;
+    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false;
     return MMM_OK;
 }
 
@@ -648,31 +1068,47 @@ int mmm_lda_update_lambda(mmm_lda* m)
 {
     if (!m) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = materialise_phi(m);
-    if (rc) return rc;
+    int rc = prepare_call(m);
+    if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
     MMM_HIP(ctx, hipMemsetAsync(m->stats.p, 0, sizeof(double) * (size_t)m->V * m->K, ctx->stream));
     if (m->nnz) hipLaunchKernelGGL(k_lda_lambda_from_phi, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, ctx->stream, m->dev(), m->nnz, m->phi.p, m->stats.p);
     MMM_LAUNCH_CHECK(ctx);
-    m->gnext_valid = false;
-    return run_mstep(m, true);
+    m->gnext_valid = false; m->phi_from_prev = false;
+    return run_topic_update(m, true);
 }
 
-int mmm_lda_update_beta(mmm_lda* m) { if (!m) return MMM_ERR_ARG; MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return run_beta(m); }
+int mmm_lda_update_beta(mmm_lda* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prepare_call(m);
+    if (rc) return rc;
+    const int c = m->cur();
+    hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, m->ctx->stream, m->V, m->eta, (const double*)nullptr, m->lambda[c].p,
+                       (double*)nullptr, (double*)nullptr, m->beta[c].p, 1);
+    MMM_LAUNCH_CHECK(m->ctx);
+    return MMM_OK;
+}
 
-int mmm_lda_update_theta(mmm_lda* m) { if (!m) return MMM_ERR_ARG; MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return launch_loglik(m, 0); }
+int mmm_lda_update_theta(mmm_lda* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prepare_call(m);
+    if (rc) return rc;
+    if ((rc = launch_loglik(m, m->gamma[m->cur()].p, nullptr, m->theta.p, 0))) return rc;
+    m->theta_valid = true;
+    return MMM_OK;
+}
 
 int mmm_lda_loglik(mmm_lda* m, double* ll)
 {
     if (!m || !ll) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
-    // the reference evaluates with the stored theta and beta (LDA.jl:194-196); this entry point recomputes
-    // theta from gamma first, which is what fit! has just done (LDA.jl:207) -- beta must be current.
-    int rc = launch_loglik(m, 1);
+    int rc = prepare_call(m);
     if (rc) return rc;
+    // the reference evaluates with the stored theta and beta (LDA.jl:194-196); this entry point recomputes theta from
+    // gamma first, which is what fit! has just done (LDA.jl:207) -- beta must be current (update_β! or a fused pass).
     double* dst = m->stats.p + (size_t)m->V * m->K + 4;
-    if ((rc = ll_to_history(m, dst))) return rc;
+    if ((rc = flush_ll(m, dst))) return rc;
     MMM_HIP(ctx, hipMemcpyAsync(ll, dst, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
@@ -684,40 +1120,20 @@ int mmm_lda_iterate(mmm_lda* m, int n_iter)
     mmm_ctx* ctx = m->ctx;
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     MMM_CHECK(ctx, n_iter >= 0, "mmm_lda_iterate: n_iter < 0");
-    int rc = ensure_hist(m, n_iter);
-    if (rc) return rc;
-    const int VK = m->V * m->K;
-    for (int it = 0; it < n_iter; ++it) {
-        // update_γ! (LDA.jl:82-90): gamma for this pass was formed from the previous pass's phi
-        if (m->gnext_valid) m->gamma.swap(m->gamma_next);
-        else {
-            if ((rc = materialise_phi(m))) return rc;
-            hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma.p, m->Elntheta.p);
-            MMM_LAUNCH_CHECK(ctx);
-        }
-        // update_ϕ! + the document loop of update_λ! + next pass's update_γ!, fused (LDA.jl:69-76,103-105,85-87)
-        EstepArgs a{m->dev(), m->gamma.p, m->Elntheta.p, m->gamma_next.p, m->expElnbeta.p, m->partial.p, nullptr};
-        { ProfSpan span(ctx); rc = launch_estep<MODE_FUSED>(m, a, m->lds_e); }
-        if (rc) return rc;
-        m->phi_valid = false; m->gnext_valid = true;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3((VK + 63) / 64), dim3(64, 16), 0, ctx->stream, m->partial.p, m->grid_e, VK, m->stats.p);
+    if (m->stop_seen) {      // a previous fit! left the device stop flag set
+        hipLaunchKernelGGL(k_ctl_clear_stop, dim3(1), dim3(1), 0, ctx->stream, m->ctl.p);
         MMM_LAUNCH_CHECK(ctx);
-        // update_λ! tail, update_Elnβ! (LDA.jl:96-108)
-        if ((rc = run_mstep(m, true))) return rc;
-        // update_β!, update_θ!, log-likelihood (LDA.jl:206-209)
-        if ((rc = run_beta(m))) return rc;
-        if ((rc = launch_loglik(m, 1))) return rc;
-        if ((rc = ll_to_history(m, m->ll_hist.p + m->n_hist))) return rc;
-        m->n_hist++;
+        m->stop_seen = false;
     }
-    return MMM_OK;
+    return fused_passes(m, n_iter, -1.0, 0);
 }
 
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)
 {
     if (!m || !n) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = prepare_call(m);
+    if (rc || (rc = flush_ll(m, nullptr))) return rc;
     const int cnt = std::min(max_n, m->n_hist);
     if (cnt > 0 && ll) MMM_HIP(ctx, hipMemcpyAsync(ll, m->ll_hist.p + (m->n_hist - cnt), sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -729,13 +1145,13 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7])
 {
     if (!m || !elbo) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    MMM_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = materialise_phi(m);
-    if (rc) return rc;
-    double* acc = m->elbopart.p + (size_t)m->grid_e * 5;      // [0..4] doc sums, [5..6] topic sums
-    hipLaunchKernelGGL(k_lda_elbo_docs, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma.p, m->Elntheta.p, m->Elnbeta.p, m->elbopart.p);
-    hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_e, 5, acc);
-    hipLaunchKernelGGL(k_lda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->V, m->K, m->lambda.p, m->Elnbeta.p, acc + 5);
+    int rc = prepare_call(m);
+    if (rc || (rc = materialise_phi(m))) return rc;
+    const int c = m->cur();
+    double* acc = m->elbopart.p + (size_t)m->grid_s * 5;      // [0..4] doc sums, [5..6] topic sums
+    hipLaunchKernelGGL(k_lda_elbo_docs, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p, m->Elnbeta[c].p, m->elbopart.p);
+    hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc);
+    hipLaunchKernelGGL(k_lda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->V, m->K, m->lambda[c].p, m->Elnbeta[c].p, acc + 5);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
     double h[7];
@@ -756,26 +1172,36 @@ int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_ite
     if (!m || !n_iter || !converged) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
     MMM_CHECK(ctx, maxiter >= 1, "mmm_lda_fit: maxiter < 1");
+    int rc = prepare_call(m);
+    if (rc || (rc = flush_ll(m, nullptr))) return rc;
+    hipLaunchKernelGGL(k_ctl_clear_stop, dim3(1), dim3(1), 0, ctx->stream, m->ctl.p);
+    MMM_LAUNCH_CHECK(ctx);
+    m->stop_seen = false;
     *converged = 0;
-    const int base = m->n_hist;
+    const int base = m->n_hist, t0 = m->t;
+    // The stopping rule (LDA.jl:215 + common.jl:53-56) is evaluated on the device in the M-step tail of pass i+1 for
+    // pass i (lagged ll); later launches are no-ops once it fires.  The host only looks at the flag between chunks.
     int done = 0;
-    std::vector<double> ll((size_t)maxiter);
-    // the convergence test needs > 10 values (LDA.jl:215): run the first 11 passes unsynchronised, then one
-    // pass per host check
-    while (done < maxiter) {
-        const int chunk = (done == 0) ? std::min(maxiter, 11) : 1;
-        int rc = mmm_lda_iterate(m, chunk);
-        if (rc) return rc;
-        MMM_HIP(ctx, hipMemcpyAsync(ll.data() + done, m->ll_hist.p + base + done, sizeof(double) * chunk, hipMemcpyDeviceToHost, ctx->stream));
-        MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        done += chunk;
-        if (done > 10) {   // common.jl:53-56
-            const double rel = fabs(ll[done - 2] - ll[done - 1]) / fabs(ll[done - 1]);
-            if (rel < tol) { *converged = 1; break; }
-        }
+    bool stopped = false;
+    while (done < maxiter && !stopped) {
+        const int chunk = std::min(maxiter - done, done == 0 ? 12 : 8);
+        if ((rc = fused_passes(m, chunk, tol, base))) return rc;
+        if ((rc = sync_ctl(m))) return rc;
+        stopped = (m->t - t0) < done + chunk;       // the device discarded passes after the criterion fired
+        done = m->t - t0;
     }
-    *n_iter = done;
-    if (ll_hist) memcpy(ll_hist, ll.data(), sizeof(double) * done);
+    if (stopped) *converged = 1;
+    else {
+        // maxiter passes ran; the ll of the last one is still pending and its convergence test is done here
+        if ((rc = flush_ll(m, nullptr))) return rc;
+    }
+    const int n = m->n_hist - base;
+    std::vector<double> ll((size_t)std::max(n, 1));
+    if (n > 0) MMM_HIP(ctx, hipMemcpyAsync(ll.data(), m->ll_hist.p + base, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!stopped && n > 10 && fabs(ll[n - 2] - ll[n - 1]) / fabs(ll[n - 1]) < tol) *converged = 1;
+    *n_iter = n;
+    if (ll_hist) memcpy(ll_hist, ll.data(), sizeof(double) * n);
     if (elbo) return mmm_lda_elbo(m, elbo, nullptr);
     return MMM_OK;
 }

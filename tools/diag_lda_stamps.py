@@ -1,0 +1,20 @@
+"""Diagnostic (not a benchmark): in-kernel s_memtime stamps of the fused LDA E-step kernel, block 0 / wave 0.
+Usage on the GPU box: make -C multimodalmusig.jl_amd/csrc diag && MMM_LIB_PATH=.../libmmmusig_hip_diag.so python tools_diag_stamps.py [D]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, mmm_pkg, np_ref
+pkg = mmm_pkg.load()
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+X, lam0 = np_ref.synth_lda(D, 96, 10, seed=3)
+m = pkg.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
+lib = pkg.lib()
+for rep in range(3):
+    pkg._lib.check(lib.mmm_lda_iterate(m._h, 5), m.ctx.h)
+    m.ctx.synchronize()
+    st = (C.c_ulonglong * 16)()
+    lib.mmm_diag_lda_stamps.argtypes = [C.c_void_p]
+    assert lib.mmm_diag_lda_stamps(st) == 0
+    s = np.array(st[:8], dtype=np.int64)
+    names = ["args", "table stage issue", "prologue+barrier", "Eln store", "chunks", "gamma reduce", "epilogue"]
+    d = np.diff(s)
+    print("D=%d rep %d total %d cycles (memtime ticks): " % (D, rep, s[7] - s[0]) + ", ".join("%s %d" % (n, x) for n, x in zip(names, d)))
