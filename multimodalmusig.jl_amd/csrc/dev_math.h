@@ -51,6 +51,42 @@ __device__ __forceinline__ double dev_digamma(double x)
     return psi + dev_digamma_series(x);
 }
 
+// 1/x to <= 1 ulp: hardware reciprocal seed (v_rcp_f64) + two Newton steps.  ~6 instructions instead of the ~15 of
+// the IEEE division sequence; used where a quotient feeds a sum that is compared at >= 1e-11 relative.
+__device__ __forceinline__ double dev_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// natural log for finite x > 0 (normal or subnormal-free inputs: probabilities and Dirichlet parameters), fdlibm-style:
+// x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))).
+// ~35 instructions (ocml's log is ~90); error < 2 ulp.
+__device__ __forceinline__ double dev_log_pos(double x)
+{
+    int e = __builtin_amdgcn_frexp_exp(x);              // x = m * 2^e, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                                 // m in [sqrt(1/2), sqrt(2))
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = f * dev_rcp(2.0 + f);
+    const double z = s * s;
+    double R = 1.479819860511658591e-01;
+    R = fma(R, z, 1.531383769920937332e-01);
+    R = fma(R, z, 1.818357216161805012e-01);
+    R = fma(R, z, 2.222219843214978396e-01);
+    R = fma(R, z, 2.857142874366239149e-01);
+    R = fma(R, z, 3.999999999940941908e-01);
+    R = fma(R, z, 6.666666666666735130e-01);
+    R *= z;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return fma(dk, 6.93147180369123816490e-01, f - (hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+}
+
 // x*log(x) with the reference's 0^0 = 1 convention of log(x^x) (LDA.jl:157; MMCTM.jl:365)
 __device__ __forceinline__ double dev_xlogx(double x) { return x > 0.0 ? x * log(x) : 0.0; }
 

@@ -63,7 +63,43 @@ struct EstepArgs {
     double* llpart;    // [gridDim]
     int do_ll;
     int t;             // this pass (1-based); the host's count, valid unless ctl->stop is set
+    // M-step of pass t-1 folded into this kernel's prologue (from_stats): every block rebuilds the exp(Elnbeta) and
+    // beta tables in LDS from the reduced statistics; block 0 also stores the topic state of pass t-1
+    int from_stats;
+    const double* stats_prev;
+    Ring lambda, Elnbeta;
 };
+
+// lambda = eta + sums, Elnbeta, exp(Elnbeta), beta for all topics (LDA.jl:96-112) by one block.  sLam/sExp: [KP*V] LDS
+// (sLam is overwritten with exp(Elnbeta)), sBet: [KP*V] LDS, sCol/sPsi: [K] LDS.  Optional global outputs.
+template <int KP>
+__device__ __forceinline__ void lda_topics_from_stats(int K, int V, double eta, const double* __restrict__ sums, double* sLam,
+                                                      double* sBet, double* sCol, double* sPsi, double* gl, double* gE,
+                                                      double* gX, double* gB)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    for (int e = tid; e < KP * V; e += nthr) sLam[e] = (e < K * V) ? eta + sums[e] : 1.0;
+    __syncthreads();
+    for (int k = wid; k < K; k += nw) {
+        double part = 0.0;
+        for (int v = lane; v < V; v += 64) part += sLam[k * V + v];
+        part = wave_sum(part);
+        if (lane == 0) { sCol[k] = part; sPsi[k] = dev_digamma_pos(part); }
+    }
+    __syncthreads();
+    for (int e = tid; e < KP * V; e += nthr) {
+        if (e < K * V) {
+            const int k = e / V;
+            const double l = sLam[e];
+            const double el = dev_digamma_pos(l) - sPsi[k];
+            const double eb = exp(el), bt = l / sCol[k];
+            sLam[e] = eb; sBet[e] = bt;
+            if (gl) { gl[e] = l; gE[e] = el; gX[e] = eb; gB[e] = bt; }
+        } else { sLam[e] = 0.0; sBet[e] = 0.0; }
+    }
+    __syncthreads();
+}
+
 
 #ifdef MMM_DIAG_STAMPS
 // diagnostic build only (make diag): s_memtime stamps of block 0 / wave 0 through the fused E-step kernel.
@@ -75,6 +111,11 @@ __device__ unsigned long long g_lda_stamps[16];
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_lda_stamps[i] = t_;                                       \
+        if ((i) == 0 || (i) == 7) {                                                                          \
+            unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                        \
+            if (blockIdx.x == 0 && threadIdx.x == 0) g_lda_stamps[8 + ((i) != 0)] = r_;                     \
+            if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_lda_stamps[10 + ((i) != 0)] = r_;        \
+        }                                                                                                    \
     } while (0)
 #else
 #define MMM_STAMP(i) do { } while (0)
@@ -94,6 +135,16 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
                                           const double* __restrict__ sB, const double* __restrict__ sBeta,
                                           const double* __restrict__ myT, double* __restrict__ slab, double& ll_acc)
 {
+    const double n = (double)tcv.y;
+    if (LL) {
+        const double* bc = sBeta + tcv.x;
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(myT[k], bc[k * V], p0); p1 = fma(myT[k + 1], bc[(k + 1) * V], p1); }
+        if (KP & 1) p0 = fma(myT[KP - 1], bc[(KP - 1) * V], p0);
+        ll_acc = fma(n, dev_log_pos(p0 + p1), ll_acc);                    // inactive lanes: n = 0
+        __builtin_amdgcn_sched_barrier(0);                                  // keep the two halves' live ranges apart
+    }
     const double* bcol = sB + tcv.x;
     double b[KP], s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -101,37 +152,22 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
 #pragma unroll
     for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
     if (KP & 1) s0 += b[KP - 1];
-    const double n = (double)tcv.y;
-    const double r = act ? n / (s0 + s1) : 0.0;
+    const double r = act ? n * dev_rcp(s0 + s1) : 0.0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) { b[k] *= r; acc[k] += b[k]; }        // phi_kw * n_w (padded topics: exact zeros)
     if (act) {
         double* scol = slab + tcv.x;
 #pragma unroll
-#if defined(MMM_DIAG_NOATOMIC)
-        for (int k = 0; k < KP; ++k) asm volatile("" ::"v"(b[k]), "v"(scol));   // timing experiment only: no slab update
-#elif defined(MMM_DIAG_PLAINRMW)
-        for (int k = 0; k < KP; ++k) scol[k * V] += b[k];                        // timing experiment only: racy
-#else
         for (int k = 0; k < KP; ++k) unsafeAtomicAdd(&scol[k * V], b[k]);
-#endif
-    }
-    if (LL) {
-        const double* bc = sBeta + tcv.x;
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(myT[k], bc[k * V], p0); p1 = fma(myT[k + 1], bc[(k + 1) * V], p1); }
-        if (KP & 1) p0 = fma(myT[KP - 1], bc[(KP - 1) * V], p0);
-        ll_acc += n * log(p0 + p1);                                      // inactive lanes: n = 0
     }
 }
 
 template <int KP, int L, bool LL, int VT>
-__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, 3) void k_lda_estep(EstepArgs a)
+__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_estep(EstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;                   // documents per wave step
-    constexpr int PRE = (96 + L - 1) / L;             // chunks whose (term,count) pairs are prefetched into registers
+    constexpr int PRE = (96 + L - 1) / L;             // chunks prefetched into registers (covers a 96-term document)
     MMM_STAMP(0);
     const int t = a.t;
     const int stop = a.ctl->stop;                     // consumed after the first prologue (its latency is hidden)
@@ -166,28 +202,30 @@ __global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, 3) void k_lda_estep(EstepArgs
     double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     int64_t start = valid ? a.c.doc_ptr[d] : 0;
     int W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+    for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
     for (int i = tid; i < KP * V; i += blockDim.x) {
         sB[i] = (i < K * V) ? eB[i] : 0.0;
         sBeta[i] = (LL && i < K * V) ? bprev[i] : 0.0;
     }
-    for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
     MMM_STAMP(1);
 
     bool first = true;
     for (;;) {
-        // ---- prefetch the document's (term,count) pairs; groups start at rotated chunks so that the G documents of
-        //      a wave instruction touch different term ranges of the slab ----------------------------------------
+        // ---- the document's (term,count) pairs are fetched one chunk ahead; groups start at rotated chunks so that
+        //      the G documents of a wave instruction touch different term ranges of the slab --------------------
         const int nch = (W + L - 1) / L;
         const int rot = nch > 0 ? g % nch : 0;
         const int2* __restrict__ tcd = a.c.tc + start;
-        int2 tcp[PRE];
-        bool actp[PRE];
+        int nchmax = nch;
+        if (G >= 2) nchmax = max(nchmax, __shfl_xor(nchmax, 32, MMM_WAVE));
+        if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
+        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+        int2 tcp[PRE];                       // (term,count) of the first PRE chunks: loads issued before the prologue math
 #pragma unroll
         for (int j = 0; j < PRE; ++j) {
             int c = j + rot; if (c >= nch) c -= nch;
             const int w = c * L + l;
-            actp[j] = (j < nch) && (w < W);
-            tcp[j] = actp[j] ? tcd[w] : make_int2(0, 0);
+            tcp[j] = ((j < nch) && (w < W)) ? tcd[w] : make_int2(-1, 0);
         }
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k), theta_{t-1} (LDA.jl:92-94) ------------------------------
         const double S = group_sum<L>(gk);
@@ -211,14 +249,18 @@ __global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, 3) void k_lda_estep(EstepArgs
             double av[KP], acc[KP];
 #pragma unroll
             for (int k = 0; k < KP; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
+#pragma unroll 1
+            for (int j = 0; j < nchmax; ++j) {
+                int2 tcv = tcp[0];
 #pragma unroll
-            for (int j = 0; j < PRE; ++j)
-                if (__any(j < nch)) lda_chunk<KP, LL>(tcp[j], actp[j], V, av, acc, sB, sBeta, myT, slab, ll_acc);
-            for (int j = PRE; __any(j < nch); ++j) {
-                int c = j + rot; if (c >= nch) c -= nch;
-                const int w = c * L + l;
-                const bool act = (j < nch) && (w < W);
-                const int2 tcv = act ? tcd[w] : make_int2(0, 0);
+                for (int q = 1; q < PRE; ++q) tcv = (j == q) ? tcp[q] : tcv;     // register select (static indices only)
+                if (j >= PRE) {
+                    int c = j + rot; if (c >= nch) c -= nch;
+                    const int w = c * L + l;
+                    tcv = ((j < nch) && (w < W)) ? tcd[w] : make_int2(-1, 0);
+                }
+                const bool act = tcv.x >= 0;
+                tcv.x = act ? tcv.x : 0;
                 lda_chunk<KP, LL>(tcv, act, V, av, acc, sB, sBeta, myT, slab, ll_acc);
             }
             MMM_STAMP(4);
@@ -263,119 +305,88 @@ __global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, 3) void k_lda_estep(EstepArgs
     MMM_STAMP(7);
 }
 
-// ---- M-step tail (one block of 1024 threads): LDA.jl:96-112 + ll + convergence (common.jl:53-56) ---------------
-struct TailArgs {
-    int V, K;
-    double eta, Nglobal, tol;
+// ---- slab reduction + log-likelihood / stopping rule ------------------------------------------------------------
+struct ReduceArgs {
+    const double* partial; const double* llpart; int nslab; int VK;
+    double* stats;         // out: [VK] summed lambda statistics of pass t, [VK] ll numerator of pass t-1
     LdaCtl* ctl;
     int t;                 // this pass (host count)
-    Ring lambda, Elnbeta, expElnbeta, beta;
-    const double* stats;   // [V*K] summed lambda statistics, [V*K] ll numerator
+    double Nglobal, tol;
     double* ll_hist;
-    int do_ll, conv_base;
+    int do_ll, conv_base, run_tail;
 };
 
-__device__ void lda_mstep_tail(const TailArgs& r, double* sh /* V*K + 2*K doubles */)
+// ll_{t-1}, the convergence test of common.jl:53-56 after > 10 values (LDA.jl:215) and t += 1 (one thread)
+__device__ void lda_pass_tail(const ReduceArgs& r)
 {
-    const int V = r.V, K = r.K, VK = V * K;
-    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
-    const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
-    const int t = r.t;
-    double* lam = r.lambda.s[t % 3];
-    double* Elnb = r.Elnbeta.s[t % 3];
-    double* eB = r.expElnbeta.s[t % 3];
-    double* bet = r.beta.s[t % 3];
-    double* sLam = sh; double* sCol = sh + VK; double* sPsi = sCol + K;
-    for (int e = tid; e < VK; e += nthr) { const double l = r.eta + r.stats[e]; lam[e] = l; sLam[e] = l; }
-    __syncthreads();
-    for (int k = wid; k < K; k += nw) {
-        double part = 0.0;
-        for (int v = lane; v < V; v += 64) part += sLam[k * V + v];
-        part = wave_sum(part);
-        if (lane == 0) { sCol[k] = part; sPsi[k] = dev_digamma_pos(part); }
-    }
-    __syncthreads();
-    for (int e = tid; e < VK; e += nthr) {
-        const int k = e / V;
-        const double l = sLam[e];
-        const double el = dev_digamma_pos(l) - sPsi[k];
-        Elnb[e] = el; eB[e] = exp(el); bet[e] = l / sCol[k];
-    }
-    if (tid == 0) {
-        int stop = 0;
-        if (r.do_ll) {
-            const int n = r.ctl->n_hist;
-            const double ll = r.stats[VK] / r.Nglobal;
-            r.ll_hist[n] = ll;
-            r.ctl->n_hist = n + 1;
-            if (n + 1 - r.conv_base > 10) {                      // common.jl:53-56 after > 10 values (LDA.jl:215)
-                const double prev = r.ll_hist[n - 1];
-                if (fabs(prev - ll) / fabs(ll) < r.tol) { stop = 1; r.ctl->stop = 1; r.ctl->stop_iter = t - 1; }
-            }
+    int stop = 0;
+    if (r.do_ll) {
+        const int n = r.ctl->n_hist;
+        const double ll = r.stats[r.VK] / r.Nglobal;
+        r.ll_hist[n] = ll;
+        r.ctl->n_hist = n + 1;
+        if (n + 1 - r.conv_base > 10) {
+            const double prev = r.ll_hist[n - 1];
+            if (fabs(prev - ll) / fabs(ll) < r.tol) { stop = 1; r.ctl->stop = 1; r.ctl->stop_iter = r.t - 1; }
         }
-        if (!stop) r.ctl->t = t;     // on convergence at t-1 the state of iteration t is discarded
-        r.ctl->ticket = 0;
     }
+    if (!stop) r.ctl->t = r.t;     // on convergence at t-1 the state of pass t is discarded
+    r.ctl->ticket = 0;
 }
 
-struct ReduceArgs {
-    const double* partial; const double* llpart; int nslab;
-    double* stats;
-    int run_tail;
-    TailArgs tail;
-};
-
-// grid = ceil(V*K/64) blocks of (64,16): fixed-order sum of the per-block partials; the last block to arrive sums
-// the ll partials and (single GPU) runs the M-step tail.
-__global__ __launch_bounds__(1024) void k_lda_reduce_mstep(ReduceArgs r)
+// grid = ceil(V*K/16) blocks of (16 entries, 64 slab lanes): fixed-order (deterministic) sum of the per-block partials
+__global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_last;
-    if (r.tail.ctl->stop) return;
-    const int VK = r.tail.V * r.tail.K;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-    const int e = blockIdx.x * 64 + tx;
+    __shared__ double sm[64][17];
+    if (r.ctl->stop) return;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int e = blockIdx.x * 16 + tx;
     double acc = 0.0;
-    if (e < VK) for (int sl = ty; sl < r.nslab; sl += 16) acc += r.partial[(size_t)sl * VK + e];
-    smem[ty * 64 + tx] = acc;
+    if (e < r.VK) for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
+    sm[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && e < VK) {
-        double tsum = 0.0;
+    if (ty < 8) {
+        double v = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tsum += smem[j * 64 + tx];
-        r.stats[e] = tsum;
-    }
-    // publish (agent-scope release) and take a ticket; the last arriver acquires and continues
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(&r.tail.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1);
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        for (int j = 0; j < 8; ++j) v += sm[ty * 8 + j][tx];
+        sm[ty * 8][tx] = v;
     }
     __syncthreads();
-    if (!s_last) return;
-    if (tid < 64) {
-        double s = 0.0;
-        for (int i = tid; i < r.nslab; i += 64) s += r.llpart[i];
-        s = wave_sum(s);
-        if (tid == 0) r.stats[VK] = s;
+    if (ty == 0 && e < r.VK) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
+        r.stats[e] = v;
     }
-    __syncthreads();
-    if (r.run_tail) lda_mstep_tail(r.tail, smem);
-    else if (tid == 0) r.tail.ctl->ticket = 0;
+    if (blockIdx.x == 0 && ty == 1) {       // wave 1 of block 0: ll numerator of pass t-1
+        double v = 0.0;
+        for (int i = tx + 16 * 0; i < r.nslab; i += 16) v += r.llpart[i];
+        v = group_sum<16>(v);
+        if (tx == 0) r.stats[r.VK] = v;
+    }
 }
 
-__global__ __launch_bounds__(1024) void k_lda_tail(TailArgs t)
+// one block: M-step of pass t from the (all-reduced) statistics (LDA.jl:96-112), then ll_{t-1} / stopping rule / t += 1
+template <int KP>
+__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_mstep(ReduceArgs r, int K, int V, double eta, Ring lambda, Ring Elnbeta,
+                                                                     Ring expElnbeta, Ring beta)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (t.ctl->stop) return;
-    lda_mstep_tail(t, smem);
+    if (r.ctl->stop) return;
+    double* sLam = smem; double* sBet = smem + (size_t)KP * V; double* sCol = sBet + (size_t)KP * V; double* sPsi = sCol + KP;
+    const int c = r.t % 3;
+    lda_topics_from_stats<KP>(K, V, eta, r.stats, sLam, sBet, sCol, sPsi, lambda.s[c], Elnbeta.s[c], expElnbeta.s[c], beta.s[c]);
+    if (threadIdx.x == 0) lda_pass_tail(r);
+}
+
+// topic state of the current pass from its reduced statistics (same arithmetic as the E-step prologue)
+template <int KP>
+__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_finalize(int K, int V, double eta, const double* sums, double* gl,
+                                                                        double* gE, double* gX, double* gB)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* sLam = smem; double* sBet = smem + (size_t)KP * V; double* sCol = sBet + (size_t)KP * V; double* sPsi = sCol + KP;
+    lda_topics_from_stats<KP>(K, V, eta, sums, sLam, sBet, sCol, sPsi, gl, gE, gX, gB);
 }
 
 // ---- on-demand / stage kernels (reference-granularity entry points; not on the fused path) -----------------------
@@ -643,7 +654,7 @@ struct mmm_lda {
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc;
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
-    DevBuf<double> partial, stats, llpart, elbopart, ll_hist;
+    DevBuf<double> partial, stats[2], scratch, llpart, elbopart, ll_hist;
     DevBuf<LdaCtl> ctl;
     // host mirror of the device control block (exact after sync_ctl)
     int t = 0, n_hist = 0, cap_hist = 0;
@@ -653,7 +664,9 @@ struct mmm_lda {
     bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
-    bool attr_e[2] = {false, false}, attr_tail = false;
+    bool topics_pending = false; // the topic state of pass t still has to be formed from stats[t&1]
+    bool stats_valid = false;    // stats[t&1] are the M-step statistics of the current state
+    bool attr_e[2] = {false, false}, attr_m = false;
     bool stop_seen = false;     // the device stop flag may be set
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
@@ -767,6 +780,8 @@ int sync_ctl(mmm_lda* m)
 }
 
 // phi of the current state: after fused passes it is softmax_k(Elntheta_t + Elnbeta_{t-1}) (LDA.jl:69-76)
+int finalize_topics(mmm_lda* m);
+
 int materialise_phi(mmm_lda* m)
 {
     int rc = sync_ctl(m);
@@ -797,14 +812,14 @@ int ensure_hist(mmm_lda* m, int extra)
 int flush_ll(mmm_lda* m, double* also_dev)
 {
     int rc = sync_ctl(m);
-    if (rc) return rc;
+    if (rc || (rc = finalize_topics(m))) return rc;
     if (!m->ll_pending && !also_dev) return MMM_OK;
     mmm_ctx* ctx = m->ctx;
     const int c = m->cur();
     if ((rc = ensure_hist(m, 1))) return rc;
     if ((rc = launch_loglik(m, m->gamma[c].p, m->beta[c].p, m->theta.p, 1))) return rc;
     m->theta_valid = true;
-    double* num = m->stats.p + (size_t)m->V * m->K;
+    double* num = m->scratch.p + (size_t)m->V * m->K;
     hipLaunchKernelGGL(k_sum_columns, dim3(1), dim3(64), 0, ctx->stream, m->llpart.p, m->grid_s, 1, num);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, num, 1))) return rc;
@@ -820,8 +835,8 @@ int run_topic_update(mmm_lda* m, bool from_sums)
 {
     mmm_ctx* ctx = m->ctx;
     const int c = m->cur();
-    if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)m->V * m->K); if (rc) return rc; }
-    hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, ctx->stream, m->V, m->eta, from_sums ? m->stats.p : nullptr,
+    if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->scratch.p, (size_t)m->V * m->K); if (rc) return rc; }
+    hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, ctx->stream, m->V, m->eta, from_sums ? m->scratch.p : nullptr,
                        m->lambda[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, 0);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
@@ -840,44 +855,64 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         m->gnext_valid = true;
     }
     const int VK = m->V * m->K;
-    const size_t lds_tail = sizeof(double) * std::max<size_t>(1024, (size_t)VK + 2 * m->K);
-    if (!m->attr_tail) {
-        if ((rc = set_lds(ctx, k_lda_reduce_mstep, lds_tail))) return rc;
-        if ((rc = set_lds(ctx, k_lda_tail, lds_tail))) return rc;
-        m->attr_tail = true;
-    }
+    const size_t lds_m = sizeof(double) * (2 * (size_t)m->KP * m->V + 2 * m->KP);
     for (int it = 0; it < n_iter; ++it) {
+        const int t = m->t + 1;
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
+        const int from_stats = 0;
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, do_ll, m->t + 1};
+                    m->partial.p, m->llpart.p, do_ll, t, from_stats, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
         { ProfSpan span(ctx); rc = launch_estep(m, a); }
         if (rc) return rc;
-        TailArgs tl{m->V, m->K, m->eta, m->Nglobal, tol, m->ctl.p, m->t + 1, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta),
-                    m->ring(m->beta), m->stats.p, m->ll_hist.p, do_ll, conv_base};
-        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, m->stats.p, ctx->nranks <= 1 ? 1 : 0, tl};
-        hipLaunchKernelGGL(k_lda_reduce_mstep, dim3((VK + 63) / 64), dim3(64, 16), lds_tail, ctx->stream, r);
+        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
+        hipLaunchKernelGGL(k_lda_reduce, dim3((VK + 15) / 16), dim3(16, 64), 0, ctx->stream, r);
         MMM_LAUNCH_CHECK(ctx);
-        if (ctx->nranks > 1) {
-            if ((rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)VK + 1))) return rc;
-            hipLaunchKernelGGL(k_lda_tail, dim3(1), dim3(1024), lds_tail, ctx->stream, tl);
-            MMM_LAUNCH_CHECK(ctx);
-        }
+        if ((rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
+        MMM_KP_SWITCH(m, {
+            auto k = k_lda_mstep<KPV>;
+            if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds_m))) return rc; m->attr_m = true; }
+            hipLaunchKernelGGL(k, dim3(1), dim3(kMaxWavesE * MMM_WAVE), lds_m, ctx->stream, r, m->K, m->V, m->eta, m->ring(m->lambda),
+                               m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta));
+        })
+        MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
         if (do_ll) m->n_hist++;
-        m->t++;
+        m->t = t;
         m->ll_pending = true;
     }
     if (n_iter > 0) {
         m->inflight = true;
         m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
+        m->topics_pending = false; m->stats_valid = true;
     }
+    return MMM_OK;
+}
+
+// form lambda/Elnbeta/exp(Elnbeta)/beta of the current pass from its statistics (they are otherwise produced by
+// the next pass's E-step prologue)
+int finalize_topics(mmm_lda* m)
+{
+    if (!m->topics_pending) return MMM_OK;
+    mmm_ctx* ctx = m->ctx;
+    const int c = m->cur();
+    const size_t lds = sizeof(double) * (2 * (size_t)m->KP * m->V + 2 * m->KP);
+    MMM_KP_SWITCH(m, {
+        auto k = k_lda_finalize<KPV>; int rc;
+        if ((rc = set_lds(ctx, k, lds))) return rc;
+        hipLaunchKernelGGL(k, dim3(1), dim3(m->waves_e * MMM_WAVE), lds, ctx->stream, m->K, m->V, m->eta, m->stats[m->t & 1].p,
+                           m->lambda[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p);
+    })
+    MMM_LAUNCH_CHECK(ctx);
+    m->topics_pending = false;
     return MMM_OK;
 }
 
 int prepare_call(mmm_lda* m)
 {
     MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
-    return sync_ctl(m);
+    int rc = sync_ctl(m);
+    if (rc) return rc;
+    return finalize_topics(m);
 }
 
 } // namespace
@@ -912,8 +947,8 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     const int G = MMM_WAVE / L;
     // waves per block of the fused kernel: as many as fit 160 KiB of LDS next to the two tables, at most 8
     const size_t tabB = (size_t)KP * V * sizeof(double);
-    // 6 waves per block: the kernel is built for 3 waves per SIMD (<= 168 VGPRs), so two 6-wave blocks fill a CU
-    int waves = 6;
+    // 8 waves per block, one block per CU: the fused kernel needs > 168 VGPRs (2 waves per SIMD)
+    int waves = 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > 80 * 1024) --waves;
     if (lds_for(waves) > 160 * 1024)
@@ -926,7 +961,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= kMaxWavesE && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
-    const int blocks_per_cu = std::max(1, std::min<int>(12 / m->waves_e, (int)((160 * 1024) / m->lds_e)));
+    const int blocks_per_cu = std::max(1, std::min<int>(8 / m->waves_e, (int)((160 * 1024) / m->lds_e)));
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
@@ -935,7 +970,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
-    A(partial, (size_t)m->grid_e * VK); A(stats, VK + 16); A(llpart, (size_t)grid_max); A(elbopart, (size_t)m->grid_s * 5 + 8);
+    A(partial, (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1);
 #undef A
     hipStream_t st = ctx->stream;
@@ -952,8 +987,8 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
         hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
     }
     if (nnz) hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)K * nnz + 255) / 256)), dim3(256), 0, st, m->phi.p, (size_t)K * nnz, 1.0 / K);
-    MMM_HIP(ctx, hipMemsetAsync(m->stats.p, 0, sizeof(double) * (VK + 16), st));
-    double* ncount = m->stats.p + VK + 1;
+    MMM_HIP(ctx, hipMemsetAsync(m->scratch.p, 0, sizeof(double) * (VK + 16), st));
+    double* ncount = m->scratch.p + VK + 1;
     if (nnz) hipLaunchKernelGGL(k_doc_counts, dim3(64), dim3(256), 0, st, m->dev(), ncount);
     MMM_LAUNCH_CHECK(ctx);
     // global N and D (sum over ranks)
@@ -1029,7 +1064,7 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     MMM_CHECK(ctx, host && n == cnt, "mmm_lda_set(field %d): expected %zu doubles, got %zu", field, cnt, n);
     if ((rc = materialise_phi(m))) return rc;     // make the implicit phi explicit before state is overwritten
     if ((rc = flush_ll(m, nullptr))) return rc;
-    m->gnext_valid = false; m->phi_from_prev = false;
+    m->gnext_valid = false; m->phi_from_prev = false; m->stats_valid = false;
     if (field == MMM_LDA_THETA) m->theta_valid = true;
     if (field == MMM_LDA_GAMMA) m->theta_valid = false;
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1049,7 +1084,7 @@ int mmm_lda_update_gamma(mmm_lda* m)
     const int c = m->cur();
     hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p);
     MMM_LAUNCH_CHECK(m->ctx);
-    m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false;
+    m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false; m->stats_valid = false;
     return MMM_OK;
 }
 
@@ -1060,7 +1095,7 @@ int mmm_lda_update_phi(mmm_lda* m)
     if (rc || (rc = flush_ll(m, nullptr))) return rc;
     const int c = m->cur();
     if ((rc = launch_phi(m, m->Elntheta[c].p, m->expElnbeta[c].p))) return rc;
-    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false;
+    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false; m->stats_valid = false;
     return MMM_OK;
 }
 
@@ -1070,10 +1105,10 @@ int mmm_lda_update_lambda(mmm_lda* m)
     mmm_ctx* ctx = m->ctx;
     int rc = prepare_call(m);
     if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
-    MMM_HIP(ctx, hipMemsetAsync(m->stats.p, 0, sizeof(double) * (size_t)m->V * m->K, ctx->stream));
-    if (m->nnz) hipLaunchKernelGGL(k_lda_lambda_from_phi, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, ctx->stream, m->dev(), m->nnz, m->phi.p, m->stats.p);
+    MMM_HIP(ctx, hipMemsetAsync(m->scratch.p, 0, sizeof(double) * (size_t)m->V * m->K, ctx->stream));
+    if (m->nnz) hipLaunchKernelGGL(k_lda_lambda_from_phi, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, ctx->stream, m->dev(), m->nnz, m->phi.p, m->scratch.p);
     MMM_LAUNCH_CHECK(ctx);
-    m->gnext_valid = false; m->phi_from_prev = false;
+    m->gnext_valid = false; m->phi_from_prev = false; m->stats_valid = false;
     return run_topic_update(m, true);
 }
 
@@ -1107,7 +1142,7 @@ int mmm_lda_loglik(mmm_lda* m, double* ll)
     if (rc) return rc;
     // the reference evaluates with the stored theta and beta (LDA.jl:194-196); this entry point recomputes theta from
     // gamma first, which is what fit! has just done (LDA.jl:207) -- beta must be current (update_β! or a fused pass).
-    double* dst = m->stats.p + (size_t)m->V * m->K + 4;
+    double* dst = m->scratch.p + (size_t)m->V * m->K + 4;
     if ((rc = flush_ll(m, dst))) return rc;
     MMM_HIP(ctx, hipMemcpyAsync(ll, dst, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));

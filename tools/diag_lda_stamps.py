@@ -15,6 +15,9 @@ for rep in range(3):
     lib.mmm_diag_lda_stamps.argtypes = [C.c_void_p]
     assert lib.mmm_diag_lda_stamps(st) == 0
     s = np.array(st[:8], dtype=np.int64)
-    names = ["args", "table stage issue", "prologue+barrier", "Eln store", "chunks", "gamma reduce", "epilogue"]
+    names = ["loads+tables", "tc prefetch+doc prologue+barrier", "Eln store", "chunks", "gamma reduce", "step end", "epilogue"]
     d = np.diff(s)
+    rt = np.array(st[8:12], dtype=np.int64)
+    print("   block0 real time %.2f us (clock %.2f GHz); last block start +%.2f us, end +%.2f us after block0 start" % (
+        (rt[1] - rt[0]) / 100.0, (s[7] - s[0]) / ((rt[1] - rt[0]) / 100.0) / 1e3, (rt[2] - rt[0]) / 100.0, (rt[3] - rt[0]) / 100.0))
     print("D=%d rep %d total %d cycles (memtime ticks): " % (D, rep, s[7] - s[0]) + ", ".join("%s %d" % (n, x) for n, x in zip(names, d)))
