@@ -1,26 +1,1407 @@
-// ctm.hip -- PLACEHOLDER while the CTM kernels are being written: every entry point reports MMM_ERR_UNSUPPORTED.
+// ctm.hip -- MMCTM / IMMCTM variational EM on gfx950 (replaces the hot path of src/MMCTM.jl, src/IMMCTM.jl, common.jl)
+//
+// Data layout in HBM (per model handle)
+//   corpus     doc_ptr int64[M*(D+1)] absolute offsets; tc int2[nnz] = (term0, count); Ndm double[D*M]
+//   documents  lambda ring[2] [d][MK]; nu [d][MK]; zeta [d][M]; props [d][MK]; theta flat (on demand)
+//   topics     gamma, Elnphi in the model layout (MMCTM [m][k][v]; IMMCTM [m][k][i][j]) and three "effective"
+//              [m][k][v] tables: Eeff = Elnphi (IMMCTM: sum over features), exp(Eeff) (ring of 2), phieff
+//   Gaussian   mu[MK], Sigma, invSigma [MK x MK]
+//
+// One outer iteration (MMCTM.jl:462-479) on one GPU:
+//   k_ctm_estep<L>   fitdoc! for every document: a wave handles 64/L documents, L >= MK lanes per document.  Lanes are
+//                    the MK coordinates for zeta and the two MMA solves (nu, lambda), and the document's nonzero terms
+//                    for theta.  theta_kw = a_k B_kv / sum_k a_k B_kv with a = exp(lambda - max) and B = exp(Eeff) in LDS
+//                    (no exp per (term, topic)); theta n is scattered into the wave's LDS slab (-> gamma) and summed
+//                    over terms (-> sumtheta); theta itself is not written (rebuilt on demand from lambda_{t-1}).
+//   k_reduce_partials  per-block slabs -> gamma statistics, fixed order
+//   k_ctm_moments    sum lambda, sum nu, sum lambda lambda^T per block -> fixed-order reduce
+//   (RCCL all-reduce of the packed statistics when documents are sharded over ranks)
+//   k_ctm_mstep      mu, Sigma = (diag sum nu + sum ll^T)/D - mu mu^T, invSigma (Gauss-Jordan in LDS), gamma, Elnphi, tables
+//   k_ctm_loglik     props = softmax(lambda block) and the per-modality log-likelihood sums (MMCTM.jl:384-448)
+//
+// The MMA solves restate NLopt's LD_MMA for zero constraints (algorithm statement: DESIGN.md "MMA" and
+// SURVEY.md §7): one objective evaluation per trip of a single wave-uniform loop, per-group state, select-based commits.
+#include "dev_math.h"
 #include "mmm_internal.h"
-struct mmm_ctm { mmm_ctx* ctx; };
-extern "C" {
-int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const int* n_feat, const int* J, const int32_t* features, const double* gamma0, const mmm_solver_opts* opts, mmm_ctm** out) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_destroy(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_get(mmm_ctm* m, int field, double* host, size_t n) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_zeta(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_theta(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_nu(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_lambda(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_mu(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_Sigma(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_gamma(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_Elnphi(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_props(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_update_phi(mmm_ctm* m) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_loglik(mmm_ctm* m, double* ll /* M */) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7]) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_grad, double* nu_val, double* nu_grad) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped, int* per_doc_nu, int* per_doc_lambda) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_ll_history(mmm_ctm* m, double* ll /* M*max_n */, int max_n, int* n) { return MMM_ERR_UNSUPPORTED; }
-int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */, int* n_iter, int* converged, double* elbo) { return MMM_ERR_UNSUPPORTED; }
+
+namespace {
+
+constexpr int kMaxM = 8;
+constexpr int kKmax = 16;          // topics per modality handled by the unrolled theta loop
+constexpr int kWavesS = 4;         // stage / auxiliary kernels
+constexpr int kBlockS = kWavesS * MMM_WAVE;
+
+enum { F_ZETA = 1, F_THETA_COMPUTE = 2, F_THETA_STORED = 4, F_THETA_STORE = 8, F_NU = 16, F_LAMBDA = 32, F_SLAB = 64 };
+
+struct CtmDims {
+    int D, M, MK, GT;                    // GT = sum_m K_m V_m
+    int K[kMaxM], V[kMaxM], koff[kMaxM + 1], goff[kMaxM + 1];
+    long long estart[kMaxM], toff[kMaxM];
+};
+
+struct CtmDev {
+    CtmDims dm;
+    const int64_t* doc_ptr;
+    const int2* tc;
+    const double* Ndm;
+};
+
+struct SolveOpts { double xtol_rel, xtol_abs, nu_lower; int xtol_rule, max_eval; };
+
+__device__ __forceinline__ void lds_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
+
+template <int L>
+__device__ __forceinline__ double group_max(double v)
+{
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    if (L >= 32) v = fmax(v, __shfl_xor(v, 16, MMM_WAVE));
+    if (L >= 64) v = fmax(v, __shfl_xor(v, 32, MMM_WAVE));
+    return v;
+}
+
+// true when `pred` is false on every lane of the caller's L-lane group
+template <int L>
+__device__ __forceinline__ bool group_none(bool pred, int g)
+{
+    const unsigned long long b = __ballot(pred);
+    if (L == 64) return b == 0ull;
+    const unsigned long long mask = ((1ull << L) - 1ull) << (g * L);
+    return (b & mask) == 0ull;
+}
+
+// ---- objectives in NLopt's minimisation form (common.jl:11-36 negated) ----------------------------------------------
+// nu: f = 1/2 sum nu_i S_ii + sum c_i exp(lambda_i + nu_i/2) - 1/2 sum log nu_i
+struct NuObj {
+    double lam, c, Sll; bool act;
+    template <int L>
+    __device__ __forceinline__ double eval(double x, double& g) const
+    {
+        const double E = exp(lam + 0.5 * x);
+        g = act ? 0.5 * Sll + 0.5 * c * E - 1.0 / (2.0 * x) : 0.0;
+        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * log(x) : 0.0;
+        return group_sum<L>(t);
+    }
+};
+
+// lambda: f = 1/2 (x-mu)' S (x-mu) - x . sumtheta + sum c_i exp(x_i + nu_i/2)
+struct LamObj {
+    double nu, c, sumth, mu; bool act; int l, MK;
+    const double* sS;     // [j*MK + i], symmetric
+    double* scr;          // group-private LDS, >= MK doubles
+    template <int L>
+    __device__ __forceinline__ double eval(double x, double& g) const
+    {
+        const double diff = act ? x - mu : 0.0;
+        lds_wave_sync();
+        scr[l] = diff;
+        lds_wave_sync();
+        double Sd = 0.0;
+        if (act) for (int j = 0; j < MK; ++j) Sd = fma(sS[j * MK + l], scr[j], Sd);
+        const double E = exp(x + 0.5 * nu);
+        g = act ? Sd - sumth + c * E : 0.0;
+        const double t = act ? 0.5 * diff * Sd - x * sumth + c * E : 0.0;
+        return group_sum<L>(t);
+    }
+};
+
+// NLopt LD_MMA, zero constraints, for the L-lane group of the calling lane (lane l holds coordinate l).  All lanes of the
+// wave execute every trip; a finished group keeps its state through selects.  Returns the number of objective
+// evaluations (negative: the evaluation cap was hit).
+template <int L, class Obj>
+__device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb, double lb, const SolveOpts& o)
+{
+    double sigma = 1.0, rho = 1.0;
+    double gcur, grad;
+    double fbest = obj.template eval<L>(x, grad);
+    double xcur = x, xprev = x, xprevprev = x;
+    int k = 1, nev = 1;
+    bool done = false, capped = false;
+    const int cap = o.max_eval > 0 ? o.max_eval : 2000;
+    while (!__all(done)) {
+        // closed-form minimiser of the separable approximation (dual problem is trivial for m = 0)
+        const double sigma2 = sigma * sigma;
+        const double u = grad * sigma2;
+        const double v = fabs(grad) * sigma + 0.5 * rho;
+        const double q = u / (v * sigma);
+        double dx = (u / v) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+        double xc = x + dx;
+        if (has_lb && xc < lb) xc = lb;
+        if (xc > x + 0.9 * sigma) xc = x + 0.9 * sigma; else if (xc < x - 0.9 * sigma) xc = x - 0.9 * sigma;
+        if (!act) xc = x;
+        dx = xc - x;
+        const double dx2 = dx * dx;
+        const double denominv = 1.0 / (sigma2 - dx2);
+        const double gl = act ? (grad * (sigma2 * dx) + (fabs(grad) * sigma + 0.5 * rho) * dx2) * denominv : 0.0;
+        const double wl = act ? 0.5 * dx2 * denominv : 0.0;
+        const double gval = fbest + group_sum<L>(gl);
+        const double wval = group_sum<L>(wl);
+        const double fcur = obj.template eval<L>(xc, gcur);
+        if (!done) {
+            ++nev;
+            xcur = xc;
+            const bool inner_done = gval >= fcur;
+            if (fcur < fbest) { fbest = fcur; x = xc; grad = gcur; }
+            if (nev >= cap) { done = true; capped = true; }
+            else if (!inner_done) {
+                if (fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + (fcur - gval) / wval));
+            } else {
+                // outer iteration finished: NLopt's x-tolerance test on (xcur, xprev)
+                const double ad = fabs(xcur - xprev);
+                bool stop;
+                if (o.xtol_rule == 0) {
+                    const double dn = group_sum<L>(act ? ad : 0.0), xn = group_sum<L>(act ? fabs(xcur) : 0.0);
+                    stop = (dn < o.xtol_rel * xn) || group_none<L>(act && !(ad < o.xtol_abs), g);
+                } else {
+                    const bool ok = isinf(xprev) ? false
+                                                  : (ad < o.xtol_abs || ad < o.xtol_rel * (fabs(xcur) + fabs(xprev)) * 0.5 ||
+                                                     (o.xtol_rel > 0 && xcur == xprev));
+                    stop = group_none<L>(act && !ok, g);
+                }
+                if (stop) done = true;
+                else {
+                    rho = fmax(0.1 * rho, 1e-5);
+                    if (k > 1) {
+                        const double s = (xcur - xprev) * (xprev - xprevprev);
+                        sigma *= (s < 0 ? 0.7 : (s > 0 ? 1.2 : 1.0));
+                    }
+                    ++k;
+                    xprevprev = xprev;
+                    xprev = xcur;
+                }
+            }
+        }
+    }
+    return capped ? -nev : nev;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct CtmEArgs {
+    CtmDev c;
+    const double* invSigma; const double* mu; const double* expE;     // topic tables used by theta: exp(Eeff)
+    const double* lam_in; double* lam_out; double* nu; double* zeta; double* theta;
+    double* partial;        // [gridDim][GT] (F_SLAB)
+    int* nev_nu; int* nev_lam;   // per document (may be NULL)
+    SolveOpts opt;
+    int flags;
+};
+
+template <int L>
+__global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int G = MMM_WAVE / L;
+    const CtmDims& dm = a.c.dm;
+    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
+    const int flags = a.flags;
+    double* sS = smem;                                 // [MK*MK]
+    double* sMu = sS + MK * MK;                        // [MK]
+    double* sB = sMu + MK;                             // [GT]
+    double* sScr = sB + GT;                            // [NW][G][2L]
+    double* sSlab = sScr + (size_t)NW * G * 2 * L;     // [NW][GT] (F_SLAB)
+    for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = a.invSigma[i];
+    for (int i = tid; i < MK; i += blockDim.x) sMu[i] = a.mu[i];
+    if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = a.expE[i];
+    if (flags & F_SLAB) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
+    __syncthreads();
+    double* slab = sSlab + (size_t)wid * GT;
+    double* scrA = sScr + ((size_t)wid * G + g) * 2 * L;   // a_k values
+    double* scrD = scrA + L;                               // lambda-objective differences
+    int mod_l = 0;
+    for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) mod_l = m;
+
+    for (int base = (blockIdx.x * NW + wid) * G; base < D; base += gridDim.x * NW * G) {
+        const int d = base + g;
+        const bool valid = d < D;
+        const bool act = valid && l < MK;
+        double lam = act ? a.lam_in[(size_t)d * MK + l] : 0.0;
+        double nu = act ? a.nu[(size_t)d * MK + l] : 1.0;
+        const double Nl = act ? a.c.Ndm[(size_t)d * M + mod_l] : 0.0;
+        // ---- update_ζ! (MMCTM.jl:172-181) -------------------------------------------------------------------------
+        double zl = 1.0;
+        if (flags & F_ZETA) {
+            const double E = act ? exp(lam + 0.5 * nu) : 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double zm = group_sum<L>((act && mod_l == m) ? E : 0.0);
+                if (mod_l == m) zl = zm;
+                if (valid && l == m) a.zeta[(size_t)d * M + m] = zm;
+            }
+        } else if (act) zl = a.zeta[(size_t)d * M + mod_l];
+        const double cl = Nl / zl;                                   // Ndivζ (MMCTM.jl:119-125)
+        // ---- update_θ! (MMCTM.jl:183-198) and sumθ (MMCTM.jl:110-117) ------------------------------------------------
+        double sumth = 0.0;
+        if (flags & (F_THETA_COMPUTE | F_THETA_STORED)) {
+            double mx = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double mm = group_max<L>((act && mod_l == m) ? lam : -1e300);
+                if (mod_l == m) mx = mm;
+            }
+            lds_wave_sync();
+            scrA[l] = act ? exp(lam - mx) : 0.0;
+            lds_wave_sync();
+            for (int m = 0; m < M; ++m) {
+                const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
+                const double* tb = sB + dm.goff[m];
+                double* sl = slab + dm.goff[m];
+                const int64_t* dp = a.c.doc_ptr + (size_t)m * (D + 1);
+                const int64_t start = valid ? dp[d] : 0;
+                const int W = valid ? (int)(dp[d + 1] - start) : 0;
+                double av[kKmax], acc[kKmax];
+#pragma unroll
+                for (int k = 0; k < kKmax; ++k) { av[k] = (k < Km) ? scrA[off + k] : 0.0; acc[k] = 0.0; }
+                for (int w0 = 0; __any(w0 < W); w0 += L) {
+                    const int w = w0 + l;
+                    const bool aw = w < W;
+                    const int2 tcv = aw ? a.c.tc[start + w] : make_int2(0, 0);
+                    const double n = (double)tcv.y;
+                    double* th = a.theta ? a.theta + dm.toff[m] + (size_t)(start + w - dm.estart[m]) * Km : nullptr;
+                    double e[kKmax], r, inv = 0.0;
+                    if (flags & F_THETA_COMPUTE) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < kKmax; ++k) { e[k] = (k < Km) ? av[k] * tb[k * Vm + tcv.x] : 0.0; s += e[k]; }
+                        inv = aw ? 1.0 / s : 0.0;
+                        r = n * inv;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kKmax; ++k) e[k] = (aw && k < Km) ? th[k] : 0.0;
+                        r = n;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kKmax; ++k) {
+                        const double pn = e[k] * r;
+                        acc[k] += pn;
+                        if (aw && k < Km) {
+                            if (flags & F_SLAB) unsafeAtomicAdd(&sl[k * Vm + tcv.x], pn);
+                            if (flags & F_THETA_STORE) th[k] = e[k] * inv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kKmax; ++k) {
+                    if (k < Km) { const double tot = group_sum<L>(acc[k]); if (l == off + k) sumth = tot; }
+                }
+            }
+        }
+        SolveOpts o = a.opt;
+        // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ ----------------
+        if (flags & F_NU) {
+            NuObj obj{lam, cl, act ? sS[l * MK + l] : 1.0, act};
+            const int nev = mma_group<L>(obj, act, g, nu, true, o.nu_lower, o);
+            if (act) a.nu[(size_t)d * MK + l] = nu;
+            if (a.nev_nu && valid && l == 0) a.nev_nu[d] = nev;
+        }
+        // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν ---------------------------------------------
+        if (flags & F_LAMBDA) {
+            LamObj obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
+            const int nev = mma_group<L>(obj, act, g, lam, false, 0.0, o);
+            if (act) a.lam_out[(size_t)d * MK + l] = lam;
+            if (a.nev_lam && valid && l == 0) a.nev_lam[d] = nev;
+        }
+    }
+    if (flags & F_SLAB) {
+        __syncthreads();
+        double* out = a.partial + (size_t)blockIdx.x * GT;
+        for (int i = tid; i < GT; i += blockDim.x) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * GT + i];
+            out[i] = s;
+        }
+    }
+}
+
+// objective values / gradients of one document at its stored (lambda, nu), in the reference's MAXIMISATION form
+// (common.jl:11-36), evaluated by the same device functors the solvers use.  One wave.
+__global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const double* invSigma, const double* mu, const double* lam,
+                                                       const double* nu, const double* zeta, const double* theta, double* out)
+{
+    __shared__ double sS[64 * 64];
+    __shared__ double scr[64];
+    const CtmDims& dm = c.dm;
+    const int MK = dm.MK, M = dm.M, l = threadIdx.x;
+    for (int i = l; i < MK * MK; i += 64) sS[i] = invSigma[i];
+    __syncthreads();
+    const bool act = l < MK;
+    int mod_l = 0;
+    for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) mod_l = m;
+    const double x = act ? lam[(size_t)d * MK + l] : 0.0, v = act ? nu[(size_t)d * MK + l] : 1.0;
+    const double cl = act ? c.Ndm[(size_t)d * M + mod_l] / zeta[(size_t)d * M + mod_l] : 0.0;
+    double sumth = 0.0;
+    if (act) {
+        const int m = mod_l, Km = dm.K[m], k = l - dm.koff[m];
+        const int64_t* dp = c.doc_ptr + (size_t)m * (dm.D + 1);
+        for (int64_t e = dp[d]; e < dp[d + 1]; ++e) sumth += theta[dm.toff[m] + (size_t)(e - dm.estart[m]) * Km + k] * (double)c.tc[e].y;
+    }
+    double g1, g2;
+    LamObj lo{v, cl, sumth, act ? mu[l] : 0.0, act, l, MK, sS, scr};
+    const double f1 = lo.eval<64>(x, g1);
+    NuObj no{x, cl, act ? sS[l * MK + l] : 1.0, act};
+    const double f2 = no.eval<64>(v, g2);
+    if (l == 0) { out[0] = -f1; out[1] = -f2; }
+    if (act) { out[2 + l] = -g1; out[2 + MK + l] = -g2; }
+}
+
+// partial[nslab][n] -> out[n], fixed summation order; grid = ceil(n/16) blocks of (16, 64)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ part, int nslab, int n, double* __restrict__ out)
+{
+    __shared__ double sm[64][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int e = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    if (e < n) for (int sl = ty; sl < nslab; sl += 64) acc += part[(size_t)sl * n + e];
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty < 8) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += sm[ty * 8 + j][tx];
+        sm[ty * 8][tx] = v;
+    }
+    __syncthreads();
+    if (ty == 0 && e < n) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
+        out[e] = v;
+    }
+}
+
+// per-block partial sums of lambda (MK), nu (MK), lambda lambda^T (MK*MK): part[block][2MK + MK*MK]
+__global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double* lam, const double* nu, double* part)
+{
+    const int n = 2 * MK + MK * MK;
+    const int per = (D + gridDim.x - 1) / gridDim.x;
+    const int d0 = blockIdx.x * per, d1 = min(D, d0 + per);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        double s = 0.0;
+        if (e < MK) for (int d = d0; d < d1; ++d) s += lam[(size_t)d * MK + e];
+        else if (e < 2 * MK) for (int d = d0; d < d1; ++d) s += nu[(size_t)d * MK + (e - MK)];
+        else {
+            const int i = (e - 2 * MK) % MK, j = (e - 2 * MK) / MK;
+            for (int d = d0; d < d1; ++d) s += lam[(size_t)d * MK + i] * lam[(size_t)d * MK + j];
+        }
+        part[(size_t)blockIdx.x * n + e] = s;
+    }
+}
+
+// ---- M-step (one block) -------------------------------------------------------------------------------------------
+struct CtmTopics {            // model-layout topic parameters
+    int immctm;
+    int nfeat[kMaxM], aoff[kMaxM + 1];      // IMMCTM: features per modality, offset into J/alpha
+    int J[4 * kMaxM];                        // concatenated J[m][i]
+    int SJ[kMaxM];                           // sum_i J[m][i]
+    int mgoff[kMaxM + 1];                    // model-layout offsets of gamma/Elnphi per modality
+    long long foff[kMaxM];                   // offsets into features
+    const int* features;                     // [foff[m] + i*V + v]
+    const double* alpha;                     // MMCTM: [M]; IMMCTM: [aoff]
+};
+
+struct MstepArgs {
+    CtmDims dm; CtmTopics tp;
+    const double* stats;    // [MK | MK | MK*MK | GT]
+    double Dglobal;
+    double* mu; double* Sigma; double* invSigma;
+    double* gamma; double* Elnphi; double* phi;      // model layout (phi: MMCTM only, may be NULL)
+    double* Eeff; double* expEeff; double* phieff;   // [GT]
+    int* status;            // 0 ok, 1 singular Sigma
+    int do_mu, do_sigma, do_gamma, gamma_from_stats;
+};
+
+// in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; returns
+// log|det A| in *logdet (thread 0).  One block.
+__device__ void block_inverse(int n, double* A, double* Ainv, double* logdet, int* singular, int* s_piv)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < n * n; i += nt) Ainv[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    if (tid == 0) { *logdet = 0.0; *singular = 0; }
+    __syncthreads();
+    for (int c = 0; c < n; ++c) {
+        if (tid == 0) {
+            int p = c; double best = fabs(A[c * n + c]);
+            for (int r = c + 1; r < n; ++r) { const double v = fabs(A[r * n + c]); if (v > best) { best = v; p = r; } }
+            *s_piv = p;
+            if (!(best > 0.0)) *singular = 1;
+            *logdet += log(best);
+        }
+        __syncthreads();
+        const int p = *s_piv;
+        if (p != c) for (int j = tid; j < n; j += nt) {
+            double t = A[c * n + j]; A[c * n + j] = A[p * n + j]; A[p * n + j] = t;
+            t = Ainv[c * n + j]; Ainv[c * n + j] = Ainv[p * n + j]; Ainv[p * n + j] = t;
+        }
+        __syncthreads();
+        const double piv = A[c * n + c];
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) { A[c * n + j] /= piv; Ainv[c * n + j] /= piv; }
+        __syncthreads();
+        for (int i = tid; i < n * n; i += nt) {
+            const int r = i / n, j = i % n;
+            if (r != c) {
+                const double f = A[r * n + c];
+                // column c of A is needed unchanged by every thread of this sweep: update it last
+                if (j != c) A[r * n + j] -= f * A[c * n + j];
+                Ainv[r * n + j] -= f * Ainv[c * n + j];
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < n; r += nt) if (r != c) A[r * n + c] = 0.0;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double s_logdet; __shared__ int s_sing, s_piv;
+    const CtmDims& dm = a.dm;
+    const int MK = dm.MK, M = dm.M, tid = threadIdx.x, nt = blockDim.x;
+    const double* sLam = a.stats; const double* sNu = a.stats + MK; const double* sLL = a.stats + 2 * MK; const double* sG = a.stats + 2 * MK + MK * MK;
+    // update_μ! (MMCTM.jl:200-202)
+    if (a.do_mu) { for (int i = tid; i < MK; i += nt) a.mu[i] = sLam[i] / a.Dglobal; }
+    __syncthreads();
+    // update_Σ! (MMCTM.jl:204-212) from raw moments: (diag Σν + Σ (λ-μ)(λ-μ)') / D with the NEW μ
+    if (a.do_sigma) {
+        double* A = smem; double* Ai = smem + MK * MK;
+        for (int e = tid; e < MK * MK; e += nt) {
+            const int i = e % MK, j = e / MK;
+            // Σ_d (λ_i-μ_i)(λ_j-μ_j) = Σλλ' - μ_i Σλ_j - μ_j Σλ_i + D μ_i μ_j
+            const double mi = a.mu[i], mj = a.mu[j];
+            double v = sLL[e] - mi * sLam[j] - mj * sLam[i] + a.Dglobal * mi * mj;
+            if (i == j) v += sNu[i];
+            v /= a.Dglobal;
+            a.Sigma[e] = v; A[i * MK + j] = v;
+        }
+        __syncthreads();
+        block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; a.invSigma[e] = Ai[i * MK + j]; }
+        if (tid == 0 && s_sing) *a.status = 1;
+        __syncthreads();
+    }
+    if (!a.do_gamma) return;
+    // update_γ! / update_Elnϕ! / update_ϕ! (MMCTM.jl:214-250; IMMCTM.jl:188-223)
+    const CtmTopics& tp = a.tp;
+    if (!tp.immctm) {
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], Vm = dm.V[m], go = dm.goff[m];
+            if (a.gamma_from_stats) for (int e = tid; e < Km * Vm; e += nt) a.gamma[go + e] = tp.alpha[m] + sG[go + e];
+            __syncthreads();
+            for (int k = 0; k < Km; ++k) {
+                double part = 0.0;
+                for (int v = tid; v < Vm; v += nt) part += a.gamma[go + k * Vm + v];
+                __shared__ double sh[4];
+                part = wave_sum(part);
+                __syncthreads();
+                if ((tid & 63) == 0) sh[tid >> 6] = part;
+                __syncthreads();
+                const double cs = sh[0] + sh[1] + sh[2] + sh[3];
+                const double pcs = dev_digamma(cs);
+                for (int v = tid; v < Vm; v += nt) {
+                    const double gm = a.gamma[go + k * Vm + v];
+                    const double el = dev_digamma(gm) - pcs;
+                    a.Elnphi[go + k * Vm + v] = el; a.Eeff[go + k * Vm + v] = el; a.expEeff[go + k * Vm + v] = exp(el);
+                    const double ph = gm / cs;
+                    if (a.phi) a.phi[go + k * Vm + v] = ph;
+                    a.phieff[go + k * Vm + v] = ph;
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], Vm = dm.V[m], go = dm.goff[m], mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
+            const int* feat = tp.features + tp.foff[m];
+            // gamma[m][k][i][j] = alpha[m][i] + sum_{v: f_vi = j} S[m][k][v]   (IMMCTM.jl:199-221)
+            if (a.gamma_from_stats) for (int e = tid; e < Km * SJ; e += nt) {
+                const int k = e / SJ; int jj = e % SJ, i = 0;
+                while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
+                double s = tp.alpha[ao + i];
+                for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
+                a.gamma[mg + e] = s;
+            }
+            __syncthreads();
+            // Elnphi[m][k][i][j] = psi(gamma) - psi(sum_j gamma)   (IMMCTM.jl:188-197)
+            for (int e = tid; e < Km * SJ; e += nt) {
+                const int k = e / SJ; int jj = e % SJ, i = 0, jo = 0;
+                while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
+                double cs = 0.0;
+                for (int j = 0; j < tp.J[ao + i]; ++j) cs += a.gamma[mg + k * SJ + jo + j];
+                a.Elnphi[mg + e] = dev_digamma(a.gamma[mg + e]) - dev_digamma(cs);
+            }
+            __syncthreads();
+            // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
+            for (int e = tid; e < Km * Vm; e += nt) {
+                const int k = e / Vm, v = e % Vm;
+                double se = 0.0, pp = 1.0; int jo = 0;
+                for (int i = 0; i < nf; ++i) {
+                    const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
+                    double cs = 0.0;
+                    for (int j = 0; j < Ji; ++j) cs += a.gamma[mg + k * SJ + jo + j];
+                    se += a.Elnphi[mg + k * SJ + jo + f];
+                    pp *= a.gamma[mg + k * SJ + jo + f] / cs;
+                    jo += Ji;
+                }
+                a.Eeff[go + e] = se; a.expEeff[go + e] = exp(se); a.phieff[go + e] = pp;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// props = softmax(lambda block) (MMCTM.jl:145-154) and per-modality ll numerators (MMCTM.jl:384-418); wave per document.
+// llpart[block][M]
+__global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
+                                                        int compute_ll)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double shw[kWavesS][kMaxM];
+    const CtmDims& dm = c.dm;
+    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double* sP = smem;                       // [GT]
+    double* sPr = smem + GT + wid * 64;      // per-wave props
+    if (compute_ll) { for (int i = tid; i < GT; i += kBlockS) sP[i] = phieff[i]; }
+    __syncthreads();
+    int mod_l = 0;
+    for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
+    double acc[kMaxM];
+    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.0;
+    for (int d = blockIdx.x * kWavesS + wid; d < D; d += gridDim.x * kWavesS) {
+        const bool act = lane < MK;
+        const double x = act ? lam[(size_t)d * MK + lane] : 0.0;
+        double pr = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const bool in = act && mod_l == m;
+            const double mx = wave_max(in ? x : -1e300);
+            const double e = in ? exp(x - mx) : 0.0;
+            const double s = wave_sum(e);
+            if (in) pr = e / s;
+        }
+        if (act && props) props[(size_t)d * MK + lane] = pr;
+        if (!compute_ll) continue;
+        lds_wave_sync();
+        sPr[lane] = pr;
+        lds_wave_sync();
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
+            const double* tb = sP + dm.goff[m];
+            const int64_t* dp = c.doc_ptr + (size_t)m * (D + 1);
+            const int64_t start = dp[d];
+            const int W = (int)(dp[d + 1] - start);
+            double a = 0.0;
+            for (int w = lane; w < W; w += MMM_WAVE) {
+                const int2 t = c.tc[start + w];
+                double p = 0.0;
+                for (int k = 0; k < Km; ++k) p = fma(sPr[off + k], tb[k * Vm + t.x], p);
+                a += (double)t.y * log(p);
+            }
+            acc[m] += wave_sum(a);
+        }
+    }
+    if (compute_ll) {
+        if (lane == 0) for (int m = 0; m < M; ++m) shw[wid][m] = acc[m];
+        __syncthreads();
+        if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)blockIdx.x * M + tid] = s; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, int stride, double* out)
+{
+    const int j = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += part[(size_t)i * stride + j];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[j] = acc;
+}
+
+__global__ void k_ll_store(int M, const double* num, const double* Nm, double* dst)
+{
+    if ((int)threadIdx.x < M) dst[threadIdx.x] = num[threadIdx.x] / Nm[threadIdx.x];
+}
+
+// per-document ELBO pieces (MMCTM.jl:286-370): out[block][6] = {ElnPeta(without logdet/const), ElnPZ, ElnPX, ElnQeta, ElnQZ, count}
+// theta is rebuilt on the fly from (lam_prev, expE_prev) when theta == NULL
+__global__ __launch_bounds__(kBlockS) void k_ctm_elbo_docs(CtmDev c, const double* invSigma, const double* mu, const double* lam, const double* nu,
+                                                           const double* zeta, const double* theta, const double* Eeff, double* out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double shw[kWavesS][5];
+    const CtmDims& dm = c.dm;
+    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double* sS = smem; double* sE = sS + MK * MK; double* scr = sE + GT + wid * 64;
+    for (int i = tid; i < MK * MK; i += kBlockS) sS[i] = invSigma[i];
+    for (int i = tid; i < GT; i += kBlockS) sE[i] = Eeff[i];
+    __syncthreads();
+    int mod_l = 0;
+    for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int d = blockIdx.x * kWavesS + wid; d < D; d += gridDim.x * kWavesS) {
+        const bool act = lane < MK;
+        const double x = act ? lam[(size_t)d * MK + lane] : 0.0, v = act ? nu[(size_t)d * MK + lane] : 1.0;
+        const double diff = act ? x - mu[lane] : 0.0;
+        lds_wave_sync(); scr[lane] = diff; lds_wave_sync();
+        double Sd = 0.0;
+        if (act) for (int j = 0; j < MK; ++j) Sd = fma(sS[j * MK + lane], scr[j], Sd);
+        // ElnPη without the constants: -1/2 (tr(diag(ν) invΣ) + diff' invΣ diff)   (MMCTM.jl:286-300)
+        t[0] += wave_sum(act ? -0.5 * (v * sS[lane * MK + lane] + diff * Sd) : 0.0);
+        // ElnQη without the constant: -1/2 Σ log ν   (MMCTM.jl:352-358)
+        t[3] += wave_sum(act ? -0.5 * log(v) : 0.0);
+        // ElnPZ (MMCTM.jl:302-316), ElnPX (318-336), ElnQZ (360-370)
+        const double Nl = act ? c.Ndm[(size_t)d * M + mod_l] : 0.0;
+        const double zl = act ? zeta[(size_t)d * M + mod_l] : 1.0;
+        double pz = act ? -(Nl / zl) * exp(x + 0.5 * v) : 0.0;
+        if (lane < M) { const double Nm = c.Ndm[(size_t)d * M + lane]; pz += Nm - Nm * log(zeta[(size_t)d * M + lane]); }
+        double px = 0.0, qz = 0.0, lin = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
+            const int64_t* dp = c.doc_ptr + (size_t)m * (D + 1);
+            const int64_t start = dp[d];
+            const int W = (int)(dp[d + 1] - start);
+            for (int w = lane; w < W; w += MMM_WAVE) {
+                const int2 tc = c.tc[start + w];
+                const double n = (double)tc.y;
+                const double* th = theta + dm.toff[m] + (size_t)(start + w - dm.estart[m]) * Km;
+                for (int k = 0; k < Km; ++k) {
+                    const double p = th[k];
+                    lin += n * p * lam[(size_t)d * MK + off + k];       // Σ λ_i sumθ_i
+                    px += n * p * sE[dm.goff[m] + k * Vm + tc.x];
+                    qz += n * dev_xlogx(p);
+                }
+            }
+        }
+        t[1] += wave_sum(pz + lin); t[2] += wave_sum(px); t[4] += wave_sum(qz);
+    }
+    if (lane == 0) for (int j = 0; j < 5; ++j) shw[wid][j] = t[j];
+    __syncthreads();
+    if (tid < 5) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; out[(size_t)blockIdx.x * 5 + tid] = s; }
+}
+
+// topic-side ELBO pieces (MMCTM.jl:271-284,338-350; IMMCTM.jl:247-262,316-330) and logdet(invSigma): out = {ElnPphi, ElnQphi, logdet}
+__global__ __launch_bounds__(256) void k_ctm_elbo_topics(CtmDims dm, CtmTopics tp, const double* gamma, const double* Elnphi, const double* invSigma, double* out)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double s_logdet; __shared__ int s_sing, s_piv; __shared__ double sh[4];
+    const int MK = dm.MK, M = dm.M, tid = threadIdx.x, nt = blockDim.x;
+    double* A = smem; double* Ai = smem + MK * MK;
+    for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; A[i * MK + j] = invSigma[e]; }
+    __syncthreads();
+    block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+    // one (m,k[,i]) Dirichlet per loop trip, handled by the whole block
+    double P = 0.0, Q = 0.0;
+    for (int m = 0; m < M; ++m) {
+        const int Km = dm.K[m];
+        const int nblk = tp.immctm ? tp.nfeat[m] : 1;
+        for (int k = 0; k < Km; ++k) {
+            int jo = 0;
+            for (int i = 0; i < nblk; ++i) {
+                const int n = tp.immctm ? tp.J[tp.aoff[m] + i] : dm.V[m];
+                const int base = tp.immctm ? tp.mgoff[m] + k * tp.SJ[m] + jo : dm.goff[m] + k * n;
+                const double al = tp.immctm ? tp.alpha[tp.aoff[m] + i] : tp.alpha[m];
+                double se = 0.0, sg = 0.0, lg = 0.0, ge = 0.0;
+                for (int v = tid; v < n; v += nt) {
+                    const double gm = gamma[base + v], el = Elnphi[base + v];
+                    se += el; sg += gm; lg += lgamma(gm); ge += (gm - 1.0) * el;
+                }
+                double vals[4] = {se, sg, lg, ge};
+                for (int q = 0; q < 4; ++q) {
+                    double w = wave_sum(vals[q]);
+                    __syncthreads();
+                    if ((tid & 63) == 0) sh[tid >> 6] = w;
+                    __syncthreads();
+                    vals[q] = sh[0] + sh[1] + sh[2] + sh[3];
+                }
+                // ElnPϕ: -(n lgamma(α) - lgamma(n α)) + (α-1) Σ Elnϕ ; ElnQϕ: -(Σ lgamma(γ) - lgamma(Σγ)) + Σ (γ-1) Elnϕ
+                P += -((double)n * lgamma(al) - lgamma((double)n * al)) + (al - 1.0) * vals[0];
+                Q += -(vals[2] - lgamma(vals[1])) + vals[3];
+                jo += n;
+            }
+        }
+    }
+    if (tid == 0) { out[0] = P; out[1] = Q; out[2] = s_logdet; }
+}
+
+__global__ void k_fill(double* p, size_t n, double v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// gamma statistics from a resident theta (stage update_γ!): sums[goff+k*V+v] += theta n, global f64 atomics
+__global__ void k_ctm_gamma_from_theta(CtmDev c, int m, const double* theta, double* sums)
+{
+    const CtmDims& dm = c.dm;
+    const int64_t e0 = dm.estart[m];
+    const int64_t e1 = c.doc_ptr[(size_t)m * (dm.D + 1) + dm.D];
+    const int64_t e = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= e1) return;
+    const int2 t = c.tc[e];
+    const int Km = dm.K[m], Vm = dm.V[m];
+    for (int k = 0; k < Km; ++k)
+        unsafeAtomicAdd(&sums[dm.goff[m] + k * Vm + t.x], theta[dm.toff[m] + (size_t)(e - e0) * Km + k] * (double)t.y);
+}
+
+} // namespace
+
+// =====================================================================================================================
+struct mmm_ctm {
+    mmm_ctx* ctx = nullptr;
+    CtmDims dm{};
+    CtmTopics tp{};
+    bool immctm = false;
+    int L = 64, GM = 0 /* model-layout gamma size */;
+    int64_t nnz = 0, theta_n = 0;
+    long long nnzm[kMaxM] = {0};
+    double Dglobal = 0;
+    SolveOpts opt{};
+    DevBuf<int64_t> doc_ptr; DevBuf<int2> tc; DevBuf<double> Ndm; DevBuf<int> features; DevBuf<double> alpha;
+    DevBuf<double> lambda[2], nu, zeta, props, theta;
+    DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff[2], phieff;
+    DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
+    DevBuf<int> nev_nu, nev_lam, status;
+    int cur = 0;              // lambda[cur] is the current lambda; lambda[cur^1] the previous one (after a fused pass)
+    int ecur = 0;             // expEeff[ecur] current table
+    bool theta_valid = false; // theta buffer == theta of the current state
+    bool theta_from_prev = false;
+    bool props_valid = false;
+    int n_hist = 0, cap_hist = 0;
+    int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1;
+    size_t lds_e = 0;
+    bool attr_set = false;
+    std::vector<double> hNm;
+    CtmDev dev() const { return CtmDev{dm, doc_ptr.p, tc.p, Ndm.p}; }
+};
+
+namespace {
+
+template <int L>
+int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid)
+{
+    mmm_ctx* ctx = m->ctx;
+    auto k = k_ctm_estep<L>;
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(m->waves_e * MMM_WAVE), lds, ctx->stream, a);
+    MMM_LAUNCH_CHECK(ctx);
+    return MMM_OK;
+}
+
+size_t estep_lds(const mmm_ctm* m, int flags)
+{
+    const int G = MMM_WAVE / m->L;
+    size_t n = (size_t)m->dm.MK * m->dm.MK + m->dm.MK + m->dm.GT + (size_t)m->waves_e * G * 2 * m->L;
+    if (flags & F_SLAB) n += (size_t)m->waves_e * m->dm.GT;
+    return n * sizeof(double);
+}
+
+int run_estep(mmm_ctm* m, int flags, const double* lam_in, double* lam_out, const double* expE)
+{
+    CtmEArgs a{m->dev(), m->invSigma.p, m->mu.p, expE, lam_in, lam_out, m->nu.p, m->zeta.p,
+               (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->partial.p, m->nev_nu.p, m->nev_lam.p, m->opt, flags};
+    const size_t lds = estep_lds(m, flags);
+    if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM E-step needs %zu B of LDS (> 160 KiB)", lds);
+    if (m->L == 16) return launch_estep_L<16>(m, a, lds, m->grid_e);
+    if (m->L == 32) return launch_estep_L<32>(m, a, lds, m->grid_e);
+    return launch_estep_L<64>(m, a, lds, m->grid_e);
+}
+
+int reduce_partials(mmm_ctm* m, const double* part, int nslab, int n, double* out)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 15) / 16), dim3(16, 64), 0, m->ctx->stream, part, nslab, n, out);
+    MMM_LAUNCH_CHECK(m->ctx);
+    return MMM_OK;
+}
+
+int run_mstep(mmm_ctm* m, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
+{
+    mmm_ctx* ctx = m->ctx;
+    MstepArgs a{m->dm, m->tp, m->stats.p, m->Dglobal, m->mu.p, m->Sigma.p, m->invSigma.p, m->gamma.p, m->Elnphi.p,
+                m->immctm ? nullptr : m->phi.p, m->Eeff.p, m->expEeff[m->ecur].p, m->phieff.p, m->status.p, do_mu, do_sigma, do_gamma, gamma_from_stats};
+    const size_t lds = sizeof(double) * 2 * (size_t)m->dm.MK * m->dm.MK;
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_ctm_mstep, dim3(1), dim3(256), lds, ctx->stream, a);
+    MMM_LAUNCH_CHECK(ctx);
+    return MMM_OK;
+}
+
+int check_status(mmm_ctm* m)
+{
+    int h = 0;
+    MMM_HIP(m->ctx, hipMemcpyAsync(&h, m->status.p, sizeof(int), hipMemcpyDeviceToHost, m->ctx->stream));
+    MMM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    if (h) return mmm_fail(m->ctx, MMM_ERR_NUMERIC, "update_Σ!: Sigma is singular (inv failed)");
+    return MMM_OK;
+}
+
+// theta of the current state into the theta buffer (MMCTM.jl:183-198)
+int materialise_theta(mmm_ctm* m)
+{
+    if (m->theta_valid) return MMM_OK;
+    const double* lam = m->theta_from_prev ? m->lambda[m->cur ^ 1].p : m->lambda[m->cur].p;
+    const double* tab = m->theta_from_prev ? m->expEeff[m->ecur ^ 1].p : m->expEeff[m->ecur].p;
+    int rc = run_estep(m, F_THETA_COMPUTE | F_THETA_STORE, lam, nullptr, tab);
+    if (rc) return rc;
+    m->theta_valid = true;
+    return MMM_OK;
+}
+
+int run_loglik(mmm_ctm* m, double* dst_dev /* M doubles */, bool compute_ll)
+{
+    mmm_ctx* ctx = m->ctx;
+    const int M = m->dm.M;
+    const size_t lds = sizeof(double) * ((size_t)m->dm.GT + kWavesS * 64);
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda[m->cur].p, m->phieff.p, m->props.p, m->llpart.p, compute_ll ? 1 : 0);
+    MMM_LAUNCH_CHECK(ctx);
+    m->props_valid = true;
+    if (!compute_ll) return MMM_OK;
+    hipLaunchKernelGGL(k_sum_columns, dim3(M), dim3(64), 0, ctx->stream, m->llpart.p, m->grid_s, M, m->llnum.p);
+    MMM_LAUNCH_CHECK(ctx);
+    int rc = mmm_allreduce_sum(ctx, m->llnum.p, M);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ll_store, dim3(1), dim3(64), 0, ctx->stream, M, m->llnum.p, m->Nm.p, dst_dev);
+    MMM_LAUNCH_CHECK(ctx);
+    return MMM_OK;
+}
+
+int ensure_hist(mmm_ctm* m, int extra)
+{
+    const int M = m->dm.M;
+    if ((m->n_hist + extra) * M <= m->cap_hist) return MMM_OK;
+    const int cap = std::max(2 * m->cap_hist, (m->n_hist + extra + 64) * M);
+    DevBuf<double> nb;
+    MMM_HIP(m->ctx, nb.alloc(cap));
+    if (m->n_hist) MMM_HIP(m->ctx, hipMemcpyAsync(nb.p, m->ll_hist.p, sizeof(double) * m->n_hist * M, hipMemcpyDeviceToDevice, m->ctx->stream));
+    MMM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    m->ll_hist.swap(nb);
+    m->cap_hist = cap;
+    return MMM_OK;
+}
+
+// one pass of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451)
+int fused_pass(mmm_ctm* m, int update_sigma)
+{
+    mmm_ctx* ctx = m->ctx;
+    const CtmDims& dm = m->dm;
+    int rc;
+    // for d in 1:D fitdoc!(model, d)
+    const int in = m->cur, out = m->cur ^ 1;
+    { ProfSpan span(ctx); rc = run_estep(m, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda[in].p, m->lambda[out].p, m->expEeff[m->ecur].p); }
+    if (rc) return rc;
+    m->cur = out;
+    m->theta_valid = false; m->theta_from_prev = true; m->props_valid = false;
+    // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
+    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), 0, ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    MMM_LAUNCH_CHECK(ctx);
+    if ((rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p))) return rc;
+    if ((rc = reduce_partials(m, m->partial.p, m->grid_e, dm.GT, m->stats.p + nmom))) return rc;
+    if ((rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)nmom + dm.GT))) return rc;
+    // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!; the exp table of this pass stays for theta materialisation
+    m->ecur ^= 1;
+    if ((rc = run_mstep(m, 1, (update_sigma || m->immctm) ? 1 : 0, 1, 1))) return rc;
+    // update_props! and the log-likelihoods
+    if ((rc = ensure_hist(m, 1))) return rc;
+    if ((rc = run_loglik(m, m->ll_hist.p + (size_t)m->n_hist * dm.M, true))) return rc;
+    m->n_hist++;
+    return MMM_OK;
+}
+
+int prep(mmm_ctm* m) { MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return MMM_OK; }
+
+} // namespace
+
+extern "C" {
+
+int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr, const int32_t* term,
+                   const int32_t* count, const int* n_feat, const int* J, const int32_t* features, const double* gamma0,
+                   const mmm_solver_opts* opts, mmm_ctm** out)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, out && K && V && alpha && doc_ptr && gamma0, "mmm_ctm_create: NULL argument");
+    MMM_CHECK(ctx, D >= 0 && M >= 1 && M <= kMaxM, "mmm_ctm_create: bad sizes D=%d M=%d (M <= %d)", D, M, kMaxM);
+    *out = nullptr;
+    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    mmm_ctm* m = new mmm_ctm();
+    m->ctx = ctx;
+    CtmDims& dm = m->dm;
+    dm.D = D; dm.M = M; dm.koff[0] = 0; dm.goff[0] = 0;
+    int64_t toff = 0;
+    for (int i = 0; i < M; ++i) {
+        if (K[i] < 1 || K[i] > kKmax || V[i] < 1) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: K[%d]=%d must be in 1..%d and V[%d]=%d >= 1", i, K[i], kKmax, i, V[i]); delete m; return rc; }
+        dm.K[i] = K[i]; dm.V[i] = V[i];
+        dm.koff[i + 1] = dm.koff[i] + K[i]; dm.goff[i + 1] = dm.goff[i] + K[i] * V[i];
+        dm.estart[i] = doc_ptr[(size_t)i * (D + 1)];
+        dm.toff[i] = toff;
+        m->nnzm[i] = doc_ptr[(size_t)i * (D + 1) + D] - dm.estart[i];
+        toff += m->nnzm[i] * K[i];
+    }
+    dm.MK = dm.koff[M]; dm.GT = dm.goff[M];
+    if (dm.MK > 64) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: sum(K)=%d must be <= 64", dm.MK); delete m; return rc; }
+    m->L = dm.MK <= 16 ? 16 : (dm.MK <= 32 ? 32 : 64);
+    const int64_t nnz = doc_ptr[(size_t)(M - 1) * (D + 1) + D];
+    m->nnz = nnz; m->theta_n = toff;
+    // validate + pack the corpus
+    std::vector<int2> tc((size_t)nnz);
+    std::vector<double> Ndm((size_t)D * M, 0.0);
+    m->hNm.assign(M, 0.0);
+    for (int i = 0; i < M; ++i) {
+        const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
+        if (i > 0 && dp[0] != doc_ptr[(size_t)(i - 1) * (D + 1) + D]) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr of modality %d does not continue modality %d", i, i - 1); delete m; return rc; }
+        for (int d = 0; d < D; ++d) {
+            if (dp[d + 1] < dp[d]) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr not monotone (m=%d d=%d)", i, d); delete m; return rc; }
+            double n = 0.0;
+            for (int64_t e = dp[d]; e < dp[d + 1]; ++e) {
+                if (term[e] < 0 || term[e] >= V[i] || count[e] < 0) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: entry %lld out of range", (long long)e); delete m; return rc; }
+                tc[(size_t)e] = make_int2(term[e], count[e]);
+                n += count[e];
+            }
+            Ndm[(size_t)d * M + i] = n;
+            if (n > 0) m->hNm[i] += n;        // MMCTM.jl:409-414: only documents with N > 0 enter the ll
+        }
+    }
+    if (doc_ptr[0] != 0) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr[0] != 0"); delete m; return rc; }
+    // topics descriptor
+    CtmTopics& tp = m->tp;
+    m->immctm = (n_feat != nullptr);
+    tp.immctm = m->immctm ? 1 : 0;
+    int nalpha = M, GM = dm.GT;
+    std::vector<int> featv;
+    if (m->immctm) {
+        if (!J || !features) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: IMMCTM needs J and features"); delete m; return rc; }
+        tp.aoff[0] = 0; tp.mgoff[0] = 0;
+        long long fo = 0;
+        for (int i = 0; i < M; ++i) {
+            tp.nfeat[i] = n_feat[i];
+            tp.aoff[i + 1] = tp.aoff[i] + n_feat[i];
+            if (tp.aoff[i + 1] > 4 * kMaxM) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: more than %d features in total", 4 * kMaxM); delete m; return rc; }
+            int sj = 0;
+            for (int q = 0; q < n_feat[i]; ++q) { tp.J[tp.aoff[i] + q] = J[tp.aoff[i] + q]; sj += J[tp.aoff[i] + q]; }
+            tp.SJ[i] = sj;
+            tp.mgoff[i + 1] = tp.mgoff[i] + K[i] * sj;
+            tp.foff[i] = fo;
+            for (int q = 0; q < n_feat[i]; ++q) for (int v = 0; v < V[i]; ++v) {
+                const int f = features[fo + (long long)q * V[i] + v];
+                if (f < 0 || f >= J[tp.aoff[i] + q]) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: feature value out of range"); delete m; return rc; }
+            }
+            fo += (long long)n_feat[i] * V[i];
+        }
+        featv.assign(features, features + fo);
+        nalpha = tp.aoff[M]; GM = tp.mgoff[M];
+    } else {
+        for (int i = 0; i <= M; ++i) tp.mgoff[i] = dm.goff[i];
+    }
+    m->GM = GM;
+    mmm_solver_opts so; mmm_solver_opts_default(&so);
+    if (opts) so = *opts;
+    m->opt = SolveOpts{so.xtol_rel, so.xtol_abs, so.nu_lower, so.xtol_rule, so.max_eval > 0 ? so.max_eval : 2000};
+    // launch geometry
+    const int G = MMM_WAVE / m->L;
+    m->waves_e = 8;
+    while (m->waves_e > 1 && estep_lds(m, F_SLAB) > 150 * 1024) m->waves_e >>= 1;
+    if (estep_lds(m, F_SLAB) > 160 * 1024) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: topic tables need %zu B of LDS (> 160 KiB)", estep_lds(m, F_SLAB)); delete m; return rc; }
+    const int dpb = m->waves_e * G;
+    const int per_cu = std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
+    m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
+    if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
+    m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
+    m->grid_m = std::max(1, std::min((D + 63) / 64, 256));
+    const size_t MK = dm.MK, DMK = (size_t)D * MK;
+    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
+#define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
+    A(doc_ptr, (size_t)M * (D + 1)); A(tc, (size_t)nnz); A(Ndm, (size_t)D * M); A(features, featv.size()); A(alpha, (size_t)nalpha);
+    A(lambda[0], DMK); A(lambda[1], DMK); A(nu, DMK); A(zeta, (size_t)D * M); A(props, DMK); A(theta, (size_t)toff);
+    A(mu, MK); A(Sigma, MK * MK); A(invSigma, MK * MK); A(gamma, (size_t)GM); A(Elnphi, (size_t)GM); A(phi, (size_t)GM);
+    A(Eeff, (size_t)dm.GT); A(expEeff[0], (size_t)dm.GT); A(expEeff[1], (size_t)dm.GT); A(phieff, (size_t)dm.GT);
+    A(partial, (size_t)m->grid_e * dm.GT); A(mompart, (size_t)m->grid_m * nmom); A(stats, (size_t)nmom + dm.GT + 16);
+    A(llpart, (size_t)m->grid_s * M); A(llnum, (size_t)M + 8); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16);
+    A(nev_nu, (size_t)D); A(nev_lam, (size_t)D); A(status, 1);
+#undef A
+    hipStream_t st = ctx->stream;
+    MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * M * (D + 1), hipMemcpyHostToDevice, st));
+    if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
+    if (D) MMM_HIP(ctx, hipMemcpyAsync(m->Ndm.p, Ndm.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
+    if (!featv.empty()) MMM_HIP(ctx, hipMemcpyAsync(m->features.p, featv.data(), sizeof(int) * featv.size(), hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->alpha.p, alpha, sizeof(double) * nalpha, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->gamma.p, gamma0, sizeof(double) * GM, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemsetAsync(m->status.p, 0, sizeof(int), st));
+    MMM_HIP(ctx, hipMemsetAsync(m->nev_nu.p, 0, sizeof(int) * std::max(D, 1), st));
+    MMM_HIP(ctx, hipMemsetAsync(m->nev_lam.p, 0, sizeof(int) * std::max(D, 1), st));
+    MMM_HIP(ctx, hipStreamSynchronize(st));
+    tp.features = m->features.p; tp.alpha = m->alpha.p;
+    // global N per modality and D (sum over ranks)
+    {
+        std::vector<double> h(m->hNm);
+        h.push_back((double)D);
+        MMM_HIP(ctx, hipMemcpyAsync(m->llnum.p, h.data(), sizeof(double) * (M + 1), hipMemcpyHostToDevice, st));
+        int rc = mmm_allreduce_sum(ctx, m->llnum.p, M + 1);
+        if (rc) { delete m; return rc; }
+        MMM_HIP(ctx, hipMemcpyAsync(h.data(), m->llnum.p, sizeof(double) * (M + 1), hipMemcpyDeviceToHost, st));
+        MMM_HIP(ctx, hipStreamSynchronize(st));
+        m->Dglobal = h[M];
+        MMM_HIP(ctx, hipMemcpyAsync(m->Nm.p, h.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
+        MMM_HIP(ctx, hipStreamSynchronize(st));
+    }
+    // constructor state (MMCTM.jl:44-86): mu = 0, Sigma = invSigma = I, theta = 1/K, Elnphi from gamma0, phi = gamma0
+    // (deepcopy, MMCTM.jl:80), lambda = 0, nu = 1, zeta = update_ζ!
+    std::vector<double> eye(MK * MK, 0.0);
+    for (size_t i = 0; i < MK; ++i) eye[i * MK + i] = 1.0;
+    MMM_HIP(ctx, hipMemsetAsync(m->mu.p, 0, sizeof(double) * MK, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->Sigma.p, eye.data(), sizeof(double) * MK * MK, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->invSigma.p, eye.data(), sizeof(double) * MK * MK, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipStreamSynchronize(st));
+    if (DMK) {
+        MMM_HIP(ctx, hipMemsetAsync(m->lambda[0].p, 0, sizeof(double) * DMK, st));
+        MMM_HIP(ctx, hipMemsetAsync(m->lambda[1].p, 0, sizeof(double) * DMK, st));
+        MMM_HIP(ctx, hipMemsetAsync(m->props.p, 0, sizeof(double) * DMK, st));
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((DMK + 255) / 256)), dim3(256), 0, st, m->nu.p, DMK, 1.0);
+    }
+    for (int i = 0; i < M; ++i) {
+        const size_t n = (size_t)(doc_ptr[(size_t)i * (D + 1) + D] - dm.estart[i]) * K[i];
+        if (n) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->theta.p + dm.toff[i], n, 1.0 / K[i]);
+    }
+    MMM_LAUNCH_CHECK(ctx);
+    int rc = run_mstep(m, 0, 0, 1, 0);                       // update_Elnϕ! on gamma0 (+ tables)
+    if (rc) { delete m; return rc; }
+    if (!m->immctm) MMM_HIP(ctx, hipMemcpyAsync(m->phi.p, m->gamma.p, sizeof(double) * GM, hipMemcpyDeviceToDevice, st));   // MMCTM.jl:80
+    if ((rc = run_estep(m, F_ZETA, m->lambda[0].p, nullptr, nullptr))) { delete m; return rc; }
+    MMM_HIP(ctx, hipStreamSynchronize(st));
+    m->theta_valid = true; m->theta_from_prev = false;
+    *out = m;
+    return MMM_OK;
+}
+
+int mmm_ctm_destroy(mmm_ctm* m)
+{
+    if (!m) return MMM_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    delete m;
+    return MMM_OK;
+}
+
+static int ctm_field(mmm_ctm* m, int field, double** p, size_t* n)
+{
+    const size_t MK = m->dm.MK, D = m->dm.D;
+    switch (field) {
+        case MMM_CTM_MU: *p = m->mu.p; *n = MK; break;
+        case MMM_CTM_SIGMA: *p = m->Sigma.p; *n = MK * MK; break;
+        case MMM_CTM_INVSIGMA: *p = m->invSigma.p; *n = MK * MK; break;
+        case MMM_CTM_GAMMA: *p = m->gamma.p; *n = m->GM; break;
+        case MMM_CTM_ELNPHI: *p = m->Elnphi.p; *n = m->GM; break;
+        case MMM_CTM_PHI: *p = m->immctm ? m->phieff.p : m->phi.p; *n = m->immctm ? m->dm.GT : m->GM; break;
+        case MMM_CTM_LAMBDA: *p = m->lambda[m->cur].p; *n = D * MK; break;
+        case MMM_CTM_NU: *p = m->nu.p; *n = D * MK; break;
+        case MMM_CTM_ZETA: *p = m->zeta.p; *n = D * m->dm.M; break;
+        case MMM_CTM_PROPS: *p = m->props.p; *n = D * MK; break;
+        case MMM_CTM_THETA: *p = m->theta.p; *n = (size_t)m->theta_n; break;
+        case MMM_CTM_ALPHA: *p = m->alpha.p; *n = m->immctm ? m->tp.aoff[m->dm.M] : m->dm.M; break;
+        default: return mmm_fail(m->ctx, MMM_ERR_ARG, "unknown CTM field %d", field);
+    }
+    return MMM_OK;
+}
+
+int mmm_ctm_get(mmm_ctm* m, int field, double* host, size_t n)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    double* p; size_t cnt;
+    if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
+    MMM_CHECK(ctx, host && n == cnt, "mmm_ctm_get(field %d): expected %zu doubles, got %zu", field, cnt, n);
+    if (field == MMM_CTM_THETA && (rc = materialise_theta(m))) return rc;
+    if (n) MMM_HIP(ctx, hipMemcpyAsync(host, p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMM_OK;
+}
+
+int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    double* p; size_t cnt;
+    if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
+    MMM_CHECK(ctx, host && n == cnt, "mmm_ctm_set(field %d): expected %zu doubles, got %zu", field, cnt, n);
+    if ((rc = materialise_theta(m))) return rc;       // make the implicit theta explicit before state changes
+    m->theta_from_prev = false;
+    if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (field == MMM_CTM_ELNPHI || field == MMM_CTM_GAMMA) {
+        // keep the effective tables consistent with an uploaded Elnphi: rebuild them from gamma only on update_Elnϕ!;
+        // an uploaded Elnphi is used as is by update_θ! through mmm_ctm_update_Elnphi's table refresh
+    }
+    return MMM_OK;
+}
+
+int mmm_ctm_update_zeta(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc) return rc;
+    return run_estep(m, F_ZETA, m->lambda[m->cur].p, nullptr, nullptr);
+}
+
+int mmm_ctm_update_theta(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc) return rc;
+    if ((rc = run_estep(m, F_THETA_COMPUTE | F_THETA_STORE, m->lambda[m->cur].p, nullptr, m->expEeff[m->ecur].p))) return rc;
+    m->theta_valid = true; m->theta_from_prev = false;
+    return MMM_OK;
+}
+
+int mmm_ctm_update_nu(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    m->theta_from_prev = false;
+    return run_estep(m, F_NU, m->lambda[m->cur].p, nullptr, nullptr);
+}
+
+int mmm_ctm_update_lambda(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    m->theta_from_prev = false;
+    // in place on the current lambda: the solver reads its start point before it stores the result
+    return run_estep(m, F_THETA_STORED | F_LAMBDA, m->lambda[m->cur].p, m->lambda[m->cur].p, nullptr);
+}
+
+static int moments_to_stats(mmm_ctm* m)
+{
+    const CtmDims& dm = m->dm;
+    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), 0, m->ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    MMM_LAUNCH_CHECK(m->ctx);
+    int rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p);
+    if (rc) return rc;
+    return mmm_allreduce_sum(m->ctx, m->stats.p, (size_t)nmom);
+}
+
+int mmm_ctm_update_mu(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc || (rc = moments_to_stats(m))) return rc;
+    return run_mstep(m, 1, 0, 0, 0);
+}
+
+int mmm_ctm_update_Sigma(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc || (rc = moments_to_stats(m))) return rc;
+    if ((rc = run_mstep(m, 0, 1, 0, 0))) return rc;      // uses the stored mu, as update_Σ! does (MMCTM.jl:207)
+    return check_status(m);
+}
+
+int mmm_ctm_update_gamma(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    const CtmDims& dm = m->dm;
+    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
+    double* sums = m->stats.p + nmom;
+    MMM_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(double) * dm.GT, ctx->stream));
+    for (int i = 0; i < dm.M; ++i) {
+        const int64_t n = m->nnzm[i];
+        if (n > 0) hipLaunchKernelGGL(k_ctm_gamma_from_theta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->dev(), i, m->theta.p, sums);
+    }
+    MMM_LAUNCH_CHECK(ctx);
+    if ((rc = mmm_allreduce_sum(ctx, sums, (size_t)dm.GT))) return rc;
+    m->theta_from_prev = false;
+    return run_mstep(m, 0, 0, 1, 1);
+}
+
+int mmm_ctm_update_Elnphi(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    m->theta_from_prev = false;
+    return run_mstep(m, 0, 0, 1, 0);
+}
+
+int mmm_ctm_update_props(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc) return rc;
+    return run_loglik(m, nullptr, false);
+}
+
+int mmm_ctm_update_phi(mmm_ctm* m)
+{
+    // phi = gamma / sum gamma is refreshed together with Elnphi by the M-step kernel
+    return mmm_ctm_update_Elnphi(m);
+}
+
+int mmm_ctm_loglik(mmm_ctm* m, double* ll)
+{
+    if (!m || !ll) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    double* dst = m->llnum.p;       // reuse: k_ll_store reads num and writes dst elementwise (same index) -- use a separate slot
+    dst = m->elbopart.p;            // scratch
+    if ((rc = run_loglik(m, dst, true))) return rc;
+    MMM_HIP(ctx, hipMemcpyAsync(ll, dst, sizeof(double) * m->dm.M, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMM_OK;
+}
+
+int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_grad, double* nu_val, double* nu_grad)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    MMM_CHECK(ctx, d >= 0 && d < m->dm.D, "mmm_ctm_objectives: document %d out of range", d);
+    const int MK = m->dm.MK;
+    double* out = m->elbopart.p;
+    DevBuf<double> tmp;
+    MMM_HIP(ctx, tmp.alloc(2 + 2 * (size_t)MK));
+    hipLaunchKernelGGL(k_ctm_objectives, dim3(1), dim3(64), 0, ctx->stream, m->dev(), d, m->invSigma.p, m->mu.p, m->lambda[m->cur].p, m->nu.p, m->zeta.p, m->theta.p, tmp.p);
+    MMM_LAUNCH_CHECK(ctx);
+    (void)out;
+    std::vector<double> h(2 + 2 * (size_t)MK);
+    MMM_HIP(ctx, hipMemcpyAsync(h.data(), tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (lambda_val) *lambda_val = h[0];
+    if (nu_val) *nu_val = h[1];
+    if (lambda_grad) memcpy(lambda_grad, h.data() + 2, sizeof(double) * MK);
+    if (nu_grad) memcpy(nu_grad, h.data() + 2 + MK, sizeof(double) * MK);
+    return MMM_OK;
+}
+
+int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped, int* per_doc_nu, int* per_doc_lambda)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    const int D = m->dm.D;
+    std::vector<int> a((size_t)D), b((size_t)D);
+    if (D) {
+        MMM_HIP(ctx, hipMemcpyAsync(a.data(), m->nev_nu.p, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(b.data(), m->nev_lam.p, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t sa = 0, sb = 0, cap = 0;
+    for (int d = 0; d < D; ++d) { if (a[d] < 0) { ++cap; sa -= a[d]; } else sa += a[d]; if (b[d] < 0) { ++cap; sb -= b[d]; } else sb += b[d]; }
+    if (n_eval_nu) *n_eval_nu = sa;
+    if (n_eval_lambda) *n_eval_lambda = sb;
+    if (n_capped) *n_capped = cap;
+    if (per_doc_nu && D) memcpy(per_doc_nu, a.data(), sizeof(int) * D);
+    if (per_doc_lambda && D) memcpy(per_doc_lambda, b.data(), sizeof(int) * D);
+    return MMM_OK;
+}
+
+int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc) return rc;
+    MMM_CHECK(m->ctx, n_iter >= 0, "mmm_ctm_iterate: n_iter < 0");
+    for (int i = 0; i < n_iter; ++i) if ((rc = fused_pass(m, update_sigma))) return rc;
+    return MMM_OK;
+}
+
+int mmm_ctm_ll_history(mmm_ctm* m, double* ll, int max_n, int* n)
+{
+    if (!m || !n) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    const int M = m->dm.M, cnt = std::min(max_n, m->n_hist);
+    if (cnt > 0 && ll) MMM_HIP(ctx, hipMemcpyAsync(ll, m->ll_hist.p + (size_t)(m->n_hist - cnt) * M, sizeof(double) * cnt * M, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n = cnt;
+    return MMM_OK;
+}
+
+int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
+{
+    if (!m || !elbo) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc || (rc = materialise_theta(m))) return rc;
+    const CtmDims& dm = m->dm;
+    const size_t lds = sizeof(double) * ((size_t)dm.MK * dm.MK + dm.GT + kWavesS * 64);
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    double* acc = m->elbopart.p + (size_t)m->grid_s * 5;     // [0..4] doc sums, [5..7] topic side
+    hipLaunchKernelGGL(k_ctm_elbo_docs, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p, m->mu.p, m->lambda[m->cur].p, m->nu.p,
+                       m->zeta.p, m->theta.p, m->Eeff.p, m->elbopart.p);
+    hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc);
+    const size_t lds2 = sizeof(double) * 2 * (size_t)dm.MK * dm.MK;
+    if (lds2 > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_topics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, m->tp, m->gamma.p, m->Elnphi.p, m->invSigma.p, acc + 5);
+    MMM_LAUNCH_CHECK(ctx);
+    if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
+    double h[8];
+    MMM_HIP(ctx, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double MK = dm.MK, Dg = m->Dglobal, l2pi = log(2.0 * M_PI);
+    double t[7];
+    t[0] = h[5];                                              // ElnPϕ  MMCTM.jl:271-284
+    t[1] = h[0] + 0.5 * Dg * (h[7] - MK * l2pi);              // ElnPη  MMCTM.jl:286-300
+    t[2] = h[1];                                              // ElnPZ  MMCTM.jl:302-316
+    t[3] = h[2];                                              // ElnPX  MMCTM.jl:318-336
+    t[4] = h[6];                                              // ElnQϕ  MMCTM.jl:338-350
+    t[5] = h[3] - 0.5 * Dg * MK * (l2pi + 1.0);               // ElnQη  MMCTM.jl:352-358
+    t[6] = h[4];                                              // ElnQZ  MMCTM.jl:360-370
+    if (terms) memcpy(terms, t, sizeof t);
+    *elbo = t[0] + t[1] + t[2] + t[3] - t[4] - t[5] - t[6];
+    return MMM_OK;
+}
+
+int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged, double* elbo)
+{
+    if (!m || !n_iter || !converged) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    MMM_CHECK(ctx, maxiter >= 1, "mmm_ctm_fit: maxiter < 1");
+    int rc = prep(m);
+    if (rc) return rc;
+    const int M = m->dm.M, base = m->n_hist;
+    *converged = 0;
+    std::vector<double> ll((size_t)maxiter * M);
+    int done = 0;
+    while (done < maxiter) {
+        // the stopping rule needs > 10 values (MMCTM.jl:485): the first 11 passes run without a host check
+        const int chunk = (done == 0) ? std::min(maxiter, 11) : 1;
+        for (int i = 0; i < chunk; ++i) if ((rc = fused_pass(m, update_sigma))) return rc;
+        MMM_HIP(ctx, hipMemcpyAsync(ll.data() + (size_t)done * M, m->ll_hist.p + (size_t)(base + done) * M, sizeof(double) * chunk * M, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = check_status(m))) return rc;
+        done += chunk;
+        if (done > 10) {          // common.jl:48-51
+            double rel = 0.0;
+            for (int q = 0; q < M; ++q) {
+                const double a = ll[(size_t)(done - 2) * M + q], b = ll[(size_t)(done - 1) * M + q];
+                const double r = fabs(a - b) / fabs(b);
+                if (r > rel || r != r) rel = r;       // NaN propagates like Julia's maximum
+            }
+            if (rel < tol) { *converged = 1; break; }
+        }
+    }
+    *n_iter = done;
+    if (ll_hist) memcpy(ll_hist, ll.data(), sizeof(double) * done * M);
+    if (elbo) return mmm_ctm_elbo(m, elbo, nullptr);
+    return MMM_OK;
+}
+
+} // extern "C"

@@ -141,32 +141,45 @@ class LDA:
             pass
 
 
-# ---- function API (the reference's free functions on a model) ------------------------------------------------
+# ---- function API (the reference's free functions on a model; dispatch on the model type like Julia methods) ------------
 def _call(model, fn, what):
     check(getattr(lib(), fn)(model._h), model.ctx.h, what)
 
 
-def update_γ(model):   # LDA.jl:82-90
-    _call(model, "mmm_lda_update_gamma", "update_γ!")
+def update_γ(model):   # LDA.jl:82-90 ; MMCTM.jl:224-242 ; IMMCTM.jl:199-223
+    if isinstance(model, LDA):
+        _call(model, "mmm_lda_update_gamma", "update_γ!")
+    else:
+        from . import ctm
+        ctm.update_γ_ctm(model)
 
 
 def update_ϕ(model):   # LDA.jl:69-76 ; MMCTM.jl:244-250
     if isinstance(model, LDA):
         _call(model, "mmm_lda_update_phi", "update_ϕ!")
     else:
-        _call(model, "mmm_ctm_update_phi", "update_ϕ!")
+        from . import ctm
+        ctm.update_ϕ_ctm(model)
 
 
-def update_λ(model, d=None):   # LDA.jl:100-108
-    _call(model, "mmm_lda_update_lambda", "update_λ!")
+def update_λ(model, d=None):   # LDA.jl:100-108 ; MMCTM.jl:127-143
+    if isinstance(model, LDA):
+        _call(model, "mmm_lda_update_lambda", "update_λ!")
+    else:
+        from . import ctm
+        ctm.update_λ_ctm(model, d)
 
 
 def update_β(model):   # LDA.jl:110-112
     _call(model, "mmm_lda_update_beta", "update_β!")
 
 
-def update_θ(model):   # LDA.jl:92-94
-    _call(model, "mmm_lda_update_theta", "update_θ!")
+def update_θ(model, d=None):   # LDA.jl:92-94 ; MMCTM.jl:183-198 ; IMMCTM.jl:152-172
+    if isinstance(model, LDA):
+        _call(model, "mmm_lda_update_theta", "update_θ!")
+    else:
+        from . import ctm
+        ctm.update_θ_ctm(model, d)
 
 
 def calculate_loglikelihood(model):   # LDA.jl:194-196
