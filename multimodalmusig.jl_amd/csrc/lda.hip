@@ -995,7 +995,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     double hd[2] = {0.0, (double)D};
     MMM_HIP(ctx, hipMemcpyAsync(&hd[0], ncount, sizeof(double), hipMemcpyDeviceToHost, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));
-    if (ctx->nranks > 1) {
+    if (ctx->comm) {
         MMM_HIP(ctx, hipMemcpyAsync(ncount, hd, sizeof hd, hipMemcpyHostToDevice, st));
         int rc = mmm_allreduce_sum(ctx, ncount, 2);
         if (rc) { delete m; return rc; }

@@ -91,7 +91,12 @@ struct DevBuf {
 // sum-all-reduce of a packed double buffer across the ranks of ctx (no-op for a single rank)
 inline int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
 {
-    if (ctx->nranks <= 1 || !ctx->comm) return MMM_OK;
+    if (!ctx->comm) return MMM_OK;
+    if (ctx->nranks <= 1) {
+        // a one-rank communicator is only exercised on request (MMM_FORCE_RCCL=1: lets a single-GPU box run the RCCL path)
+        static const bool force = getenv("MMM_FORCE_RCCL") != nullptr;
+        if (!force) return MMM_OK;
+    }
     MMM_NCCL(ctx, ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     return MMM_OK;
 }

@@ -1,0 +1,306 @@
+# MultiModalMuSigHIP.jl -- drop-in Julia front-end over libmmmusig_hip.so (include/mmmusig.h).
+#
+# Same exported names and call signatures as MultiModalMuSig.jl (src/MultiModalMuSig.jl:9):
+#     IMMCTM, MMCTM, LDA, fit!, format_counts_lda, format_counts_ctm, format_counts_mmctm
+# and the same struct field names; every hot-path function is one `ccall`.  Model state lives in HBM inside the
+# library handle; after `fit!` the fields the reference exposes (ϕ, θ, γ, λ, μ, Σ, props, elbo, ll, converged, ...) are
+# downloaded into ordinary Julia arrays of the reference's shapes.
+#
+# STATUS: Julia is not installed in the build container or on the GPU test boxes, so this file has NOT been executed;
+# it is a 1:1 mechanical mapping onto the C ABI (each ccall's argument list is the corresponding prototype of
+# include/mmmusig.h), which itself is exercised end-to-end by the Python host mirror and the test-suite.
+#
+# Random initialisation is drawn here with `rand(1:100, ...)` in the same order as the reference constructors
+# (LDA.jl:36; MMCTM.jl:60-63; IMMCTM.jl:59-65), so `Random.seed!` behaves as upstream.
+module MultiModalMuSigHIP
+
+using DataFrames
+
+export IMMCTM, MMCTM, LDA, fit!, format_counts_lda, format_counts_ctm, format_counts_mmctm
+
+const LIB = get(ENV, "MMM_LIB_PATH", joinpath(@__DIR__, "..", "lib", "libmmmusig_hip.so"))
+
+# ---- context ------------------------------------------------------------------------------------------------------
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer=0)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:mmm_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, out)
+        rc == 0 || error("mmm_ctx_create: " * unsafe_string(ccall((:mmm_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+        ctx = new(out[])
+        finalizer(c -> ccall((:mmm_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), ctx)
+        return ctx
+    end
+end
+
+const DEFAULT_CTX = Ref{Union{Nothing,Context}}(nothing)
+default_context() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context(0)); DEFAULT_CTX[])
+
+function check(rc::Cint, ctx::Context, what::String)
+    rc == 0 || error(what * ": " * unsafe_string(ccall((:mmm_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.h)))
+    nothing
+end
+
+# ---- count formatting (identical to src/utils.jl:1-36) --------------------------------------------------------------
+function make_count_matrix(counts)
+    idx = findall(counts .> 0)
+    countmat = Array{Int}(undef, length(idx), 2)
+    countmat[:, 1] = idx
+    countmat[:, 2] = counts[idx]
+    return countmat
+end
+format_counts_lda(df::DataFrame, cols::Vector{Symbol}) = Matrix{Int}[make_count_matrix(convert(Array, df[!, c])) for c in cols]
+format_counts_mmctm(dfs::Vector{DataFrame}, cols::Vector{Symbol}) =
+    Vector{Matrix{Int}}[Matrix{Int}[make_count_matrix(convert(Array, df[!, c])) for df in dfs] for c in cols]
+format_counts_ctm(df::DataFrame, cols::Vector{Symbol}) = format_counts_mmctm([df], cols)
+
+# CSR packing expected by the ABI: 0-based Int32 terms, Int32 counts, Int64 offsets
+function pack_lda(X::Vector{Matrix{Int}})
+    D = length(X)
+    doc_ptr = zeros(Int64, D + 1)
+    for d in 1:D doc_ptr[d + 1] = doc_ptr[d] + size(X[d], 1) end
+    term = Vector{Int32}(undef, doc_ptr[end]); count = Vector{Int32}(undef, doc_ptr[end])
+    for d in 1:D, w in 1:size(X[d], 1)
+        term[doc_ptr[d] + w] = X[d][w, 1] - 1
+        count[doc_ptr[d] + w] = X[d][w, 2]
+    end
+    return doc_ptr, term, count
+end
+
+function pack_mm(X::Vector{Vector{Matrix{Int}}}, M::Int)
+    D = length(X)
+    doc_ptr = zeros(Int64, M * (D + 1)); term = Int32[]; count = Int32[]
+    base = 0
+    for m in 1:M
+        dp, t, c = pack_lda(Matrix{Int}[X[d][m] for d in 1:D])
+        doc_ptr[(m - 1) * (D + 1) + 1:m * (D + 1)] = dp .+ base
+        base += dp[end]; append!(term, t); append!(count, c)
+    end
+    return doc_ptr, term, count
+end
+
+# ---- LDA (struct fields as LDA.jl:1-22) ---------------------------------------------------------------------------------
+mutable struct LDA
+    K::Int; D::Int; N::Vector{Int}; V::Int
+    η::Float64; λ::Matrix{Float64}; β::Matrix{Float64}; Elnβ::Matrix{Float64}
+    α::Float64; γ::Matrix{Float64}; θ::Matrix{Float64}; Elnθ::Matrix{Float64}
+    ϕ::Vector{Matrix{Float64}}
+    X::Vector{Matrix{Int}}
+    converged::Bool; elbo::Float64; ll::Float64
+    ctx::Context; h::Ptr{Cvoid}; doc_ptr::Vector{Int64}
+
+    function LDA(k::Int, α::Float64, η::Float64, V::Int, X::Vector{Matrix{Int}}; ctx::Context=default_context())
+        model = new()
+        model.K = k; model.α = α; model.η = η; model.X = X; model.D = length(X); model.V = V
+        model.N = [sum(X[d][:, 2]) for d in 1:model.D]
+        model.λ = rand(1:100, V, k)                                   # LDA.jl:36
+        doc_ptr, term, count = pack_lda(X)
+        model.doc_ptr = doc_ptr; model.ctx = ctx
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mmm_lda_create, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Cint, Cdouble, Cdouble, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+                    ctx.h, model.D, V, k, α, η, doc_ptr, term, count, model.λ, out), ctx, "mmm_lda_create")
+        model.h = out[]
+        finalizer(m -> ccall((:mmm_lda_destroy, LIB), Cint, (Ptr{Cvoid},), m.h), model)
+        model.converged = false
+        download!(model)
+        return model
+    end
+end
+
+function LDA(k::Int, α::Float64, η::Float64, X::Vector{Matrix{Int}}; kw...)     # LDA.jl:57-67
+    V = 0
+    for d in 1:length(X)
+        size(X[d], 1) > 0 && (V = max(V, maximum(X[d][:, 1])))
+    end
+    return LDA(k, α, η, V, X; kw...)
+end
+
+function lda_get(model::LDA, field::Int, n::Int)
+    buf = Vector{Float64}(undef, n)
+    check(ccall((:mmm_lda_get, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, buf, n), model.ctx, "mmm_lda_get")
+    return buf
+end
+
+function download!(model::LDA)
+    V, K, D = model.V, model.K, model.D
+    model.λ = reshape(lda_get(model, 0, V * K), V, K); model.Elnβ = reshape(lda_get(model, 1, V * K), V, K)
+    model.β = reshape(lda_get(model, 2, V * K), V, K)
+    model.γ = reshape(lda_get(model, 3, K * D), K, D); model.Elnθ = reshape(lda_get(model, 4, K * D), K, D)
+    model.θ = reshape(lda_get(model, 5, K * D), K, D)
+    flat = lda_get(model, 6, K * model.doc_ptr[end])
+    model.ϕ = [reshape(flat[K * model.doc_ptr[d] + 1:K * model.doc_ptr[d + 1]], K, :) for d in 1:D]
+    return model
+end
+
+# fit!(model; maxiter, tol, verbose) -- LDA.jl:198-224
+function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true)
+    ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_lda_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+                model.h, maxiter, tol, ll, n, cv, elbo), model.ctx, "mmm_lda_fit")
+    resize!(ll, n[])
+    if verbose
+        for (iter, v) in enumerate(ll) println("$iter\tLog-likelihood: ", v) end
+    end
+    model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = ll[end]
+    download!(model)
+    return ll
+end
+
+# ---- MMCTM / IMMCTM (struct fields as MMCTM.jl:1-27 / IMMCTM.jl:1-27) -----------------------------------------------------
+struct SolverOpts
+    xtol_rel::Cdouble; xtol_abs::Cdouble; nu_lower::Cdouble; xtol_rule::Cint; max_eval::Cint
+end
+
+mutable struct MMCTM
+    K::Vector{Int}; D::Int; N::Vector{Vector{Int}}; M::Int; V::Vector{Int}
+    μ::Vector{Float64}; Σ::Matrix{Float64}; invΣ::Matrix{Float64}
+    props::Vector{Vector{Vector{Float64}}}; α::Vector{Float64}; ϕ::Vector{Vector{Vector{Float64}}}
+    ζ::Vector{Vector{Float64}}; θ::Vector{Vector{Matrix{Float64}}}; λ::Vector{Vector{Float64}}; ν::Vector{Vector{Float64}}
+    γ::Vector{Vector{Vector{Float64}}}; Elnϕ::Vector{Vector{Vector{Float64}}}
+    X::Vector{Vector{Matrix{Int}}}
+    converged::Bool; elbo::Float64; ll::Vector{Float64}
+    ctx::Context; h::Ptr{Cvoid}; doc_ptr::Vector{Int64}
+
+    function MMCTM(k::Vector{Int}, α::Vector{Float64}, V::Vector{Int}, X::Vector{Vector{Matrix{Int}}};
+                   init=:random, ctx::Context=default_context())
+        init == :random || error("init must be either :random or :document")      # MMCTM.jl:76
+        model = new()
+        model.K = copy(k); model.α = copy(α); model.X = X; model.D = length(X); model.M = length(k); model.V = copy(V)
+        model.N = [[sum(X[d][m][:, 2]) for m in 1:model.M] for d in 1:model.D]
+        model.γ = [[Float64.(rand(1:100, model.V[m])) for kk in 1:model.K[m]] for m in 1:model.M]   # MMCTM.jl:60-63
+        gamma0 = vcat([vcat(model.γ[m]...) for m in 1:model.M]...)
+        doc_ptr, term, count = pack_mm(X, model.M)
+        model.doc_ptr = doc_ptr; model.ctx = ctx
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mmm_ctm_create, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32},
+                     Ptr{Cint}, Ptr{Cint}, Ptr{Int32}, Ptr{Cdouble}, Ptr{SolverOpts}, Ref{Ptr{Cvoid}}),
+                    ctx.h, model.D, model.M, Cint.(k), Cint.(V), α, doc_ptr, term, count, C_NULL, C_NULL, C_NULL, gamma0, C_NULL, out),
+              ctx, "mmm_ctm_create")
+        model.h = out[]
+        finalizer(m -> ccall((:mmm_ctm_destroy, LIB), Cint, (Ptr{Cvoid},), m.h), model)
+        model.converged = false
+        download!(model)
+        return model
+    end
+end
+
+function MMCTM(k::Vector{Int}, α::Vector{Float64}, X::Vector{Vector{Matrix{Int}}}; kw...)    # MMCTM.jl:94-108
+    M = length(k); V = zeros(Int, M)
+    for d in 1:length(X), m in 1:M
+        size(X[d][m], 1) > 0 && (V[m] = max(V[m], maximum(X[d][m][:, 1])))
+    end
+    return MMCTM(k, α, V, X; kw...)
+end
+
+function ctm_get(model, field::Int, n::Int)
+    buf = Vector{Float64}(undef, n)
+    check(ccall((:mmm_ctm_get, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, buf, n), model.ctx, "mmm_ctm_get")
+    return buf
+end
+
+function download!(model::MMCTM)
+    M, D, K, V = model.M, model.D, model.K, model.V
+    MK = sum(K); koff = cumsum([0; K]); goff = cumsum([0; K .* V])
+    model.μ = ctm_get(model, 0, MK); model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK); model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
+    nest(flat) = [[flat[goff[m] + (kk - 1) * V[m] + 1:goff[m] + kk * V[m]] for kk in 1:K[m]] for m in 1:M]
+    model.γ = nest(ctm_get(model, 3, goff[end])); model.Elnϕ = nest(ctm_get(model, 4, goff[end])); model.ϕ = nest(ctm_get(model, 5, goff[end]))
+    lam = reshape(ctm_get(model, 6, D * MK), MK, D); nu = reshape(ctm_get(model, 7, D * MK), MK, D)
+    model.λ = [lam[:, d] for d in 1:D]; model.ν = [nu[:, d] for d in 1:D]
+    z = reshape(ctm_get(model, 8, D * M), M, D); model.ζ = [z[:, d] for d in 1:D]
+    pr = reshape(ctm_get(model, 9, D * MK), MK, D)
+    model.props = [[pr[koff[m] + 1:koff[m + 1], d] for m in 1:M] for d in 1:D]
+    dp = model.doc_ptr
+    estart = [dp[(m - 1) * (D + 1) + 1] for m in 1:M]
+    nnz = [dp[m * (D + 1)] - estart[m] for m in 1:M]
+    toff = cumsum([0; nnz .* K])
+    th = ctm_get(model, 10, toff[end])
+    model.θ = [[reshape(th[toff[m] + (dp[(m - 1) * (D + 1) + d] - estart[m]) * K[m] + 1:toff[m] + (dp[(m - 1) * (D + 1) + d + 1] - estart[m]) * K[m]], K[m], :)
+                for m in 1:M] for d in 1:D]
+    return model
+end
+
+# fit!(model; maxiter, tol, verbose, autoα, updateΣ) -- MMCTM.jl:457-494
+function fit!(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true)
+    autoα && error("autoα (update_α!) is not part of the HIP backend")
+    M = model.M
+    ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+                model.h, maxiter, tol, updateΣ ? 1 : 0, ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
+    hist = [ll[(i - 1) * M + 1:i * M] for i in 1:n[]]
+    if verbose
+        for (iter, v) in enumerate(hist) println("$iter\tLog-likelihoods: ", join(v, ", ")) end
+    end
+    model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = hist[end]
+    download!(model)
+    return hist
+end
+
+# IMMCTM(k, α, features, X) -- IMMCTM.jl:29-88: same handle type on the C side (mmm_ctm_create with n_feat/J/features);
+# the field download mirrors MMCTM with γ/Elnϕ nested one level deeper ([m][k][i][j]) and no props/ϕ fields.
+mutable struct IMMCTM
+    K::Vector{Int}; D::Int; N::Vector{Vector{Int}}; M::Int; I::Vector{Int}; J::Vector{Vector{Int}}; V::Vector{Int}
+    μ::Vector{Float64}; Σ::Matrix{Float64}; invΣ::Matrix{Float64}; α::Vector{Vector{Float64}}
+    ζ::Vector{Vector{Float64}}; θ::Vector{Vector{Matrix{Float64}}}; λ::Vector{Vector{Float64}}; ν::Vector{Vector{Float64}}
+    γ::Vector{Vector{Vector{Vector{Float64}}}}; Elnϕ::Vector{Vector{Vector{Vector{Float64}}}}
+    features::Vector{Matrix{Int}}; X::Vector{Vector{Matrix{Int}}}
+    converged::Bool; elbo::Float64; ll::Vector{Float64}
+    ctx::Context; h::Ptr{Cvoid}; doc_ptr::Vector{Int64}
+
+    function IMMCTM(k::Vector{Int}, α::Vector{Vector{Float64}}, features::Vector{Matrix{Int}}, X::Vector{Vector{Matrix{Int}}};
+                    ctx::Context=default_context())
+        model = new()
+        model.K = copy(k); model.α = deepcopy(α); model.features = deepcopy(features); model.X = X
+        model.D = length(X); model.M = length(features)
+        model.I = [size(features[m])[2] for m in 1:model.M]
+        model.J = [vec(maximum(features[m], dims=1)) for m in 1:model.M]
+        model.V = [size(features[m])[1] for m in 1:model.M]
+        model.N = [[sum(X[d][m][:, 2]) for m in 1:model.M] for d in 1:model.D]
+        model.γ = [[[Float64.(rand(1:100, model.J[m][i])) for i in 1:model.I[m]] for kk in 1:model.K[m]] for m in 1:model.M]  # IMMCTM.jl:59-65
+        gamma0 = vcat([vcat([vcat(model.γ[m][kk]...) for kk in 1:model.K[m]]...) for m in 1:model.M]...)
+        featflat = Int32.(vcat([vec(features[m] .- 1) for m in 1:model.M]...))       # [foff[m] + (i-1)*V + v], 0-based values
+        doc_ptr, term, count = pack_mm(X, model.M)
+        model.doc_ptr = doc_ptr; model.ctx = ctx
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mmm_ctm_create, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32},
+                     Ptr{Cint}, Ptr{Cint}, Ptr{Int32}, Ptr{Cdouble}, Ptr{SolverOpts}, Ref{Ptr{Cvoid}}),
+                    ctx.h, model.D, model.M, Cint.(k), Cint.(model.V), vcat(α...), doc_ptr, term, count,
+                    Cint.(model.I), Cint.(vcat(model.J...)), featflat, gamma0, C_NULL, out), ctx, "mmm_ctm_create")
+        model.h = out[]
+        finalizer(m -> ccall((:mmm_ctm_destroy, LIB), Cint, (Ptr{Cvoid},), m.h), model)
+        model.converged = false
+        return model
+    end
+end
+
+function IMMCTM(k::Vector{Int}, α::Vector{Float64}, features::Vector{Matrix{Int}}, X::Vector{Vector{Matrix{Int}}}; kw...)   # IMMCTM.jl:81-88
+    I = [size(features[m])[2] for m in 1:length(features)]
+    return IMMCTM(k, Vector{Float64}[fill(α[m], I[m]) for m in 1:length(features)], features, X; kw...)
+end
+
+function fit!(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false)    # IMMCTM.jl:437-466
+    autoα && error("autoα (update_α!) is not part of the HIP backend")
+    M = model.M
+    ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+                model.h, maxiter, tol, 1, ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
+    hist = [ll[(i - 1) * M + 1:i * M] for i in 1:n[]]
+    if verbose
+        for (iter, v) in enumerate(hist) println("$iter\tLog-likelihoods: ", join(v, ", ")) end
+    end
+    model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = hist[end]
+    MK = sum(model.K); D = model.D
+    model.μ = ctm_get(model, 0, MK); model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK); model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
+    lam = reshape(ctm_get(model, 6, D * MK), MK, D); nu = reshape(ctm_get(model, 7, D * MK), MK, D)
+    model.λ = [lam[:, d] for d in 1:D]; model.ν = [nu[:, d] for d in 1:D]
+    SJ = [sum(model.J[m]) for m in 1:M]; mgoff = cumsum([0; model.K .* SJ])
+    gflat = ctm_get(model, 3, mgoff[end]); eflat = ctm_get(model, 4, mgoff[end])
+    nest(flat) = [[[flat[mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i - 1]) + 1:mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i])]
+                    for i in 1:model.I[m]] for kk in 1:model.K[m]] for m in 1:M]
+    model.γ = nest(gflat); model.Elnϕ = nest(eflat)
+    return hist
+end
+
+end # module

@@ -1,0 +1,46 @@
+"""The RCCL code path on a single-GPU box: a one-rank communicator with MMM_FORCE_RCCL=1 makes every all-reduce of the
+packed sufficient statistics go through ncclAllReduce on the context stream.  Results must equal the plain path exactly
+(a one-rank sum is the identity).  Runs in a child process because the flag is read once per process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, mmm_pkg, np_ref
+pkg = mmm_pkg.load()
+ctx = pkg.Context(0)
+if os.environ.get("MMM_FORCE_RCCL"):
+    ctx.init_comm(1, 0, pkg.comm_unique_id())
+X, lam0 = np_ref.synth_lda(300, 96, 10, seed=9, mean_n=800)
+g = pkg.LDA(10, 0.1, 0.1, 96, X, λ0=lam0, ctx=ctx)
+ll = pkg.fit(g, maxiter=14, tol=0.0, verbose=False)
+Xm, g0 = np_ref.synth_mm(120, [40, 24], [5, 4], seed=4, means=[600, 80], empty_frac=0.1)
+c = pkg.MMCTM([5, 4], [0.1, 0.1], [40, 24], Xm, γ0=g0, ctx=ctx)
+llc = pkg.fit(c, maxiter=5, tol=0.0, verbose=False)
+print("RESULT " + json.dumps({"ll": ll.tolist(), "elbo": g.elbo, "lam": g.λ.sum(), "llc": llc.tolist(), "elboc": c.elbo, "mu": c.μ.tolist()}))
+"""
+
+
+def _run(force):
+    env = dict(os.environ)
+    env.pop("MMM_FORCE_RCCL", None)
+    if force:
+        env["MMM_FORCE_RCCL"] = "1"
+    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_one_rank_rccl_path_equals_plain_path():
+    a, b = _run(False), _run(True)
+    assert a["ll"] == b["ll"] and a["elbo"] == b["elbo"] and a["lam"] == b["lam"]
+    assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
