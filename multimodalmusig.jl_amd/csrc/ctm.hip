@@ -103,7 +103,16 @@ struct LamObj {
         scr[l] = diff;
         lds_wave_sync();
         double Sd = 0.0;
-        if (act) for (int j = 0; j < MK; ++j) Sd = fma(sS[j * MK + l], scr[j], Sd);
+        if (act) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // four independent chains, combined pairwise
+            int j = 0;
+            for (; j + 3 < MK; j += 4) {
+                s0 = fma(sS[j * MK + l], scr[j], s0); s1 = fma(sS[(j + 1) * MK + l], scr[j + 1], s1);
+                s2 = fma(sS[(j + 2) * MK + l], scr[j + 2], s2); s3 = fma(sS[(j + 3) * MK + l], scr[j + 3], s3);
+            }
+            for (; j < MK; ++j) s0 = fma(sS[j * MK + l], scr[j], s0);
+            Sd = (s0 + s1) + (s2 + s3);
+        }
         const double E = exp(x + 0.5 * nu);
         g = act ? Sd - sumth + c * E : 0.0;
         const double t = act ? 0.5 * diff * Sd - x * sumth + c * E : 0.0;
@@ -143,33 +152,35 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         const double gval = fbest + group_sum<L>(gl);
         const double wval = group_sum<L>(wl);
         const double fcur = obj.template eval<L>(xc, gcur);
+        bool inner_done = false;
         if (!done) {
             ++nev;
             xcur = xc;
-            const bool inner_done = gval >= fcur;
+            inner_done = gval >= fcur;
             if (fcur < fbest) { fbest = fcur; x = xc; grad = gcur; }
-            if (nev >= cap) { done = true; capped = true; }
-            else if (!inner_done) {
-                if (fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + (fcur - gval) / wval));
+            if (nev >= cap) { done = true; capped = true; inner_done = false; }
+            else if (!inner_done && fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + (fcur - gval) / wval));
+        }
+        // outer iteration finished in at least one group of this wave: NLopt's x-tolerance test on (xcur, xprev)
+        if (__any(inner_done)) {
+            const double ad = fabs(xcur - xprev);
+            bool stop;
+            if (o.xtol_rule == 0) {
+                const double dn = group_sum<L>(act ? ad : 0.0), xn = group_sum<L>(act ? fabs(xcur) : 0.0);
+                stop = (dn < o.xtol_rel * xn) || group_none<L>(act && !(ad < o.xtol_abs), g);
             } else {
-                // outer iteration finished: NLopt's x-tolerance test on (xcur, xprev)
-                const double ad = fabs(xcur - xprev);
-                bool stop;
-                if (o.xtol_rule == 0) {
-                    const double dn = group_sum<L>(act ? ad : 0.0), xn = group_sum<L>(act ? fabs(xcur) : 0.0);
-                    stop = (dn < o.xtol_rel * xn) || group_none<L>(act && !(ad < o.xtol_abs), g);
-                } else {
-                    const bool ok = isinf(xprev) ? false
-                                                  : (ad < o.xtol_abs || ad < o.xtol_rel * (fabs(xcur) + fabs(xprev)) * 0.5 ||
-                                                     (o.xtol_rel > 0 && xcur == xprev));
-                    stop = group_none<L>(act && !ok, g);
-                }
+                const bool ok = isinf(xprev) ? false
+                                              : (ad < o.xtol_abs || ad < o.xtol_rel * (fabs(xcur) + fabs(xprev)) * 0.5 ||
+                                                 (o.xtol_rel > 0 && xcur == xprev));
+                stop = group_none<L>(act && !ok, g);
+            }
+            if (inner_done) {
                 if (stop) done = true;
                 else {
                     rho = fmax(0.1 * rho, 1e-5);
                     if (k > 1) {
-                        const double s = (xcur - xprev) * (xprev - xprevprev);
-                        sigma *= (s < 0 ? 0.7 : (s > 0 ? 1.2 : 1.0));
+                        const double sgn = (xcur - xprev) * (xprev - xprevprev);
+                        sigma *= (sgn < 0 ? 0.7 : (sgn > 0 ? 1.2 : 1.0));
                     }
                     ++k;
                     xprevprev = xprev;
@@ -186,14 +197,17 @@ struct CtmEArgs {
     CtmDev c;
     const double* invSigma; const double* mu; const double* expE;     // topic tables used by theta: exp(Eeff)
     const double* lam_in; double* lam_out; double* nu; double* zeta; double* theta;
+    double* sumth;          // [D][MK]: written by the theta phase, read by the solve phase
     double* partial;        // [gridDim][GT] (F_SLAB)
     int* nev_nu; int* nev_lam;   // per document (may be NULL)
     SolveOpts opt;
     int flags;
 };
 
-template <int L>
-__global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
+// PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
+// PH = 1: the two LD_MMA solves (few registers, high occupancy: the solves are latency-bound dependent chains)
+template <int L, int PH>
+__global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;
@@ -203,15 +217,19 @@ __global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / L, l = lane % L;
     const int flags = a.flags;
-    double* sS = smem;                                 // [MK*MK]
-    double* sMu = sS + MK * MK;                        // [MK]
-    double* sB = sMu + MK;                             // [GT]
-    double* sScr = sB + GT;                            // [NW][G][2L]
-    double* sSlab = sScr + (size_t)NW * G * 2 * L;     // [NW][GT] (F_SLAB)
-    for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = a.invSigma[i];
-    for (int i = tid; i < MK; i += blockDim.x) sMu[i] = a.mu[i];
-    if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = a.expE[i];
-    if (flags & F_SLAB) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
+    // PH 1: [MK*MK invSigma | MK mu | scratch];  PH 0: [scratch | GT table | NW*GT slabs]
+    double* sScr = smem;                               // [NW][G][2L]
+    double* sS = sScr + (size_t)NW * G * 2 * L;        // [MK*MK]   (PH 1)
+    double* sMu = sS + MK * MK;                        // [MK]      (PH 1)
+    double* sB = sScr + (size_t)NW * G * 2 * L;        // [GT]      (PH 0)
+    double* sSlab = sB + GT;                           // [NW][GT]  (PH 0, F_SLAB)
+    if (PH == 1) {
+        for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = a.invSigma[i];
+        for (int i = tid; i < MK; i += blockDim.x) sMu[i] = a.mu[i];
+    } else {
+        if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = a.expE[i];
+        if (flags & F_SLAB) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
+    }
     __syncthreads();
     double* slab = sSlab + (size_t)wid * GT;
     double* scrA = sScr + ((size_t)wid * G + g) * 2 * L;   // a_k values
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
         const double Nl = act ? a.c.Ndm[(size_t)d * M + mod_l] : 0.0;
         // ---- update_ζ! (MMCTM.jl:172-181) -------------------------------------------------------------------------
         double zl = 1.0;
-        if (flags & F_ZETA) {
+        if (PH == 0 && (flags & F_ZETA)) {
             const double E = act ? exp(lam + 0.5 * nu) : 0.0;
             for (int m = 0; m < M; ++m) {
                 const double zm = group_sum<L>((act && mod_l == m) ? E : 0.0);
@@ -239,7 +257,8 @@ __global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
         const double cl = Nl / zl;                                   // Ndivζ (MMCTM.jl:119-125)
         // ---- update_θ! (MMCTM.jl:183-198) and sumθ (MMCTM.jl:110-117) ------------------------------------------------
         double sumth = 0.0;
-        if (flags & (F_THETA_COMPUTE | F_THETA_STORED)) {
+        if (PH == 1) sumth = act ? a.sumth[(size_t)d * MK + l] : 0.0;
+        if (PH == 0 && (flags & (F_THETA_COMPUTE | F_THETA_STORED))) {
             double mx = 0.0;
             for (int m = 0; m < M; ++m) {
                 const double mm = group_max<L>((act && mod_l == m) ? lam : -1e300);
@@ -292,6 +311,7 @@ __global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
                 }
             }
         }
+        if (PH == 0) { if (act) a.sumth[(size_t)d * MK + l] = sumth; continue; }
         SolveOpts o = a.opt;
         // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ ----------------
         if (flags & F_NU) {
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(512) void k_ctm_estep(CtmEArgs a)
             if (a.nev_lam && valid && l == 0) a.nev_lam[d] = nev;
         }
     }
-    if (flags & F_SLAB) {
+    if (PH == 0 && (flags & F_SLAB)) {
         __syncthreads();
         double* out = a.partial + (size_t)blockIdx.x * GT;
         for (int i = tid; i < GT; i += blockDim.x) {
@@ -763,7 +783,7 @@ struct mmm_ctm {
     double Dglobal = 0;
     SolveOpts opt{};
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc; DevBuf<double> Ndm; DevBuf<int> features; DevBuf<double> alpha;
-    DevBuf<double> lambda[2], nu, zeta, props, theta;
+    DevBuf<double> lambda[2], nu, zeta, props, theta, sumth;
     DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff[2], phieff;
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
     DevBuf<int> nev_nu, nev_lam, status;
@@ -773,7 +793,7 @@ struct mmm_ctm {
     bool theta_from_prev = false;
     bool props_valid = false;
     int n_hist = 0, cap_hist = 0;
-    int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1;
+    int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1, grid_v = 1, waves_s = 4;
     size_t lds_e = 0;
     bool attr_set = false;
     std::vector<double> hNm;
@@ -782,34 +802,53 @@ struct mmm_ctm {
 
 namespace {
 
-template <int L>
-int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid)
+template <int L, int PH>
+int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L>;
+    auto k = k_ctm_estep<L, PH>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(m->waves_e * MMM_WAVE), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
-size_t estep_lds(const mmm_ctm* m, int flags)
+size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 {
     const int G = MMM_WAVE / m->L;
-    size_t n = (size_t)m->dm.MK * m->dm.MK + m->dm.MK + m->dm.GT + (size_t)m->waves_e * G * 2 * m->L;
+    size_t n = (size_t)m->dm.GT + (size_t)m->waves_e * G * 2 * m->L;
     if (flags & F_SLAB) n += (size_t)m->waves_e * m->dm.GT;
     return n * sizeof(double);
+}
+
+size_t solve_lds(const mmm_ctm* m)
+{
+    const int G = MMM_WAVE / m->L;
+    return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * G * 2 * m->L);
+}
+
+template <int PH>
+int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves)
+{
+    if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves);
+    if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves);
+    return launch_estep_L<64, PH>(m, a, lds, grid, waves);
 }
 
 int run_estep(mmm_ctm* m, int flags, const double* lam_in, double* lam_out, const double* expE)
 {
     CtmEArgs a{m->dev(), m->invSigma.p, m->mu.p, expE, lam_in, lam_out, m->nu.p, m->zeta.p,
-               (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->partial.p, m->nev_nu.p, m->nev_lam.p, m->opt, flags};
-    const size_t lds = estep_lds(m, flags);
-    if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM E-step needs %zu B of LDS (> 160 KiB)", lds);
-    if (m->L == 16) return launch_estep_L<16>(m, a, lds, m->grid_e);
-    if (m->L == 32) return launch_estep_L<32>(m, a, lds, m->grid_e);
-    return launch_estep_L<64>(m, a, lds, m->grid_e);
+               (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->sumth.p, m->partial.p, m->nev_nu.p, m->nev_lam.p, m->opt, flags};
+    int rc;
+    if (flags & (F_ZETA | F_THETA_COMPUTE | F_THETA_STORED | F_SLAB)) {
+        const size_t lds = estep_lds(m, flags);
+        if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM theta phase needs %zu B of LDS (> 160 KiB)", lds);
+        if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e))) return rc;
+    }
+    if (flags & (F_NU | F_LAMBDA)) {
+        if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s))) return rc;
+    }
+    return MMM_OK;
 }
 
 int reduce_partials(mmm_ctm* m, const double* part, int nslab, int n, double* out)
@@ -1012,12 +1051,15 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
     if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
+    m->waves_s = 4;
+    m->grid_v = std::max(1, std::min((D + m->waves_s * G - 1) / (m->waves_s * G), ctx->num_cu * 8));
+    if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     m->grid_m = std::max(1, std::min((D + 63) / 64, 256));
     const size_t MK = dm.MK, DMK = (size_t)D * MK;
     const int nmom = 2 * dm.MK + dm.MK * dm.MK;
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
     A(doc_ptr, (size_t)M * (D + 1)); A(tc, (size_t)nnz); A(Ndm, (size_t)D * M); A(features, featv.size()); A(alpha, (size_t)nalpha);
-    A(lambda[0], DMK); A(lambda[1], DMK); A(nu, DMK); A(zeta, (size_t)D * M); A(props, DMK); A(theta, (size_t)toff);
+    A(lambda[0], DMK); A(lambda[1], DMK); A(nu, DMK); A(sumth, DMK); A(zeta, (size_t)D * M); A(props, DMK); A(theta, (size_t)toff);
     A(mu, MK); A(Sigma, MK * MK); A(invSigma, MK * MK); A(gamma, (size_t)GM); A(Elnphi, (size_t)GM); A(phi, (size_t)GM);
     A(Eeff, (size_t)dm.GT); A(expEeff[0], (size_t)dm.GT); A(expEeff[1], (size_t)dm.GT); A(phieff, (size_t)dm.GT);
     A(partial, (size_t)m->grid_e * dm.GT); A(mompart, (size_t)m->grid_m * nmom); A(stats, (size_t)nmom + dm.GT + 16);
