@@ -162,8 +162,9 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
     }
 }
 
-template <int KP, int L, bool LL, int VT>
-__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_estep(EstepArgs a)
+// SINGLE: the grid covers every document with one step per wave (no step loop: 46 VGPRs less -> 3 waves per SIMD)
+template <int KP, int L, bool LL, int VT, bool SINGLE>
+__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, SINGLE ? 3 : 2) void k_lda_estep(EstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;                   // documents per wave step
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_estep(EstepArgs a)
             if (valid && l < K) gnext[(size_t)d * K + l] = a.c.alpha + mine;
         }
         MMM_STAMP(5);
+        if (SINGLE) break;
         base += stride;
         if (base >= D) break;
         // ---- loads of the next step ------------------------------------------------------------------------------
@@ -668,6 +670,7 @@ struct mmm_lda {
     bool stats_valid = false;    // stats[t&1] are the M-step statistics of the current state
     bool attr_e[2] = {false, false}, attr_m = false;
     bool stop_seen = false;     // the device stop flag may be set
+    bool single_step = false;   // one step per wave: the grid covers every document
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
     LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta}; }
@@ -706,14 +709,21 @@ int set_lds(mmm_ctx* ctx, Kern kern, size_t lds)
     return MMM_OK;
 }
 
-template <int KPV, int LV, bool LLV, int VT>
-int go_estep2(mmm_lda* m, const EstepArgs& a)
+template <int KPV, int LV, bool LLV, int VT, bool SG>
+int go_estep3(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_lda_estep<KPV, LV, LLV, VT>;
+    auto k = k_lda_estep<KPV, LV, LLV, VT, SG>;
     if (!m->attr_e[LLV]) { int rc = set_lds(ctx, k, m->lds_e); if (rc) return rc; m->attr_e[LLV] = true; }
     hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_e, ctx->stream, a);
     return MMM_OK;
+}
+
+template <int KPV, int LV, bool LLV, int VT>
+int go_estep2(mmm_lda* m, const EstepArgs& a)
+{
+    if constexpr (VT == 96) { if (m->single_step) return go_estep3<KPV, LV, LLV, VT, true>(m, a); }
+    return go_estep3<KPV, LV, LLV, VT, false>(m, a);
 }
 
 template <int KPV, int LV, bool LLV>
@@ -947,8 +957,10 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     const int G = MMM_WAVE / L;
     // waves per block of the fused kernel: as many as fit 160 KiB of LDS next to the two tables, at most 8
     const size_t tabB = (size_t)KP * V * sizeof(double);
-    // 8 waves per block, one block per CU: the fused kernel needs > 168 VGPRs (2 waves per SIMD)
-    int waves = 8;
+    // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
+    // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
+    const bool small = (V == 96) && (KP == 8 || KP == 10) && ((D + 6 * G - 1) / (6 * G) <= 2 * ctx->num_cu);
+    int waves = small ? 6 : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > 80 * 1024) --waves;
     if (lds_for(waves) > 160 * 1024)
@@ -961,9 +973,11 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= kMaxWavesE && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
-    const int blocks_per_cu = std::max(1, std::min<int>(8 / m->waves_e, (int)((160 * 1024) / m->lds_e)));
+    const int blocks_per_cu = std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
+    m->single_step = small && m->waves_e == 6;
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
+    if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)

@@ -290,3 +290,28 @@ def test_fit_matches_oracle(mmm, oracle, case):
           (case, np.median(ge), ge.max(), np.median(th_err), np.quantile(th_err, 0.99)))
     assert ge.max() < 5e-2 and np.median(ge) < 1e-3
     assert np.median(th_err) < 1e-3
+
+
+@pytest.mark.parametrize("K,V", [([16, 16, 12], [30, 20, 12]), ([3], [25]), ([9, 9, 9, 9], [12, 12, 12, 12])])
+def test_lane_group_widths(mmm, oracle, K, V):
+    """sum(K) = 44 -> one document per wave (64 lanes); sum(K) = 3 -> four per wave; sum(K) = 36 -> 64 lanes, four modalities."""
+    D = 30
+    X, g, o = _pair(mmm, oracle, D, K, V, seed=91, means=[200] * len(K), empty_frac=0.1)
+    MK, M = sum(K), len(K)
+    mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+    o.estep_range(0, D); o.update_mu(); assert o.update_Sigma() == 0; o.update_gamma(); o.update_props(); o.update_phi()
+    _cmp_docs(g, o, D, MK, M)
+    np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=1e-4)
+    np.testing.assert_allclose(g.invΣ, o.invSigma.reshape(MK, MK, order="F"), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g._get("theta"), o.theta, rtol=1e-9, atol=1e-300)
+    assert g.solver_stats()["n_capped"] == 0
+
+
+def test_unsupported_shapes_are_reported(mmm):
+    X = [[np.array([[1, 3]]), np.array([[1, 2]])]]
+    with pytest.raises(mmm.MmmError, match="must be in 1..16"):
+        mmm.MMCTM([17, 2], [0.1, 0.1], [4, 4], X, seed=0)
+    with pytest.raises(mmm.MmmError, match="<= 64"):
+        mmm.MMCTM([16] * 5, [0.1] * 5, [4] * 5, [[np.array([[1, 3]])] * 5], seed=0)
+    with pytest.raises(mmm.MmmError, match="not supported"):
+        mmm.LDA(40, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)

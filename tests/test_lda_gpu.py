@@ -161,3 +161,24 @@ def test_invariants_at_full_size(mmm):
     ll2 = mmm.fit(g2, maxiter=12, tol=0.0, verbose=False)
     np.testing.assert_array_equal(ll, ll2)
     np.testing.assert_array_equal(g.λ, g2.λ)
+
+
+@pytest.mark.parametrize("D,V,K", [(70, 50, 16), (50, 96, 20), (40, 30, 32), (45, 96, 13)])
+def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, D, V, K):
+    """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16."""
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=300 + K, empty=(2,))
+    ll_g = mmm.fit(g, maxiter=13, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=13, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    _cmp_state(g, o, 1e-8)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-8)
+
+
+def test_many_documents_per_wave_loop(mmm, oracle, monkeypatch):
+    """A tiny grid forces every wave through several document steps (the grid-stride path used for large corpora)."""
+    monkeypatch.setenv("MMM_LDA_GRID", "3")
+    X, g, o = _pair(mmm, oracle, 500, 96, 10, seed=12, mean_n=500, empty=(7, 499))
+    ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=12, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    _cmp_state(g, o, 1e-8)
