@@ -97,6 +97,9 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         ctx.init_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
+    elif os.environ.get("MMM_FORCE_RCCL"):
+        # single-GPU rehearsal of the collective path: a one-rank communicator, every all-reduce goes through RCCL
+        ctx.init_comm(1, 0, pkg.comm_unique_id())
 
     def barrier():
         if world > 1:
@@ -119,11 +122,15 @@ def main():
 
     steps(args.warmup)
     barrier()
-    ctx.profile_begin()
     t0 = time.perf_counter()
     steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    # Dominant-kernel duration: the same K steps again with every k_lda_estep launch bracketed by a HIP event pair on the
+    # library's stream.  Kept out of the timed region above because each hipEventRecord opens a ~5.6 us bubble in the
+    # otherwise back-to-back kernel stream (rocprofv3 trace: profiles/), i.e. +25 % on ms_per_step.
+    ctx.profile_begin()
+    steps(args.steps)
     n_launch, k_ms = ctx.profile_end()
 
     if world > 1:
@@ -151,9 +158,15 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_lda_estep<10,16,true,96>", "launches": n_launch, "avg_us": avg_s * 1e6,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "timing": "HIP events around each launch, repeat of the timed K steps (events perturb the loop)"},
             "ll_last": float(ll[0]),
         }
+        tp = os.path.join(ROOT, "profiles", "r01_traffic_lda_estep.json")
+        if world == 1 and D == 10000 and os.path.exists(tp):
+            tr = json.load(open(tp))
+            res["roofline"]["traffic"] = tr["hbm_bytes_per_launch_gfx950_corrected"]
+            res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/r01_traffic_lda_estep.json"
         if world == 1:
             res.update(parity_probe(pkg, K, alpha, eta, V, seed + 7))
             if not args.no_cpu_baseline:

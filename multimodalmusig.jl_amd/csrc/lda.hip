@@ -368,17 +368,25 @@ __global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
     }
 }
 
-// one block: M-step of pass t from the (all-reduced) statistics (LDA.jl:96-112), then ll_{t-1} / stopping rule / t += 1
-template <int KP>
-__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_mstep(ReduceArgs r, int K, int V, double eta, Ring lambda, Ring Elnbeta,
-                                                                     Ring expElnbeta, Ring beta)
+// M-step of pass t from the (all-reduced) statistics, one wave per topic (no inter-block dependency: Elnbeta_k needs
+// only the column sum of topic k): lambda = eta + sums, Elnbeta, exp table, beta (LDA.jl:96-112); block 0 then finalises
+// ll_{t-1}, the stopping rule and the pass counter.
+__global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     if (r.ctl->stop) return;
-    double* sLam = smem; double* sBet = smem + (size_t)KP * V; double* sCol = sBet + (size_t)KP * V; double* sPsi = sCol + KP;
-    const int c = r.t % 3;
-    lda_topics_from_stats<KP>(K, V, eta, r.stats, sLam, sBet, sCol, sPsi, lambda.s[c], Elnbeta.s[c], expElnbeta.s[c], beta.s[c]);
-    if (threadIdx.x == 0) lda_pass_tail(r);
+    const int k = blockIdx.x, lane = threadIdx.x, c = r.t % 3;
+    const double* sums = r.stats + (size_t)k * V;
+    double part = 0.0;
+    for (int v = lane; v < V; v += 64) part += eta + sums[v];
+    const double cs = wave_sum(part);
+    const double psi = dev_digamma_pos(cs);
+    for (int v = lane; v < V; v += 64) {
+        const double l = eta + sums[v];
+        const double el = dev_digamma_pos(l) - psi;
+        const size_t e = (size_t)k * V + v;
+        lambda.s[c][e] = l; Elnbeta.s[c][e] = el; expElnbeta.s[c][e] = exp(el); beta.s[c][e] = l / cs;
+    }
+    if (k == 0 && lane == 0) lda_pass_tail(r);
 }
 
 // topic state of the current pass from its reduced statistics (same arithmetic as the E-step prologue)
@@ -865,7 +873,6 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         m->gnext_valid = true;
     }
     const int VK = m->V * m->K;
-    const size_t lds_m = sizeof(double) * (2 * (size_t)m->KP * m->V + 2 * m->KP);
     for (int it = 0; it < n_iter; ++it) {
         const int t = m->t + 1;
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
@@ -878,12 +885,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         hipLaunchKernelGGL(k_lda_reduce, dim3((VK + 15) / 16), dim3(16, 64), 0, ctx->stream, r);
         MMM_LAUNCH_CHECK(ctx);
         if ((rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
-        MMM_KP_SWITCH(m, {
-            auto k = k_lda_mstep<KPV>;
-            if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds_m))) return rc; m->attr_m = true; }
-            hipLaunchKernelGGL(k, dim3(1), dim3(kMaxWavesE * MMM_WAVE), lds_m, ctx->stream, r, m->K, m->V, m->eta, m->ring(m->lambda),
-                               m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta));
-        })
+        hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+                           m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
         if (do_ll) m->n_hist++;
