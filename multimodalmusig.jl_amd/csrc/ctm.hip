@@ -395,21 +395,43 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
     }
 }
 
-// per-block partial sums of lambda (MK), nu (MK), lambda lambda^T (MK*MK): part[block][2MK + MK*MK]
-__global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double* lam, const double* nu, double* part)
+// per-block partial sums of lambda (MK), nu (MK), lambda lambda^T (MK*MK): part[block][2MK + MK*MK].  A block walks its
+// contiguous document range in tiles of 32 documents staged in LDS (coalesced loads); thread e owns output entry e.
+__global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double* __restrict__ lam, const double* __restrict__ nu, double* part)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];      // [32*MK] lambda tile, [32*MK] nu tile
+    constexpr int T = 32;
+    double* sL = smem; double* sN = smem + T * MK;
     const int n = 2 * MK + MK * MK;
     const int per = (D + gridDim.x - 1) / gridDim.x;
     const int d0 = blockIdx.x * per, d1 = min(D, d0 + per);
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        double s = 0.0;
-        if (e < MK) for (int d = d0; d < d1; ++d) s += lam[(size_t)d * MK + e];
-        else if (e < 2 * MK) for (int d = d0; d < d1; ++d) s += nu[(size_t)d * MK + (e - MK)];
-        else {
-            const int i = (e - 2 * MK) % MK, j = (e - 2 * MK) / MK;
-            for (int d = d0; d < d1; ++d) s += lam[(size_t)d * MK + i] * lam[(size_t)d * MK + j];
+    // up to 4 output entries per thread (n <= 2*64 + 64*64 needs more: loop)
+    for (int e0 = 0; e0 < n; e0 += 4 * blockDim.x) {
+        double acc[4] = {0, 0, 0, 0};
+        for (int t0 = d0; t0 < d1; t0 += T) {
+            const int nt = min(T, d1 - t0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt * MK; i += blockDim.x) { sL[i] = lam[(size_t)t0 * MK + i]; sN[i] = nu[(size_t)t0 * MK + i]; }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * blockDim.x + threadIdx.x;
+                if (e >= n) continue;
+                double s = 0.0;
+                if (e < MK) for (int d = 0; d < nt; ++d) s += sL[d * MK + e];
+                else if (e < 2 * MK) for (int d = 0; d < nt; ++d) s += sN[d * MK + (e - MK)];
+                else {
+                    const int i = (e - 2 * MK) % MK, j = (e - 2 * MK) / MK;
+                    for (int d = 0; d < nt; ++d) s = fma(sL[d * MK + i], sL[d * MK + j], s);
+                }
+                acc[q] += s;
+            }
         }
-        part[(size_t)blockIdx.x * n + e] = s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * blockDim.x + threadIdx.x;
+            if (e < n) part[(size_t)blockIdx.x * n + e] = acc[q];
+        }
     }
 }
 
@@ -483,8 +505,8 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv;
     const CtmDims& dm = a.dm;
-    const int MK = dm.MK, M = dm.M, tid = threadIdx.x, nt = blockDim.x;
-    const double* sLam = a.stats; const double* sNu = a.stats + MK; const double* sLL = a.stats + 2 * MK; const double* sG = a.stats + 2 * MK + MK * MK;
+    const int MK = dm.MK, tid = threadIdx.x, nt = blockDim.x;
+    const double* sLam = a.stats; const double* sNu = a.stats + MK; const double* sLL = a.stats + 2 * MK;
     // update_μ! (MMCTM.jl:200-202)
     if (a.do_mu) { for (int i = tid; i < MK; i += nt) a.mu[i] = sLam[i] / a.Dglobal; }
     __syncthreads();
@@ -506,72 +528,74 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
         if (tid == 0 && s_sing) *a.status = 1;
         __syncthreads();
     }
-    if (!a.do_gamma) return;
-    // update_γ! / update_Elnϕ! / update_ϕ! (MMCTM.jl:214-250; IMMCTM.jl:188-223)
+}
+
+// update_γ! / update_Elnϕ! / update_ϕ! (MMCTM.jl:214-250; IMMCTM.jl:188-223): one block per topic (m,k) -- topics are
+// independent of each other and of the Gaussian part, so they run beside block 0 of k_ctm_mstep's work.
+__global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
+{
+    __shared__ double sh[4];
+    const CtmDims& dm = a.dm;
     const CtmTopics& tp = a.tp;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double* sG = a.stats + 2 * dm.MK + dm.MK * dm.MK;
+    int m = 0;
+    while (m + 1 < dm.M && (int)blockIdx.x >= dm.koff[m + 1]) ++m;
+    const int k = blockIdx.x - dm.koff[m];
+    const int Vm = dm.V[m], go = dm.goff[m];
     if (!tp.immctm) {
-        for (int m = 0; m < M; ++m) {
-            const int Km = dm.K[m], Vm = dm.V[m], go = dm.goff[m];
-            if (a.gamma_from_stats) for (int e = tid; e < Km * Vm; e += nt) a.gamma[go + e] = tp.alpha[m] + sG[go + e];
-            __syncthreads();
-            for (int k = 0; k < Km; ++k) {
-                double part = 0.0;
-                for (int v = tid; v < Vm; v += nt) part += a.gamma[go + k * Vm + v];
-                __shared__ double sh[4];
-                part = wave_sum(part);
-                __syncthreads();
-                if ((tid & 63) == 0) sh[tid >> 6] = part;
-                __syncthreads();
-                const double cs = sh[0] + sh[1] + sh[2] + sh[3];
-                const double pcs = dev_digamma(cs);
-                for (int v = tid; v < Vm; v += nt) {
-                    const double gm = a.gamma[go + k * Vm + v];
-                    const double el = dev_digamma(gm) - pcs;
-                    a.Elnphi[go + k * Vm + v] = el; a.Eeff[go + k * Vm + v] = el; a.expEeff[go + k * Vm + v] = exp(el);
-                    const double ph = gm / cs;
-                    if (a.phi) a.phi[go + k * Vm + v] = ph;
-                    a.phieff[go + k * Vm + v] = ph;
-                }
-                __syncthreads();
-            }
+        double part = 0.0;
+        for (int v = tid; v < Vm; v += nt) {
+            const double gm = a.gamma_from_stats ? tp.alpha[m] + sG[go + k * Vm + v] : a.gamma[go + k * Vm + v];
+            if (a.gamma_from_stats) a.gamma[go + k * Vm + v] = gm;
+            part += gm;
+        }
+        part = wave_sum(part);
+        if ((tid & 63) == 0) sh[tid >> 6] = part;
+        __syncthreads();
+        const double cs = sh[0] + sh[1] + sh[2] + sh[3];
+        const double pcs = dev_digamma(cs);
+        for (int v = tid; v < Vm; v += nt) {
+            const double gm = a.gamma[go + k * Vm + v];
+            const double el = dev_digamma(gm) - pcs;
+            a.Elnphi[go + k * Vm + v] = el; a.Eeff[go + k * Vm + v] = el; a.expEeff[go + k * Vm + v] = exp(el);
+            const double ph = gm / cs;
+            if (a.phi) a.phi[go + k * Vm + v] = ph;
+            a.phieff[go + k * Vm + v] = ph;
         }
     } else {
-        for (int m = 0; m < M; ++m) {
-            const int Km = dm.K[m], Vm = dm.V[m], go = dm.goff[m], mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
-            const int* feat = tp.features + tp.foff[m];
-            // gamma[m][k][i][j] = alpha[m][i] + sum_{v: f_vi = j} S[m][k][v]   (IMMCTM.jl:199-221)
-            if (a.gamma_from_stats) for (int e = tid; e < Km * SJ; e += nt) {
-                const int k = e / SJ; int jj = e % SJ, i = 0;
-                while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
-                double s = tp.alpha[ao + i];
-                for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
-                a.gamma[mg + e] = s;
-            }
-            __syncthreads();
-            // Elnphi[m][k][i][j] = psi(gamma) - psi(sum_j gamma)   (IMMCTM.jl:188-197)
-            for (int e = tid; e < Km * SJ; e += nt) {
-                const int k = e / SJ; int jj = e % SJ, i = 0, jo = 0;
-                while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
+        const int mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
+        const int* feat = tp.features + tp.foff[m];
+        // gamma[m][k][i][j] = alpha[m][i] + sum_{v: f_vi = j} S[m][k][v]   (IMMCTM.jl:199-221)
+        if (a.gamma_from_stats) for (int e = tid; e < SJ; e += nt) {
+            int jj = e, i = 0;
+            while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
+            double s = tp.alpha[ao + i];
+            for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
+            a.gamma[mg + k * SJ + e] = s;
+        }
+        __syncthreads();
+        // Elnphi[m][k][i][j] = psi(gamma) - psi(sum_j gamma)   (IMMCTM.jl:188-197)
+        for (int e = tid; e < SJ; e += nt) {
+            int jj = e, i = 0, jo = 0;
+            while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
+            double cs = 0.0;
+            for (int j = 0; j < tp.J[ao + i]; ++j) cs += a.gamma[mg + k * SJ + jo + j];
+            a.Elnphi[mg + k * SJ + e] = dev_digamma(a.gamma[mg + k * SJ + e]) - dev_digamma(cs);
+        }
+        __syncthreads();
+        // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
+        for (int v = tid; v < Vm; v += nt) {
+            double se = 0.0, pp = 1.0; int jo = 0;
+            for (int i = 0; i < nf; ++i) {
+                const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
                 double cs = 0.0;
-                for (int j = 0; j < tp.J[ao + i]; ++j) cs += a.gamma[mg + k * SJ + jo + j];
-                a.Elnphi[mg + e] = dev_digamma(a.gamma[mg + e]) - dev_digamma(cs);
+                for (int j = 0; j < Ji; ++j) cs += a.gamma[mg + k * SJ + jo + j];
+                se += a.Elnphi[mg + k * SJ + jo + f];
+                pp *= a.gamma[mg + k * SJ + jo + f] / cs;
+                jo += Ji;
             }
-            __syncthreads();
-            // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
-            for (int e = tid; e < Km * Vm; e += nt) {
-                const int k = e / Vm, v = e % Vm;
-                double se = 0.0, pp = 1.0; int jo = 0;
-                for (int i = 0; i < nf; ++i) {
-                    const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
-                    double cs = 0.0;
-                    for (int j = 0; j < Ji; ++j) cs += a.gamma[mg + k * SJ + jo + j];
-                    se += a.Elnphi[mg + k * SJ + jo + f];
-                    pp *= a.gamma[mg + k * SJ + jo + f] / cs;
-                    jo += Ji;
-                }
-                a.Eeff[go + e] = se; a.expEeff[go + e] = exp(se); a.phieff[go + e] = pp;
-            }
-            __syncthreads();
+            a.Eeff[go + k * Vm + v] = se; a.expEeff[go + k * Vm + v] = exp(se); a.phieff[go + k * Vm + v] = pp;
         }
     }
 }
@@ -864,8 +888,11 @@ int run_mstep(mmm_ctm* m, int do_mu, int do_sigma, int do_gamma, int gamma_from_
     MstepArgs a{m->dm, m->tp, m->stats.p, m->Dglobal, m->mu.p, m->Sigma.p, m->invSigma.p, m->gamma.p, m->Elnphi.p,
                 m->immctm ? nullptr : m->phi.p, m->Eeff.p, m->expEeff[m->ecur].p, m->phieff.p, m->status.p, do_mu, do_sigma, do_gamma, gamma_from_stats};
     const size_t lds = sizeof(double) * 2 * (size_t)m->dm.MK * m->dm.MK;
-    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ctm_mstep, dim3(1), dim3(256), lds, ctx->stream, a);
+    if (do_mu || do_sigma) {
+        if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_ctm_mstep, dim3(1), dim3(256), lds, ctx->stream, a);
+    }
+    if (do_gamma) hipLaunchKernelGGL(k_ctm_mstep_topics, dim3(m->dm.MK), dim3(256), 0, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
@@ -938,7 +965,7 @@ int fused_pass(mmm_ctm* m, int update_sigma)
     m->theta_valid = false; m->theta_from_prev = true; m->props_valid = false;
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
     const int nmom = 2 * dm.MK + dm.MK * dm.MK;
-    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), 0, ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p))) return rc;
     if ((rc = reduce_partials(m, m->partial.p, m->grid_e, dm.GT, m->stats.p + nmom))) return rc;
@@ -1054,7 +1081,7 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     m->waves_s = 4;
     m->grid_v = std::max(1, std::min((D + m->waves_s * G - 1) / (m->waves_s * G), ctx->num_cu * 8));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
-    m->grid_m = std::max(1, std::min((D + 63) / 64, 256));
+    m->grid_m = std::max(1, std::min((D + 127) / 128, 512));
     const size_t MK = dm.MK, DMK = (size_t)D * MK;
     const int nmom = 2 * dm.MK + dm.MK * dm.MK;
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
@@ -1226,7 +1253,7 @@ static int moments_to_stats(mmm_ctm* m)
 {
     const CtmDims& dm = m->dm;
     const int nmom = 2 * dm.MK + dm.MK * dm.MK;
-    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), 0, m->ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), sizeof(double) * 64 * dm.MK, m->ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
     MMM_LAUNCH_CHECK(m->ctx);
     int rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p);
     if (rc) return rc;
