@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;                    // stage kernels
 constexpr int kBlock = kWavesPerBlock * MMM_WAVE;
-constexpr int kMaxWavesE = 8;                        // fused E-step kernel: up to 512 threads
+constexpr int kMaxWavesE = 12;                       // fused E-step kernel: up to 768 threads
 
 struct LdaDev {
     int D, V, K;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
 
 // SINGLE: the grid covers every document with one step per wave (no step loop: 46 VGPRs less -> 3 waves per SIMD)
 template <int KP, int L, bool LL, int VT, bool SINGLE>
-__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE, SINGLE ? 3 : 2) void k_lda_estep(EstepArgs a)
+__global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 2) void k_lda_estep(EstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;                   // documents per wave step
@@ -962,10 +962,11 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     const size_t tabB = (size_t)KP * V * sizeof(double);
     // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
     // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
-    const bool small = (V == 96) && (KP == 8 || KP == 10) && ((D + 6 * G - 1) / (6 * G) <= 2 * ctx->num_cu);
-    int waves = small ? 6 : 8;
+    const bool small = (V == 96) && (KP == 8 || KP == 10) && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
+                       !getenv("MMM_LDA_WAVES");
+    int waves = small ? 12 : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
-    while (waves > 1 && lds_for(waves) > 80 * 1024) --waves;
+    while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
     if (lds_for(waves) > 160 * 1024)
         return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K*V = %d*%d needs %zu B of LDS (> 160 KiB)", K, V, lds_for(waves));
 
@@ -973,11 +974,11 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     mmm_lda* m = new mmm_lda();
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
     m->waves_e = waves; m->lds_e = lds_for(waves); m->lds_tab = tabB;
-    if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= kMaxWavesE && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
+    if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
     const int blocks_per_cu = std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
-    m->single_step = small && m->waves_e == 6;
+    m->single_step = small && m->waves_e == 12;
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
