@@ -964,7 +964,11 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
     const bool small = (V == 96) && (KP == 8 || KP == 10) && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
                        !getenv("MMM_LDA_WAVES");
-    int waves = small ? 12 : 8;
+    // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
+    // per SIMD = shorter step); MMM_LDA_SWAVES overrides for experiments
+    int swaves = std::max(4, std::min(12, (D + G * ctx->num_cu - 1) / (G * ctx->num_cu)));
+    if (const char* sw = getenv("MMM_LDA_SWAVES")) swaves = std::max(4, std::min(12, atoi(sw)));
+    int waves = small ? swaves : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
     if (lds_for(waves) > 160 * 1024)
@@ -978,7 +982,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
     const int blocks_per_cu = std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
-    m->single_step = small && m->waves_e == 12;
+    m->single_step = small && (int64_t)m->waves_e * G * ctx->num_cu >= D;
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
