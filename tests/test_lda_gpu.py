@@ -182,3 +182,15 @@ def test_many_documents_per_wave_loop(mmm, oracle, monkeypatch):
     ll_o = o.fit(maxiter=12, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
     _cmp_state(g, o, 1e-8)
+
+
+def test_degenerate_shapes(mmm, oracle):
+    """K = 1, a single document, a corpus whose documents are all empty but one, V larger than any used term."""
+    for D, V, K, empty in [(5, 7, 1, ()), (1, 96, 10, ()), (6, 30, 4, (0, 1, 2, 4, 5)), (3, 200, 2, ())]:
+        X, g, o = _pair(mmm, oracle, D, V, K, seed=900 + D + K, mean_n=50, empty=empty)
+        ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
+        ll_o = o.fit(maxiter=4, tol=0.0)
+        np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+        _cmp_state(g, o, 1e-9)
+        assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+        g.close()
