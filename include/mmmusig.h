@@ -163,6 +163,25 @@ int mmm_ctm_ll_history(mmm_ctm* m, double* ll /* M*max_n */, int max_n, int* n);
 int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
                 int* n_iter, int* converged, double* elbo);
 
+/* Restart batching -- scripts/run_mmctm.jl:77-134 fits the same corpus from several random initialisations and
+ * keeps the best.  A batch handle holds R independent models ("replicas") over ONE resident corpus; the batched
+ * fit advances all of them with one launch per kernel (replica on grid.y), so the many small-corpus fits of a
+ * restart sweep fill the GPU together.  Replica r computes exactly what a model created from gamma0[r] alone
+ * computes.  gamma0: R contiguous blocks in the layout of mmm_ctm_create.
+ * The per-model API above (get/set/update_* /loglik/elbo/iterate/fit) acts on the selected replica (0 after
+ * create).  theta is kept for one replica at a time and rebuilt when the selection changes. */
+int mmm_ctm_create_batch(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, const double* alpha,
+                         const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const int* n_feat,
+                         const int* J, const int32_t* features, const double* gamma0,
+                         const mmm_solver_opts* opts, mmm_ctm** out);
+int mmm_ctm_replicas(const mmm_ctm* m);
+int mmm_ctm_select(mmm_ctm* m, int r);
+/* fit! of every replica, in lock step; a replica stops when its own stopping rule fires (common.jl:48-51).
+ * ll_hist: [R][maxiter][M]; n_iter, converged: [R]; elbo: [R] or NULL.  All replicas must have the same number
+ * of earlier passes. */
+int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter,
+                      int* converged, double* elbo);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,10 +7,10 @@ from . import _lib
 from ._lib import Context, MmmError, build, comm_unique_id, default_context, lib
 from .models import (LDA, calculate_elbo, calculate_loglikelihood, fit, fit_bang, update_β, update_γ, update_θ,
                      update_λ, update_ϕ)
-from .ctm import (IMMCTM, MMCTM, calculate_loglikelihoods, fitdoc, update_Elnϕ, update_props, update_Σ, update_ζ, update_μ,
+from .ctm import (IMMCTM, MMCTM, calculate_loglikelihoods, fit_restarts, fitdoc, pick_optimal_modality_models, update_Elnϕ, update_props, update_Σ, update_ζ, update_μ,
                   update_ν)
 from .utils import (format_counts_ctm, format_counts_lda, format_counts_mmctm, make_count_matrix, pack_lda,
                     pack_mm, read_counts_tsv, shard_documents)
 
 __all__ = ["IMMCTM", "MMCTM", "LDA", "fit", "fit_bang", "format_counts_lda", "format_counts_ctm", "format_counts_mmctm", "Context",
-           "MmmError", "build"]
+           "MmmError", "build", "fit_restarts"]

@@ -88,6 +88,10 @@ _SIGS = {
     "mmm_ctm_iterate": (C.c_int, [vp, C.c_int, C.c_int]),
     "mmm_ctm_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_ctm_fit": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "mmm_ctm_create_batch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, f64p, i64p, vp, vp, vp, vp, vp, f64p, C.POINTER(SolverOpts), C.POINTER(vp)]),
+    "mmm_ctm_replicas": (C.c_int, [vp]),
+    "mmm_ctm_select": (C.c_int, [vp, C.c_int]),
+    "mmm_ctm_fit_batch": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]),
 }
 
 

@@ -21,6 +21,7 @@
 //
 // The MMA solves restate NLopt's LD_MMA for zero constraints (algorithm statement: DESIGN.md "MMA" and
 // SURVEY.md §7): one objective evaluation per trip of a single wave-uniform loop, per-group state, select-based commits.
+#include <memory>
 #include "dev_math.h"
 #include "mmm_internal.h"
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ bool group_none(bool pred, int g)
 {
     const unsigned long long b = __ballot(pred);
     if (L == 64) return b == 0ull;
-    const unsigned long long mask = ((1ull << L) - 1ull) << (g * L);
+    const unsigned long long mask = ((1ull << (L & 63)) - 1ull) << (g * L);
     return (b & mask) == 0ull;
 }
 
@@ -202,6 +203,7 @@ struct CtmEArgs {
     int* nev_nu; int* nev_lam;   // per document (may be NULL)
     SolveOpts opt;
     int flags;
+    const int* active;      // batched launches (grid.y = replicas): per-replica activity flags, may be NULL
 };
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
@@ -213,6 +215,16 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
     constexpr int G = MMM_WAVE / L;
     const CtmDims& dm = a.c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    {   // replica r = blockIdx.y of a batched launch works on the r-th copy of every per-model array
+        const size_t r = blockIdx.y;
+        if (a.active && !a.active[r]) return;
+        a.invSigma += r * MK * MK; a.mu += r * MK; a.lam_in += r * D * MK; a.nu += r * D * MK; a.zeta += r * D * M; a.sumth += r * D * MK;
+        if (a.expE) a.expE += r * GT;
+        if (a.lam_out) a.lam_out += r * D * MK;
+        if (a.partial) a.partial += r * gridDim.x * GT;
+        if (a.nev_nu) a.nev_nu += r * D;
+        if (a.nev_lam) a.nev_lam += r * D;
+    }
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / L, l = lane % L;
@@ -371,9 +383,12 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
 }
 
 // partial[nslab][n] -> out[n], fixed summation order; grid = ceil(n/16) blocks of (16, 64)
-__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ part, int nslab, int n, double* __restrict__ out)
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ part, int nslab, int n, double* __restrict__ out,
+                                                          size_t out_stride, const int* active)
 {
     __shared__ double sm[64][17];
+    if (active && !active[blockIdx.y]) return;
+    part += (size_t)blockIdx.y * nslab * n; out += (size_t)blockIdx.y * out_stride;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int e = blockIdx.x * 16 + tx;
     double acc = 0.0;
@@ -397,10 +412,13 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restri
 
 // per-block partial sums of lambda (MK), nu (MK), lambda lambda^T (MK*MK): part[block][2MK + MK*MK].  A block walks its
 // contiguous document range in tiles of 32 documents staged in LDS (coalesced loads); thread e owns output entry e.
-__global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double* __restrict__ lam, const double* __restrict__ nu, double* part)
+__global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double* __restrict__ lam, const double* __restrict__ nu, double* part,
+                                                     const int* active)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];      // [32*MK] lambda tile, [32*MK] nu tile
     constexpr int T = 32;
+    if (active && !active[blockIdx.y]) return;
+    lam += (size_t)blockIdx.y * D * MK; nu += (size_t)blockIdx.y * D * MK; part += (size_t)blockIdx.y * gridDim.x * (2 * MK + MK * MK);
     double* sL = smem; double* sN = smem + T * MK;
     const int n = 2 * MK + MK * MK;
     const int per = (D + gridDim.x - 1) / gridDim.x;
@@ -456,7 +474,19 @@ struct MstepArgs {
     double* Eeff; double* expEeff; double* phieff;   // [GT]
     int* status;            // 0 ok, 1 singular Sigma
     int do_mu, do_sigma, do_gamma, gamma_from_stats;
+    size_t stats_stride; int GM; const int* active;      // batched launches
 };
+
+__device__ __forceinline__ bool mstep_replica(MstepArgs& a)
+{
+    const size_t r = blockIdx.y;
+    if (a.active && !a.active[r]) return false;
+    const size_t MK = a.dm.MK, GT = a.dm.GT, GM = a.GM;
+    a.stats += r * a.stats_stride; a.mu += r * MK; a.Sigma += r * MK * MK; a.invSigma += r * MK * MK;
+    a.gamma += r * GM; a.Elnphi += r * GM; if (a.phi) a.phi += r * GM;
+    a.Eeff += r * GT; a.expEeff += r * GT; a.phieff += r * GT; a.status += r;
+    return true;
+}
 
 // in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; returns
 // log|det A| in *logdet (thread 0).  One block.
@@ -504,6 +534,7 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv;
+    if (!mstep_replica(a)) return;
     const CtmDims& dm = a.dm;
     const int MK = dm.MK, tid = threadIdx.x, nt = blockDim.x;
     const double* sLam = a.stats; const double* sNu = a.stats + MK; const double* sLL = a.stats + 2 * MK;
@@ -535,6 +566,7 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
 __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
 {
     __shared__ double sh[4];
+    if (!mstep_replica(a)) return;
     const CtmDims& dm = a.dm;
     const CtmTopics& tp = a.tp;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -603,12 +635,15 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
 // props = softmax(lambda block) (MMCTM.jl:145-154) and per-modality ll numerators (MMCTM.jl:384-418); wave per document.
 // llpart[block][M]
 __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
-                                                        int compute_ll)
+                                                        int compute_ll, const int* active)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double shw[kWavesS][kMaxM];
     const CtmDims& dm = c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    if (active && !active[blockIdx.y]) return;
+    lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * gridDim.x * M;
+    if (props) props += (size_t)blockIdx.y * D * MK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double* sP = smem;                       // [GT]
     double* sPr = smem + GT + wid * 64;      // per-wave props
@@ -657,18 +692,21 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     }
 }
 
-__global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, int stride, double* out)
+__global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, int stride, double* out, size_t out_stride, const int* active)
 {
     const int j = blockIdx.x;
+    if (active && !active[blockIdx.y]) return;
+    part += (size_t)blockIdx.y * n * stride; out += (size_t)blockIdx.y * out_stride;
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 64) acc += part[(size_t)i * stride + j];
     acc = wave_sum(acc);
     if (threadIdx.x == 0) out[j] = acc;
 }
 
-__global__ void k_ll_store(int M, const double* num, const double* Nm, double* dst)
+__global__ void k_ll_store(int M, const double* num, size_t num_stride, const double* Nm, double* dst, size_t dst_stride, const int* active)
 {
-    if ((int)threadIdx.x < M) dst[threadIdx.x] = num[threadIdx.x] / Nm[threadIdx.x];
+    if (active && !active[blockIdx.y]) return;
+    if ((int)threadIdx.x < M) dst[blockIdx.y * dst_stride + threadIdx.x] = num[blockIdx.y * num_stride + threadIdx.x] / Nm[threadIdx.x];
 }
 
 // per-document ELBO pieces (MMCTM.jl:286-370): out[block][6] = {ElnPeta(without logdet/const), ElnPZ, ElnPX, ElnQeta, ElnQZ, count}
@@ -793,46 +831,66 @@ __global__ void k_ctm_gamma_from_theta(CtmDev c, int m, const double* theta, dou
         unsafeAtomicAdd(&sums[dm.goff[m] + k * Vm + t.x], theta[dm.toff[m] + (size_t)(e - e0) * Km + k] * (double)t.y);
 }
 
+// copy n doubles per replica, active replicas only (grid.y = replicas)
+__global__ void k_copy_rep(double* dst, const double* src, size_t n, const int* active)
+{
+    if (active && !active[blockIdx.y]) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[blockIdx.y * n + i] = src[blockIdx.y * n + i];
+}
+
 } // namespace
 
 // =====================================================================================================================
+// A handle holds R >= 1 independent models ("replicas": the restarts of scripts/run_mmctm.jl:77-134) over ONE resident
+// corpus.  Every per-model array is R contiguous copies; batched launches put the replica on grid.y.  The classic
+// single-model API works on the selected replica (`sel`, 0 by default).
 struct mmm_ctm {
     mmm_ctx* ctx = nullptr;
     CtmDims dm{};
     CtmTopics tp{};
     bool immctm = false;
+    int R = 1, sel = 0;
     int L = 64, GM = 0 /* model-layout gamma size */;
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
     double Dglobal = 0;
     SolveOpts opt{};
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc; DevBuf<double> Ndm; DevBuf<int> features; DevBuf<double> alpha;
-    DevBuf<double> lambda[2], nu, zeta, props, theta, sumth;
-    DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff[2], phieff;
+    DevBuf<double> lambda, lambda_prev, nu, zeta, props, sumth;                 // [R][D*MK] / [R][D*M]
+    DevBuf<double> theta;                                                        // ONE replica (the selected one), on demand
+    DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff, expEeff_prev, phieff;   // [R][...]
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
-    DevBuf<int> nev_nu, nev_lam, status;
-    int cur = 0;              // lambda[cur] is the current lambda; lambda[cur^1] the previous one (after a fused pass)
-    int ecur = 0;             // expEeff[ecur] current table
-    bool theta_valid = false; // theta buffer == theta of the current state
-    bool theta_from_prev = false;
-    bool props_valid = false;
-    int n_hist = 0, cap_hist = 0;
+    DevBuf<int> nev_nu, nev_lam, status, active;
+    std::vector<int> h_active, n_hist;        // per replica
+    // theta (the largest array) exists once, not per replica.  Per replica we know how to rebuild it:
+    // 0 = constructor value 1/K, 1 = update_θ! on (lambda_prev, expEeff_prev) -- the theta the last pass used --,
+    // 2 = explicit (update_θ! stage call or upload; parked in theta_spill[r] when another replica takes the buffer)
+    std::vector<char> theta_state;
+    std::vector<std::unique_ptr<DevBuf<double>>> theta_spill;
+    int theta_rep = -1;                       // replica whose theta is in the theta buffer (-1: none)
+    int cap_hist = 0;
     int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1, grid_v = 1, waves_s = 4;
-    size_t lds_e = 0;
-    bool attr_set = false;
+    int nmom = 0; size_t s_stats = 0, s_llnum = 0;
     std::vector<double> hNm;
     CtmDev dev() const { return CtmDev{dm, doc_ptr.p, tc.p, Ndm.p}; }
+    size_t sDMK() const { return (size_t)dm.D * dm.MK; }
 };
 
 namespace {
 
+// which replicas a launch covers: one (stage API, on the selected replica) or all active ones (batched fit)
+struct Scope { int rep0, nrep; const int* active; };
+inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
+inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
+
 template <int L, int PH>
-int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves)
+int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
     auto k = k_ctm_estep<L, PH>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
@@ -852,151 +910,217 @@ size_t solve_lds(const mmm_ctm* m)
 }
 
 template <int PH>
-int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves)
+int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
-    if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves);
-    if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves);
-    return launch_estep_L<64, PH>(m, a, lds, grid, waves);
+    if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves, nrep);
+    if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves, nrep);
+    return launch_estep_L<64, PH>(m, a, lds, grid, waves, nrep);
 }
 
-int run_estep(mmm_ctm* m, int flags, const double* lam_in, double* lam_out, const double* expE)
+// lam_in / expE: per-replica arrays (base of replica 0); lam_out likewise (may alias lam_in: in-place update)
+int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam_out, const double* expE)
 {
-    CtmEArgs a{m->dev(), m->invSigma.p, m->mu.p, expE, lam_in, lam_out, m->nu.p, m->zeta.p,
-               (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->sumth.p, m->partial.p, m->nev_nu.p, m->nev_lam.p, m->opt, flags};
+    const CtmDims& dm = m->dm;
+    const size_t r0 = sc.rep0, DMK = m->sDMK(), MK = dm.MK;
+    CtmEArgs a{m->dev(), m->invSigma.p + r0 * MK * MK, m->mu.p + r0 * MK, expE ? expE + r0 * dm.GT : nullptr, lam_in + r0 * DMK,
+               lam_out ? lam_out + r0 * DMK : nullptr, m->nu.p + r0 * DMK, m->zeta.p + r0 * dm.D * dm.M,
+               (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->sumth.p + r0 * DMK,
+               m->partial.p + r0 * m->grid_e * dm.GT, m->nev_nu.p + r0 * dm.D, m->nev_lam.p + r0 * dm.D, m->opt, flags, sc.active};
     int rc;
     if (flags & (F_ZETA | F_THETA_COMPUTE | F_THETA_STORED | F_SLAB)) {
         const size_t lds = estep_lds(m, flags);
         if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM theta phase needs %zu B of LDS (> 160 KiB)", lds);
-        if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e))) return rc;
+        if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
     }
     if (flags & (F_NU | F_LAMBDA)) {
-        if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s))) return rc;
+        if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
     }
     return MMM_OK;
 }
 
-int reduce_partials(mmm_ctm* m, const double* part, int nslab, int n, double* out)
+// part: [R][nslab][n] -> out: per replica at out + r*out_stride
+int reduce_partials(mmm_ctm* m, Scope sc, const double* part, int nslab, int n, double* out, size_t out_stride)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 15) / 16), dim3(16, 64), 0, m->ctx->stream, part, nslab, n, out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 15) / 16, sc.nrep), dim3(16, 64), 0, m->ctx->stream, part + (size_t)sc.rep0 * nslab * n, nslab, n,
+                       out + sc.rep0 * out_stride, out_stride, sc.active);
     MMM_LAUNCH_CHECK(m->ctx);
     return MMM_OK;
 }
 
-int run_mstep(mmm_ctm* m, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
+int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
 {
     mmm_ctx* ctx = m->ctx;
-    MstepArgs a{m->dm, m->tp, m->stats.p, m->Dglobal, m->mu.p, m->Sigma.p, m->invSigma.p, m->gamma.p, m->Elnphi.p,
-                m->immctm ? nullptr : m->phi.p, m->Eeff.p, m->expEeff[m->ecur].p, m->phieff.p, m->status.p, do_mu, do_sigma, do_gamma, gamma_from_stats};
-    const size_t lds = sizeof(double) * 2 * (size_t)m->dm.MK * m->dm.MK;
+    const size_t r0 = sc.rep0, MK = m->dm.MK, GT = m->dm.GT, GM = m->GM;
+    MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
+                m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
+                m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active};
+    const size_t lds = sizeof(double) * 2 * MK * MK;
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_ctm_mstep, dim3(1), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k_ctm_mstep, dim3(1, sc.nrep), dim3(256), lds, ctx->stream, a);
     }
-    if (do_gamma) hipLaunchKernelGGL(k_ctm_mstep_topics, dim3(m->dm.MK), dim3(256), 0, ctx->stream, a);
+    if (do_gamma) hipLaunchKernelGGL(k_ctm_mstep_topics, dim3(m->dm.MK, sc.nrep), dim3(256), 0, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
-int check_status(mmm_ctm* m)
+// status words of the scope: singular Sigma in any replica -> error
+int check_status(mmm_ctm* m, Scope sc)
 {
-    int h = 0;
-    MMM_HIP(m->ctx, hipMemcpyAsync(&h, m->status.p, sizeof(int), hipMemcpyDeviceToHost, m->ctx->stream));
+    std::vector<int> h((size_t)sc.nrep, 0);
+    MMM_HIP(m->ctx, hipMemcpyAsync(h.data(), m->status.p + sc.rep0, sizeof(int) * sc.nrep, hipMemcpyDeviceToHost, m->ctx->stream));
     MMM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    if (h) return mmm_fail(m->ctx, MMM_ERR_NUMERIC, "update_Σ!: Sigma is singular (inv failed)");
+    for (int i = 0; i < sc.nrep; ++i)
+        if (h[i]) return mmm_fail(m->ctx, MMM_ERR_NUMERIC, "update_Σ!: Sigma is singular (inv failed) in replica %d", sc.rep0 + i);
     return MMM_OK;
 }
 
-// theta of the current state into the theta buffer (MMCTM.jl:183-198)
+// the theta buffer is about to be given to the selected replica: park an explicit theta of its current owner
+int claim_theta(mmm_ctm* m)
+{
+    const int own = m->theta_rep;
+    if (own < 0 || own == m->sel || m->theta_state[own] != 2) return MMM_OK;
+    if (!m->theta_spill[own]) {
+        m->theta_spill[own].reset(new DevBuf<double>());
+        MMM_HIP(m->ctx, m->theta_spill[own]->alloc((size_t)m->theta_n));
+    }
+    if (m->theta_n) MMM_HIP(m->ctx, hipMemcpyAsync(m->theta_spill[own]->p, m->theta.p, sizeof(double) * m->theta_n, hipMemcpyDeviceToDevice, m->ctx->stream));
+    m->theta_rep = -1;
+    return MMM_OK;
+}
+
+// theta of the selected replica into the theta buffer (MMCTM.jl:183-198)
 int materialise_theta(mmm_ctm* m)
 {
-    if (m->theta_valid) return MMM_OK;
-    const double* lam = m->theta_from_prev ? m->lambda[m->cur ^ 1].p : m->lambda[m->cur].p;
-    const double* tab = m->theta_from_prev ? m->expEeff[m->ecur ^ 1].p : m->expEeff[m->ecur].p;
-    int rc = run_estep(m, F_THETA_COMPUTE | F_THETA_STORE, lam, nullptr, tab);
+    if (m->theta_rep == m->sel) return MMM_OK;
+    int rc = claim_theta(m);
     if (rc) return rc;
-    m->theta_valid = true;
+    const int st = m->theta_state[m->sel];
+    if (st == 2) {
+        MMM_CHECK(m->ctx, m->theta_spill[m->sel], "theta of replica %d was never stored", m->sel);
+        if (m->theta_n) MMM_HIP(m->ctx, hipMemcpyAsync(m->theta.p, m->theta_spill[m->sel]->p, sizeof(double) * m->theta_n, hipMemcpyDeviceToDevice, m->ctx->stream));
+    } else if (st == 0) {
+        for (int i = 0; i < m->dm.M; ++i) {
+            const size_t n = (size_t)m->nnzm[i] * m->dm.K[i];
+            if (n) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->ctx->stream, m->theta.p + m->dm.toff[i], n, 1.0 / m->dm.K[i]);
+        }
+        MMM_LAUNCH_CHECK(m->ctx);
+    } else {
+        const bool prev = st == 1;
+        rc = run_estep(m, one(m), F_THETA_COMPUTE | F_THETA_STORE, prev ? m->lambda_prev.p : m->lambda.p, nullptr, prev ? m->expEeff_prev.p : m->expEeff.p);
+        if (rc) return rc;
+    }
+    m->theta_rep = m->sel;
     return MMM_OK;
 }
 
-int run_loglik(mmm_ctm* m, double* dst_dev /* M doubles */, bool compute_ll)
+// props (+ ll written to dst + r*dst_stride for every replica of the scope)
+int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool compute_ll)
 {
     mmm_ctx* ctx = m->ctx;
     const int M = m->dm.M;
+    const size_t r0 = sc.rep0;
     const size_t lds = sizeof(double) * ((size_t)m->dm.GT + kWavesS * 64);
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda[m->cur].p, m->phieff.p, m->props.p, m->llpart.p, compute_ll ? 1 : 0);
+    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(), m->phieff.p + r0 * m->dm.GT,
+                       m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active);
     MMM_LAUNCH_CHECK(ctx);
-    m->props_valid = true;
     if (!compute_ll) return MMM_OK;
-    hipLaunchKernelGGL(k_sum_columns, dim3(M), dim3(64), 0, ctx->stream, m->llpart.p, m->grid_s, M, m->llnum.p);
+    hipLaunchKernelGGL(k_sum_columns, dim3(M, sc.nrep), dim3(64), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->llnum.p + r0 * m->s_llnum,
+                       m->s_llnum, sc.active);
     MMM_LAUNCH_CHECK(ctx);
-    int rc = mmm_allreduce_sum(ctx, m->llnum.p, M);
+    int rc = mmm_allreduce_sum(ctx, m->llnum.p + r0 * m->s_llnum, (size_t)sc.nrep * m->s_llnum);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ll_store, dim3(1), dim3(64), 0, ctx->stream, M, m->llnum.p, m->Nm.p, dst_dev);
+    hipLaunchKernelGGL(k_ll_store, dim3(1, sc.nrep), dim3(64), 0, ctx->stream, M, m->llnum.p + r0 * m->s_llnum, m->s_llnum, m->Nm.p, dst_dev, dst_stride, sc.active);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
 
+// ll history: [R][cap_hist][M]
 int ensure_hist(mmm_ctm* m, int extra)
 {
     const int M = m->dm.M;
-    if ((m->n_hist + extra) * M <= m->cap_hist) return MMM_OK;
-    const int cap = std::max(2 * m->cap_hist, (m->n_hist + extra + 64) * M);
+    int need = 0;
+    for (int r = 0; r < m->R; ++r) need = std::max(need, m->n_hist[r] + extra);
+    if (need <= m->cap_hist) return MMM_OK;
+    const int cap = std::max(2 * m->cap_hist, need + 64);
     DevBuf<double> nb;
-    MMM_HIP(m->ctx, nb.alloc(cap));
-    if (m->n_hist) MMM_HIP(m->ctx, hipMemcpyAsync(nb.p, m->ll_hist.p, sizeof(double) * m->n_hist * M, hipMemcpyDeviceToDevice, m->ctx->stream));
+    MMM_HIP(m->ctx, nb.alloc((size_t)m->R * cap * M));
+    for (int r = 0; r < m->R; ++r)
+        if (m->n_hist[r]) MMM_HIP(m->ctx, hipMemcpyAsync(nb.p + (size_t)r * cap * M, m->ll_hist.p + (size_t)r * m->cap_hist * M, sizeof(double) * m->n_hist[r] * M,
+                                                         hipMemcpyDeviceToDevice, m->ctx->stream));
     MMM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
     m->ll_hist.swap(nb);
     m->cap_hist = cap;
     return MMM_OK;
 }
 
-// one pass of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451)
-int fused_pass(mmm_ctm* m, int update_sigma)
+int copy_rep(mmm_ctm* m, Scope sc, double* dst, const double* src, size_t n)
+{
+    if (!n) return MMM_OK;
+    hipLaunchKernelGGL(k_copy_rep, dim3((unsigned)((n + 255) / 256), sc.nrep), dim3(256), 0, m->ctx->stream, dst + sc.rep0 * n, src + sc.rep0 * n, n, sc.active);
+    MMM_LAUNCH_CHECK(m->ctx);
+    return MMM_OK;
+}
+
+// one pass of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) for every replica of the scope.  All replicas of the
+// scope must have the same history length (they do: a batched fit advances its active replicas in lock step).
+int fused_pass(mmm_ctm* m, Scope sc, int update_sigma)
 {
     mmm_ctx* ctx = m->ctx;
     const CtmDims& dm = m->dm;
     int rc;
-    // for d in 1:D fitdoc!(model, d)
-    const int in = m->cur, out = m->cur ^ 1;
-    { ProfSpan span(ctx); rc = run_estep(m, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda[in].p, m->lambda[out].p, m->expEeff[m->ecur].p); }
+    // keep lambda_{t-1} and the exp table of this pass: theta_t is rebuilt from them on demand
+    if ((rc = copy_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK()))) return rc;
+    if ((rc = copy_rep(m, sc, m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
+    // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
+    { ProfSpan span(ctx); rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p); }
     if (rc) return rc;
-    m->cur = out;
-    m->theta_valid = false; m->theta_from_prev = true; m->props_valid = false;
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
-    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
-    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    const size_t r0 = sc.rep0;
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
+                       m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
     MMM_LAUNCH_CHECK(ctx);
-    if ((rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p))) return rc;
-    if ((rc = reduce_partials(m, m->partial.p, m->grid_e, dm.GT, m->stats.p + nmom))) return rc;
-    if ((rc = mmm_allreduce_sum(ctx, m->stats.p, (size_t)nmom + dm.GT))) return rc;
-    // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!; the exp table of this pass stays for theta materialisation
-    m->ecur ^= 1;
-    if ((rc = run_mstep(m, 1, (update_sigma || m->immctm) ? 1 : 0, 1, 1))) return rc;
+    if ((rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats))) return rc;
+    if ((rc = reduce_partials(m, sc, m->partial.p, m->grid_e, dm.GT, m->stats.p + m->nmom, m->s_stats))) return rc;
+    if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
+    // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!
+    if ((rc = run_mstep(m, sc, 1, (update_sigma || m->immctm) ? 1 : 0, 1, 1))) return rc;
     // update_props! and the log-likelihoods
     if ((rc = ensure_hist(m, 1))) return rc;
-    if ((rc = run_loglik(m, m->ll_hist.p + (size_t)m->n_hist * dm.M, true))) return rc;
-    m->n_hist++;
+    const int M = dm.M;
+    int nh = 0;       // the replicas still running share one history length (fit_scope checks it)
+    for (int i = 0; i < sc.nrep; ++i)
+        if (!sc.active || m->h_active[sc.rep0 + i]) nh = std::max(nh, m->n_hist[sc.rep0 + i]);
+    if ((rc = run_loglik(m, sc, m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + nh) * M, (size_t)m->cap_hist * M, true))) return rc;
+    for (int i = 0; i < sc.nrep; ++i) {
+        const int r = sc.rep0 + i;
+        if (sc.active && !m->h_active[r]) continue;
+        m->n_hist[r]++; m->theta_state[r] = 1;
+        if (m->theta_rep == r) m->theta_rep = -1;
+    }
     return MMM_OK;
 }
 
 int prep(mmm_ctm* m) { MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return MMM_OK; }
 
-} // namespace
+int upload_active(mmm_ctm* m)
+{
+    MMM_HIP(m->ctx, hipMemcpyAsync(m->active.p, m->h_active.data(), sizeof(int) * m->R, hipMemcpyHostToDevice, m->ctx->stream));
+    return MMM_OK;
+}
 
-extern "C" {
-
-int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr, const int32_t* term,
-                   const int32_t* count, const int* n_feat, const int* J, const int32_t* features, const double* gamma0,
-                   const mmm_solver_opts* opts, mmm_ctm** out)
+int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr, const int32_t* term,
+                const int32_t* count, const int* n_feat, const int* J, const int32_t* features, const double* gamma0,
+                const mmm_solver_opts* opts, mmm_ctm** out)
 {
     if (!ctx) return MMM_ERR_ARG;
     MMM_CHECK(ctx, out && K && V && alpha && doc_ptr && gamma0, "mmm_ctm_create: NULL argument");
-    MMM_CHECK(ctx, D >= 0 && M >= 1 && M <= kMaxM, "mmm_ctm_create: bad sizes D=%d M=%d (M <= %d)", D, M, kMaxM);
+    MMM_CHECK(ctx, D >= 0 && M >= 1 && M <= kMaxM && R >= 1, "mmm_ctm_create: bad sizes D=%d M=%d (M <= %d) R=%d", D, M, kMaxM, R);
     *out = nullptr;
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_ctm* m = new mmm_ctm();
-    m->ctx = ctx;
+    m->ctx = ctx; m->R = R;
     CtmDims& dm = m->dm;
     dm.D = D; dm.M = M; dm.koff[0] = 0; dm.goff[0] = 0;
     int64_t toff = 0;
@@ -1018,6 +1142,7 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     std::vector<int2> tc((size_t)nnz);
     std::vector<double> Ndm((size_t)D * M, 0.0);
     m->hNm.assign(M, 0.0);
+    if (doc_ptr[0] != 0) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr[0] != 0"); delete m; return rc; }
     for (int i = 0; i < M; ++i) {
         const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
         if (i > 0 && dp[0] != doc_ptr[(size_t)(i - 1) * (D + 1) + D]) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr of modality %d does not continue modality %d", i, i - 1); delete m; return rc; }
@@ -1033,7 +1158,6 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
             if (n > 0) m->hNm[i] += n;        // MMCTM.jl:409-414: only documents with N > 0 enter the ll
         }
     }
-    if (doc_ptr[0] != 0) { int rc = mmm_fail(ctx, MMM_ERR_ARG, "mmm_ctm_create: doc_ptr[0] != 0"); delete m; return rc; }
     // topics descriptor
     CtmTopics& tp = m->tp;
     m->immctm = (n_feat != nullptr);
@@ -1082,16 +1206,19 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     m->grid_v = std::max(1, std::min((D + m->waves_s * G - 1) / (m->waves_s * G), ctx->num_cu * 8));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     m->grid_m = std::max(1, std::min((D + 127) / 128, 512));
-    const size_t MK = dm.MK, DMK = (size_t)D * MK;
-    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
+    const size_t MK = dm.MK, DMK = (size_t)D * MK, Rz = (size_t)R;
+    m->nmom = 2 * dm.MK + dm.MK * dm.MK;
+    m->s_stats = (size_t)m->nmom + dm.GT + 16;
+    m->s_llnum = (size_t)M + 8;
+    m->h_active.assign(R, 1); m->n_hist.assign(R, 0); m->theta_state.assign(R, 0); m->theta_spill.resize(R);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
     A(doc_ptr, (size_t)M * (D + 1)); A(tc, (size_t)nnz); A(Ndm, (size_t)D * M); A(features, featv.size()); A(alpha, (size_t)nalpha);
-    A(lambda[0], DMK); A(lambda[1], DMK); A(nu, DMK); A(sumth, DMK); A(zeta, (size_t)D * M); A(props, DMK); A(theta, (size_t)toff);
-    A(mu, MK); A(Sigma, MK * MK); A(invSigma, MK * MK); A(gamma, (size_t)GM); A(Elnphi, (size_t)GM); A(phi, (size_t)GM);
-    A(Eeff, (size_t)dm.GT); A(expEeff[0], (size_t)dm.GT); A(expEeff[1], (size_t)dm.GT); A(phieff, (size_t)dm.GT);
-    A(partial, (size_t)m->grid_e * dm.GT); A(mompart, (size_t)m->grid_m * nmom); A(stats, (size_t)nmom + dm.GT + 16);
-    A(llpart, (size_t)m->grid_s * M); A(llnum, (size_t)M + 8); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16);
-    A(nev_nu, (size_t)D); A(nev_lam, (size_t)D); A(status, 1);
+    A(lambda, Rz * DMK); A(lambda_prev, Rz * DMK); A(nu, Rz * DMK); A(sumth, Rz * DMK); A(zeta, Rz * D * M); A(props, Rz * DMK); A(theta, (size_t)toff);
+    A(mu, Rz * MK); A(Sigma, Rz * MK * MK); A(invSigma, Rz * MK * MK); A(gamma, Rz * GM); A(Elnphi, Rz * GM); A(phi, Rz * GM);
+    A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
+    A(partial, Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
+    A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
+    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz);
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * M * (D + 1), hipMemcpyHostToDevice, st));
@@ -1099,10 +1226,12 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     if (D) MMM_HIP(ctx, hipMemcpyAsync(m->Ndm.p, Ndm.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
     if (!featv.empty()) MMM_HIP(ctx, hipMemcpyAsync(m->features.p, featv.data(), sizeof(int) * featv.size(), hipMemcpyHostToDevice, st));
     MMM_HIP(ctx, hipMemcpyAsync(m->alpha.p, alpha, sizeof(double) * nalpha, hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->gamma.p, gamma0, sizeof(double) * GM, hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemsetAsync(m->status.p, 0, sizeof(int), st));
-    MMM_HIP(ctx, hipMemsetAsync(m->nev_nu.p, 0, sizeof(int) * std::max(D, 1), st));
-    MMM_HIP(ctx, hipMemsetAsync(m->nev_lam.p, 0, sizeof(int) * std::max(D, 1), st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->gamma.p, gamma0, sizeof(double) * Rz * GM, hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemsetAsync(m->status.p, 0, sizeof(int) * R, st));
+    MMM_HIP(ctx, hipMemsetAsync(m->nev_nu.p, 0, sizeof(int) * std::max<size_t>(Rz * D, 1), st));
+    MMM_HIP(ctx, hipMemsetAsync(m->nev_lam.p, 0, sizeof(int) * std::max<size_t>(Rz * D, 1), st));
+    int rc = upload_active(m);
+    if (rc) { delete m; return rc; }
     MMM_HIP(ctx, hipStreamSynchronize(st));
     tp.features = m->features.p; tp.alpha = m->alpha.p;
     // global N per modality and D (sum over ranks)
@@ -1110,8 +1239,7 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
         std::vector<double> h(m->hNm);
         h.push_back((double)D);
         MMM_HIP(ctx, hipMemcpyAsync(m->llnum.p, h.data(), sizeof(double) * (M + 1), hipMemcpyHostToDevice, st));
-        int rc = mmm_allreduce_sum(ctx, m->llnum.p, M + 1);
-        if (rc) { delete m; return rc; }
+        if ((rc = mmm_allreduce_sum(ctx, m->llnum.p, M + 1))) { delete m; return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(h.data(), m->llnum.p, sizeof(double) * (M + 1), hipMemcpyDeviceToHost, st));
         MMM_HIP(ctx, hipStreamSynchronize(st));
         m->Dglobal = h[M];
@@ -1120,30 +1248,54 @@ int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const
     }
     // constructor state (MMCTM.jl:44-86): mu = 0, Sigma = invSigma = I, theta = 1/K, Elnphi from gamma0, phi = gamma0
     // (deepcopy, MMCTM.jl:80), lambda = 0, nu = 1, zeta = update_ζ!
-    std::vector<double> eye(MK * MK, 0.0);
-    for (size_t i = 0; i < MK; ++i) eye[i * MK + i] = 1.0;
-    MMM_HIP(ctx, hipMemsetAsync(m->mu.p, 0, sizeof(double) * MK, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->Sigma.p, eye.data(), sizeof(double) * MK * MK, hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->invSigma.p, eye.data(), sizeof(double) * MK * MK, hipMemcpyHostToDevice, st));
+    std::vector<double> eye(Rz * MK * MK, 0.0);
+    for (size_t r = 0; r < Rz; ++r) for (size_t i = 0; i < MK; ++i) eye[r * MK * MK + i * MK + i] = 1.0;
+    MMM_HIP(ctx, hipMemsetAsync(m->mu.p, 0, sizeof(double) * Rz * MK, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->Sigma.p, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice, st));
+    MMM_HIP(ctx, hipMemcpyAsync(m->invSigma.p, eye.data(), sizeof(double) * eye.size(), hipMemcpyHostToDevice, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));
     if (DMK) {
-        MMM_HIP(ctx, hipMemsetAsync(m->lambda[0].p, 0, sizeof(double) * DMK, st));
-        MMM_HIP(ctx, hipMemsetAsync(m->lambda[1].p, 0, sizeof(double) * DMK, st));
-        MMM_HIP(ctx, hipMemsetAsync(m->props.p, 0, sizeof(double) * DMK, st));
-        hipLaunchKernelGGL(k_fill, dim3((unsigned)((DMK + 255) / 256)), dim3(256), 0, st, m->nu.p, DMK, 1.0);
-    }
-    for (int i = 0; i < M; ++i) {
-        const size_t n = (size_t)(doc_ptr[(size_t)i * (D + 1) + D] - dm.estart[i]) * K[i];
-        if (n) hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->theta.p + dm.toff[i], n, 1.0 / K[i]);
+        MMM_HIP(ctx, hipMemsetAsync(m->lambda.p, 0, sizeof(double) * Rz * DMK, st));
+        MMM_HIP(ctx, hipMemsetAsync(m->lambda_prev.p, 0, sizeof(double) * Rz * DMK, st));
+        MMM_HIP(ctx, hipMemsetAsync(m->props.p, 0, sizeof(double) * Rz * DMK, st));
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((Rz * DMK + 255) / 256)), dim3(256), 0, st, m->nu.p, Rz * DMK, 1.0);
     }
     MMM_LAUNCH_CHECK(ctx);
-    int rc = run_mstep(m, 0, 0, 1, 0);                       // update_Elnϕ! on gamma0 (+ tables)
-    if (rc) { delete m; return rc; }
-    if (!m->immctm) MMM_HIP(ctx, hipMemcpyAsync(m->phi.p, m->gamma.p, sizeof(double) * GM, hipMemcpyDeviceToDevice, st));   // MMCTM.jl:80
-    if ((rc = run_estep(m, F_ZETA, m->lambda[0].p, nullptr, nullptr))) { delete m; return rc; }
+    if ((rc = materialise_theta(m))) { delete m; return rc; }
+    Scope sc{0, R, nullptr};
+    if ((rc = run_mstep(m, sc, 0, 0, 1, 0))) { delete m; return rc; }                       // update_Elnϕ! on gamma0 (+ tables)
+    if (!m->immctm) MMM_HIP(ctx, hipMemcpyAsync(m->phi.p, m->gamma.p, sizeof(double) * Rz * GM, hipMemcpyDeviceToDevice, st));   // MMCTM.jl:80
+    if ((rc = run_estep(m, sc, F_ZETA, m->lambda.p, nullptr, nullptr))) { delete m; return rc; }
     MMM_HIP(ctx, hipStreamSynchronize(st));
-    m->theta_valid = true; m->theta_from_prev = false;
     *out = m;
+    return MMM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr, const int32_t* term,
+                   const int32_t* count, const int* n_feat, const int* J, const int32_t* features, const double* gamma0,
+                   const mmm_solver_opts* opts, mmm_ctm** out)
+{
+    return create_impl(ctx, 1, D, M, K, V, alpha, doc_ptr, term, count, n_feat, J, features, gamma0, opts, out);
+}
+
+int mmm_ctm_create_batch(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, const double* alpha, const int64_t* doc_ptr,
+                         const int32_t* term, const int32_t* count, const int* n_feat, const int* J, const int32_t* features,
+                         const double* gamma0, const mmm_solver_opts* opts, mmm_ctm** out)
+{
+    return create_impl(ctx, R, D, M, K, V, alpha, doc_ptr, term, count, n_feat, J, features, gamma0, opts, out);
+}
+
+int mmm_ctm_replicas(const mmm_ctm* m) { return m ? m->R : 0; }
+
+int mmm_ctm_select(mmm_ctm* m, int r)
+{
+    if (!m) return MMM_ERR_ARG;
+    MMM_CHECK(m->ctx, r >= 0 && r < m->R, "mmm_ctm_select: replica %d out of range (0..%d)", r, m->R - 1);
+    m->sel = r;
     return MMM_OK;
 }
 
@@ -1156,20 +1308,21 @@ int mmm_ctm_destroy(mmm_ctm* m)
     return MMM_OK;
 }
 
+// pointer to the selected replica's copy of a field
 static int ctm_field(mmm_ctm* m, int field, double** p, size_t* n)
 {
-    const size_t MK = m->dm.MK, D = m->dm.D;
+    const size_t MK = m->dm.MK, D = m->dm.D, r = m->sel, GT = m->dm.GT, GM = m->GM;
     switch (field) {
-        case MMM_CTM_MU: *p = m->mu.p; *n = MK; break;
-        case MMM_CTM_SIGMA: *p = m->Sigma.p; *n = MK * MK; break;
-        case MMM_CTM_INVSIGMA: *p = m->invSigma.p; *n = MK * MK; break;
-        case MMM_CTM_GAMMA: *p = m->gamma.p; *n = m->GM; break;
-        case MMM_CTM_ELNPHI: *p = m->Elnphi.p; *n = m->GM; break;
-        case MMM_CTM_PHI: *p = m->immctm ? m->phieff.p : m->phi.p; *n = m->immctm ? m->dm.GT : m->GM; break;
-        case MMM_CTM_LAMBDA: *p = m->lambda[m->cur].p; *n = D * MK; break;
-        case MMM_CTM_NU: *p = m->nu.p; *n = D * MK; break;
-        case MMM_CTM_ZETA: *p = m->zeta.p; *n = D * m->dm.M; break;
-        case MMM_CTM_PROPS: *p = m->props.p; *n = D * MK; break;
+        case MMM_CTM_MU: *p = m->mu.p + r * MK; *n = MK; break;
+        case MMM_CTM_SIGMA: *p = m->Sigma.p + r * MK * MK; *n = MK * MK; break;
+        case MMM_CTM_INVSIGMA: *p = m->invSigma.p + r * MK * MK; *n = MK * MK; break;
+        case MMM_CTM_GAMMA: *p = m->gamma.p + r * GM; *n = GM; break;
+        case MMM_CTM_ELNPHI: *p = m->Elnphi.p + r * GM; *n = GM; break;
+        case MMM_CTM_PHI: *p = m->immctm ? m->phieff.p + r * GT : m->phi.p + r * GM; *n = m->immctm ? GT : GM; break;
+        case MMM_CTM_LAMBDA: *p = m->lambda.p + r * D * MK; *n = D * MK; break;
+        case MMM_CTM_NU: *p = m->nu.p + r * D * MK; *n = D * MK; break;
+        case MMM_CTM_ZETA: *p = m->zeta.p + r * D * m->dm.M; *n = D * m->dm.M; break;
+        case MMM_CTM_PROPS: *p = m->props.p + r * D * MK; *n = D * MK; break;
         case MMM_CTM_THETA: *p = m->theta.p; *n = (size_t)m->theta_n; break;
         case MMM_CTM_ALPHA: *p = m->alpha.p; *n = m->immctm ? m->tp.aoff[m->dm.M] : m->dm.M; break;
         default: return mmm_fail(m->ctx, MMM_ERR_ARG, "unknown CTM field %d", field);
@@ -1192,6 +1345,14 @@ int mmm_ctm_get(mmm_ctm* m, int field, double* host, size_t n)
     return MMM_OK;
 }
 
+// stage calls that read theta: bring the selected replica's theta into the buffer first
+static int begin_stage(mmm_ctm* m)
+{
+    int rc = prep(m);
+    if (rc) return rc;
+    return materialise_theta(m);
+}
+
 int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n)
 {
     if (!m) return MMM_ERR_ARG;
@@ -1201,14 +1362,10 @@ int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n)
     double* p; size_t cnt;
     if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
     MMM_CHECK(ctx, host && n == cnt, "mmm_ctm_set(field %d): expected %zu doubles, got %zu", field, cnt, n);
-    if ((rc = materialise_theta(m))) return rc;       // make the implicit theta explicit before state changes
-    m->theta_from_prev = false;
+    if (field == MMM_CTM_THETA && (rc = claim_theta(m))) return rc;
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (field == MMM_CTM_ELNPHI || field == MMM_CTM_GAMMA) {
-        // keep the effective tables consistent with an uploaded Elnphi: rebuild them from gamma only on update_Elnϕ!;
-        // an uploaded Elnphi is used as is by update_θ! through mmm_ctm_update_Elnphi's table refresh
-    }
+    if (field == MMM_CTM_THETA) { m->theta_rep = m->sel; m->theta_state[m->sel] = 2; }
     return MMM_OK;
 }
 
@@ -1217,7 +1374,7 @@ int mmm_ctm_update_zeta(mmm_ctm* m)
     if (!m) return MMM_ERR_ARG;
     int rc = prep(m);
     if (rc) return rc;
-    return run_estep(m, F_ZETA, m->lambda[m->cur].p, nullptr, nullptr);
+    return run_estep(m, one(m), F_ZETA, m->lambda.p, nullptr, nullptr);
 }
 
 int mmm_ctm_update_theta(mmm_ctm* m)
@@ -1225,39 +1382,40 @@ int mmm_ctm_update_theta(mmm_ctm* m)
     if (!m) return MMM_ERR_ARG;
     int rc = prep(m);
     if (rc) return rc;
-    if ((rc = run_estep(m, F_THETA_COMPUTE | F_THETA_STORE, m->lambda[m->cur].p, nullptr, m->expEeff[m->ecur].p))) return rc;
-    m->theta_valid = true; m->theta_from_prev = false;
+    if ((rc = claim_theta(m))) return rc;
+    if ((rc = run_estep(m, one(m), F_THETA_COMPUTE | F_THETA_STORE, m->lambda.p, nullptr, m->expEeff.p))) return rc;
+    m->theta_rep = m->sel; m->theta_state[m->sel] = 2;
     return MMM_OK;
 }
 
 int mmm_ctm_update_nu(mmm_ctm* m)
 {
     if (!m) return MMM_ERR_ARG;
-    int rc = prep(m);
-    if (rc || (rc = materialise_theta(m))) return rc;
-    m->theta_from_prev = false;
-    return run_estep(m, F_NU, m->lambda[m->cur].p, nullptr, nullptr);
+    int rc = begin_stage(m);
+    if (rc) return rc;
+    return run_estep(m, one(m), F_NU, m->lambda.p, nullptr, nullptr);
 }
 
 int mmm_ctm_update_lambda(mmm_ctm* m)
 {
     if (!m) return MMM_ERR_ARG;
-    int rc = prep(m);
-    if (rc || (rc = materialise_theta(m))) return rc;
-    m->theta_from_prev = false;
+    int rc = begin_stage(m);
+    if (rc) return rc;
     // in place on the current lambda: the solver reads its start point before it stores the result
-    return run_estep(m, F_THETA_STORED | F_LAMBDA, m->lambda[m->cur].p, m->lambda[m->cur].p, nullptr);
+    return run_estep(m, one(m), F_THETA_STORED | F_LAMBDA, m->lambda.p, m->lambda.p, nullptr);
 }
 
 static int moments_to_stats(mmm_ctm* m)
 {
     const CtmDims& dm = m->dm;
-    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
-    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m), dim3(256), sizeof(double) * 64 * dm.MK, m->ctx->stream, dm.D, dm.MK, m->lambda[m->cur].p, m->nu.p, m->mompart.p);
+    const Scope sc = one(m);
+    const size_t r0 = sc.rep0;
+    hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, 1), dim3(256), sizeof(double) * 64 * dm.MK, m->ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
+                       m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, (const int*)nullptr);
     MMM_LAUNCH_CHECK(m->ctx);
-    int rc = reduce_partials(m, m->mompart.p, m->grid_m, nmom, m->stats.p);
+    int rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats);
     if (rc) return rc;
-    return mmm_allreduce_sum(m->ctx, m->stats.p, (size_t)nmom);
+    return mmm_allreduce_sum(m->ctx, m->stats.p + r0 * m->s_stats, (size_t)m->nmom);
 }
 
 int mmm_ctm_update_mu(mmm_ctm* m)
@@ -1265,7 +1423,7 @@ int mmm_ctm_update_mu(mmm_ctm* m)
     if (!m) return MMM_ERR_ARG;
     int rc = prep(m);
     if (rc || (rc = moments_to_stats(m))) return rc;
-    return run_mstep(m, 1, 0, 0, 0);
+    return run_mstep(m, one(m), 1, 0, 0, 0);
 }
 
 int mmm_ctm_update_Sigma(mmm_ctm* m)
@@ -1273,19 +1431,18 @@ int mmm_ctm_update_Sigma(mmm_ctm* m)
     if (!m) return MMM_ERR_ARG;
     int rc = prep(m);
     if (rc || (rc = moments_to_stats(m))) return rc;
-    if ((rc = run_mstep(m, 0, 1, 0, 0))) return rc;      // uses the stored mu, as update_Σ! does (MMCTM.jl:207)
-    return check_status(m);
+    if ((rc = run_mstep(m, one(m), 0, 1, 0, 0))) return rc;      // uses the stored mu, as update_Σ! does (MMCTM.jl:207)
+    return check_status(m, one(m));
 }
 
 int mmm_ctm_update_gamma(mmm_ctm* m)
 {
     if (!m) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    int rc = prep(m);
-    if (rc || (rc = materialise_theta(m))) return rc;
+    int rc = begin_stage(m);
+    if (rc) return rc;
     const CtmDims& dm = m->dm;
-    const int nmom = 2 * dm.MK + dm.MK * dm.MK;
-    double* sums = m->stats.p + nmom;
+    double* sums = m->stats.p + (size_t)m->sel * m->s_stats + m->nmom;
     MMM_HIP(ctx, hipMemsetAsync(sums, 0, sizeof(double) * dm.GT, ctx->stream));
     for (int i = 0; i < dm.M; ++i) {
         const int64_t n = m->nnzm[i];
@@ -1293,17 +1450,15 @@ int mmm_ctm_update_gamma(mmm_ctm* m)
     }
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, sums, (size_t)dm.GT))) return rc;
-    m->theta_from_prev = false;
-    return run_mstep(m, 0, 0, 1, 1);
+    return run_mstep(m, one(m), 0, 0, 1, 1);
 }
 
 int mmm_ctm_update_Elnphi(mmm_ctm* m)
 {
     if (!m) return MMM_ERR_ARG;
-    int rc = prep(m);
-    if (rc || (rc = materialise_theta(m))) return rc;
-    m->theta_from_prev = false;
-    return run_mstep(m, 0, 0, 1, 0);
+    int rc = begin_stage(m);
+    if (rc) return rc;
+    return run_mstep(m, one(m), 0, 0, 1, 0);
 }
 
 int mmm_ctm_update_props(mmm_ctm* m)
@@ -1311,7 +1466,7 @@ int mmm_ctm_update_props(mmm_ctm* m)
     if (!m) return MMM_ERR_ARG;
     int rc = prep(m);
     if (rc) return rc;
-    return run_loglik(m, nullptr, false);
+    return run_loglik(m, one(m), nullptr, 0, false);
 }
 
 int mmm_ctm_update_phi(mmm_ctm* m)
@@ -1326,9 +1481,8 @@ int mmm_ctm_loglik(mmm_ctm* m, double* ll)
     mmm_ctx* ctx = m->ctx;
     int rc = prep(m);
     if (rc) return rc;
-    double* dst = m->llnum.p;       // reuse: k_ll_store reads num and writes dst elementwise (same index) -- use a separate slot
-    dst = m->elbopart.p;            // scratch
-    if ((rc = run_loglik(m, dst, true))) return rc;
+    double* dst = m->elbopart.p;            // scratch
+    if ((rc = run_loglik(m, one(m), dst, 0, true))) return rc;
     MMM_HIP(ctx, hipMemcpyAsync(ll, dst, sizeof(double) * m->dm.M, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
@@ -1341,14 +1495,13 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
     int rc = prep(m);
     if (rc || (rc = materialise_theta(m))) return rc;
     MMM_CHECK(ctx, d >= 0 && d < m->dm.D, "mmm_ctm_objectives: document %d out of range", d);
-    const int MK = m->dm.MK;
-    double* out = m->elbopart.p;
+    const size_t MK = m->dm.MK, r = m->sel;
     DevBuf<double> tmp;
-    MMM_HIP(ctx, tmp.alloc(2 + 2 * (size_t)MK));
-    hipLaunchKernelGGL(k_ctm_objectives, dim3(1), dim3(64), 0, ctx->stream, m->dev(), d, m->invSigma.p, m->mu.p, m->lambda[m->cur].p, m->nu.p, m->zeta.p, m->theta.p, tmp.p);
+    MMM_HIP(ctx, tmp.alloc(2 + 2 * MK));
+    hipLaunchKernelGGL(k_ctm_objectives, dim3(1), dim3(64), 0, ctx->stream, m->dev(), d, m->invSigma.p + r * MK * MK, m->mu.p + r * MK, m->lambda.p + r * m->sDMK(),
+                       m->nu.p + r * m->sDMK(), m->zeta.p + r * m->dm.D * m->dm.M, m->theta.p, tmp.p);
     MMM_LAUNCH_CHECK(ctx);
-    (void)out;
-    std::vector<double> h(2 + 2 * (size_t)MK);
+    std::vector<double> h(2 + 2 * MK);
     MMM_HIP(ctx, hipMemcpyAsync(h.data(), tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (lambda_val) *lambda_val = h[0];
@@ -1367,8 +1520,8 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
     const int D = m->dm.D;
     std::vector<int> a((size_t)D), b((size_t)D);
     if (D) {
-        MMM_HIP(ctx, hipMemcpyAsync(a.data(), m->nev_nu.p, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
-        MMM_HIP(ctx, hipMemcpyAsync(b.data(), m->nev_lam.p, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(a.data(), m->nev_nu.p + (size_t)m->sel * D, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(b.data(), m->nev_lam.p + (size_t)m->sel * D, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
     }
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int64_t sa = 0, sb = 0, cap = 0;
@@ -1387,7 +1540,7 @@ int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma)
     int rc = prep(m);
     if (rc) return rc;
     MMM_CHECK(m->ctx, n_iter >= 0, "mmm_ctm_iterate: n_iter < 0");
-    for (int i = 0; i < n_iter; ++i) if ((rc = fused_pass(m, update_sigma))) return rc;
+    for (int i = 0; i < n_iter; ++i) if ((rc = fused_pass(m, one(m), update_sigma))) return rc;
     return MMM_OK;
 }
 
@@ -1397,8 +1550,8 @@ int mmm_ctm_ll_history(mmm_ctm* m, double* ll, int max_n, int* n)
     mmm_ctx* ctx = m->ctx;
     int rc = prep(m);
     if (rc) return rc;
-    const int M = m->dm.M, cnt = std::min(max_n, m->n_hist);
-    if (cnt > 0 && ll) MMM_HIP(ctx, hipMemcpyAsync(ll, m->ll_hist.p + (size_t)(m->n_hist - cnt) * M, sizeof(double) * cnt * M, hipMemcpyDeviceToHost, ctx->stream));
+    const int M = m->dm.M, nh = m->n_hist[m->sel], cnt = std::min(max_n, nh);
+    if (cnt > 0 && ll) MMM_HIP(ctx, hipMemcpyAsync(ll, m->ll_hist.p + ((size_t)m->sel * m->cap_hist + (nh - cnt)) * M, sizeof(double) * cnt * M, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n = cnt;
     return MMM_OK;
@@ -1411,15 +1564,17 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     int rc = prep(m);
     if (rc || (rc = materialise_theta(m))) return rc;
     const CtmDims& dm = m->dm;
-    const size_t lds = sizeof(double) * ((size_t)dm.MK * dm.MK + dm.GT + kWavesS * 64);
+    const size_t MKz = dm.MK, r = m->sel;
+    const size_t lds = sizeof(double) * (MKz * MKz + dm.GT + kWavesS * 64);
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double* acc = m->elbopart.p + (size_t)m->grid_s * 5;     // [0..4] doc sums, [5..7] topic side
-    hipLaunchKernelGGL(k_ctm_elbo_docs, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p, m->mu.p, m->lambda[m->cur].p, m->nu.p,
-                       m->zeta.p, m->theta.p, m->Eeff.p, m->elbopart.p);
-    hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc);
-    const size_t lds2 = sizeof(double) * 2 * (size_t)dm.MK * dm.MK;
+    hipLaunchKernelGGL(k_ctm_elbo_docs, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p + r * MKz * MKz, m->mu.p + r * MKz,
+                       m->lambda.p + r * m->sDMK(), m->nu.p + r * m->sDMK(), m->zeta.p + r * dm.D * dm.M, m->theta.p, m->Eeff.p + r * dm.GT, m->elbopart.p);
+    hipLaunchKernelGGL(k_sum_columns, dim3(5, 1), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc, (size_t)0, (const int*)nullptr);
+    const size_t lds2 = sizeof(double) * 2 * MKz * MKz;
     if (lds2 > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_topics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, m->tp, m->gamma.p, m->Elnphi.p, m->invSigma.p, acc + 5);
+    hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, m->tp, m->gamma.p + r * m->GM, m->Elnphi.p + r * m->GM,
+                       m->invSigma.p + r * MKz * MKz, acc + 5);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
     double h[8];
@@ -1439,37 +1594,84 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     return MMM_OK;
 }
 
+// fit! for the replicas of a scope, in lock step: every pass advances all still-active replicas; a replica leaves when
+// its stopping rule fires (MMCTM.jl:485 + common.jl:48-51).  ll_hist: [nrep][maxiter][M].
+static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged)
+{
+    mmm_ctx* ctx = m->ctx;
+    const int M = m->dm.M, nrep = sc.nrep;
+    int rc;
+    std::vector<int> base(nrep), done(nrep, 0);
+    for (int i = 0; i < nrep; ++i) { base[i] = m->n_hist[sc.rep0 + i]; converged[i] = 0; }
+    const bool batch = sc.active != nullptr;
+    if (batch) {
+        for (int i = 1; i < nrep; ++i) MMM_CHECK(ctx, base[i] == base[0], "mmm_ctm_fit_batch: replicas have different histories (%d vs %d passes)", base[i], base[0]);
+        std::fill(m->h_active.begin(), m->h_active.end(), 1);
+        if ((rc = upload_active(m))) return rc;
+    }
+    std::vector<double> ll((size_t)nrep * maxiter * M);
+    int pass = 0, nactive = nrep;
+    while (pass < maxiter && nactive > 0) {
+        // the stopping rule needs > 10 values: the first 11 passes run without a host check
+        const int chunk = (pass == 0) ? std::min(maxiter, 11) : 1;
+        for (int i = 0; i < chunk; ++i) if ((rc = fused_pass(m, sc, update_sigma))) return rc;
+        for (int i = 0; i < nrep; ++i) {
+            const int r = sc.rep0 + i;
+            if (batch && !m->h_active[r]) continue;
+            MMM_HIP(ctx, hipMemcpyAsync(ll.data() + ((size_t)i * maxiter + pass) * M, m->ll_hist.p + ((size_t)r * m->cap_hist + base[i] + pass) * M,
+                                        sizeof(double) * chunk * M, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if ((rc = check_status(m, sc))) return rc;
+        pass += chunk;
+        bool changed = false;
+        for (int i = 0; i < nrep; ++i) {
+            const int r = sc.rep0 + i;
+            if (batch && !m->h_active[r]) continue;
+            done[i] = pass;
+            if (pass > 10) {          // common.jl:48-51
+                double rel = 0.0;
+                for (int q = 0; q < M; ++q) {
+                    const double a = ll[((size_t)i * maxiter + pass - 2) * M + q], b = ll[((size_t)i * maxiter + pass - 1) * M + q];
+                    const double rr = fabs(a - b) / fabs(b);
+                    if (rr > rel || rr != rr) rel = rr;       // NaN propagates like Julia's maximum
+                }
+                if (rel < tol) { converged[i] = 1; if (batch) { m->h_active[r] = 0; changed = true; } --nactive; }
+            }
+        }
+        if (!batch && converged[0]) break;
+        if (changed && (rc = upload_active(m))) return rc;
+    }
+    for (int i = 0; i < nrep; ++i) {
+        n_iter[i] = done[i];
+        if (ll_hist) memcpy(ll_hist + (size_t)i * maxiter * M, ll.data() + (size_t)i * maxiter * M, sizeof(double) * done[i] * M);
+    }
+    return MMM_OK;
+}
+
 int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged, double* elbo)
 {
     if (!m || !n_iter || !converged) return MMM_ERR_ARG;
-    mmm_ctx* ctx = m->ctx;
-    MMM_CHECK(ctx, maxiter >= 1, "mmm_ctm_fit: maxiter < 1");
+    MMM_CHECK(m->ctx, maxiter >= 1, "mmm_ctm_fit: maxiter < 1");
     int rc = prep(m);
-    if (rc) return rc;
-    const int M = m->dm.M, base = m->n_hist;
-    *converged = 0;
-    std::vector<double> ll((size_t)maxiter * M);
-    int done = 0;
-    while (done < maxiter) {
-        // the stopping rule needs > 10 values (MMCTM.jl:485): the first 11 passes run without a host check
-        const int chunk = (done == 0) ? std::min(maxiter, 11) : 1;
-        for (int i = 0; i < chunk; ++i) if ((rc = fused_pass(m, update_sigma))) return rc;
-        MMM_HIP(ctx, hipMemcpyAsync(ll.data() + (size_t)done * M, m->ll_hist.p + (size_t)(base + done) * M, sizeof(double) * chunk * M, hipMemcpyDeviceToHost, ctx->stream));
-        if ((rc = check_status(m))) return rc;
-        done += chunk;
-        if (done > 10) {          // common.jl:48-51
-            double rel = 0.0;
-            for (int q = 0; q < M; ++q) {
-                const double a = ll[(size_t)(done - 2) * M + q], b = ll[(size_t)(done - 1) * M + q];
-                const double r = fabs(a - b) / fabs(b);
-                if (r > rel || r != r) rel = r;       // NaN propagates like Julia's maximum
-            }
-            if (rel < tol) { *converged = 1; break; }
-        }
-    }
-    *n_iter = done;
-    if (ll_hist) memcpy(ll_hist, ll.data(), sizeof(double) * done * M);
+    if (rc || (rc = fit_scope(m, one(m), maxiter, tol, update_sigma, ll_hist, n_iter, converged))) return rc;
     if (elbo) return mmm_ctm_elbo(m, elbo, nullptr);
+    return MMM_OK;
+}
+
+int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged, double* elbo)
+{
+    if (!m || !n_iter || !converged) return MMM_ERR_ARG;
+    MMM_CHECK(m->ctx, maxiter >= 1, "mmm_ctm_fit_batch: maxiter < 1");
+    int rc = prep(m);
+    if (rc || (rc = fit_scope(m, all(m), maxiter, tol, update_sigma, ll_hist, n_iter, converged))) return rc;
+    if (elbo) {
+        const int keep = m->sel;
+        for (int r = 0; r < m->R; ++r) {
+            m->sel = r;
+            if ((rc = mmm_ctm_elbo(m, elbo + r, nullptr))) { m->sel = keep; return rc; }
+        }
+        m->sel = keep;
+    }
     return MMM_OK;
 }
 

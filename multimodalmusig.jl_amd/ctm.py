@@ -82,16 +82,34 @@ class _CTM:
         self.ll = None
 
     def _create(self, V, alpha_flat, gamma0, nfeat=None, J=None, features=None):
+        """gamma0: flat init of one model, or R of them stacked ([R, GM]) for a restart batch."""
         self._h = C.c_void_p()
+        gamma0 = np.ascontiguousarray(gamma0, dtype=np.float64)
+        self.R = 1 if gamma0.ndim == 1 else int(gamma0.shape[0])
+        if gamma0.size != self.R * self._GM:
+            raise ValueError("γ0 has %d values, expected %d per model" % (gamma0.size, self._GM))
+        self._sel = 0
         Kc = np.ascontiguousarray(self.K, dtype=np.int32); Vc = np.ascontiguousarray(V, dtype=np.int32)
         tp = self._term.ctypes.data if self._term.size else None
         cp = self._count.ctypes.data if self._count.size else None
         keep = [np.ascontiguousarray(x, dtype=np.int32) if x is not None else None for x in (nfeat, J, features)]
         ptr = [x.ctypes.data if x is not None else None for x in keep]
-        check(lib().mmm_ctm_create(self.ctx.h, self.D, self.M, Kc, Vc, np.ascontiguousarray(alpha_flat, dtype=np.float64), self._doc_ptr, tp, cp,
-                                   ptr[0], ptr[1], ptr[2], np.ascontiguousarray(gamma0, dtype=np.float64), C.byref(self._opts), C.byref(self._h)),
-              self.ctx.h, "mmm_ctm_create")
+        check(lib().mmm_ctm_create_batch(self.ctx.h, self.R, self.D, self.M, Kc, Vc, np.ascontiguousarray(alpha_flat, dtype=np.float64), self._doc_ptr,
+                                         tp, cp, ptr[0], ptr[1], ptr[2], gamma0.ravel(), C.byref(self._opts), C.byref(self._h)),
+              self.ctx.h, "mmm_ctm_create_batch")
         _lib.track(self)
+        self.restart_ll = None; self.restart_elbo = None; self.restart_converged = None; self.restart_iters = None
+
+    # ---- restart batch (scripts/run_mmctm.jl:77-134) -------------------------------------------------------------------
+    def select(self, r):
+        """Make restart `r` the model the fields and the per-model functions act on."""
+        check(lib().mmm_ctm_select(self._h, int(r)), self.ctx.h, "select")
+        self._sel = int(r)
+        return self
+
+    @property
+    def selected(self):
+        return self._sel
 
     # ---- flat field transfer --------------------------------------------------------------------------------------
     def _fsize(self, name):
@@ -212,7 +230,7 @@ class MMCTM(_CTM):
     unless `γ0` (list over m of K_m x V_m arrays) is given."""
     _immctm = False
 
-    def __init__(self, k, α, *args, γ0=None, seed=None, init="random", ctx=None, xtol_rule=0, max_eval=0):
+    def __init__(self, k, α, *args, γ0=None, seed=None, init="random", ctx=None, xtol_rule=0, max_eval=0, restarts=None):
         if init != "random":
             raise ValueError("init must be either :random or :document")       # MMCTM.jl:76 (only :random works upstream)
         if len(args) == 1:
@@ -232,10 +250,22 @@ class MMCTM(_CTM):
         self.α = np.asarray(α, dtype=np.float64).copy()
         self._goff = np.concatenate([[0], np.cumsum([self.K[m] * self.V[m] for m in range(self.M)])]).astype(np.int64)
         self._GM = self._GT = int(self._goff[-1]); self._nalpha = self.M
-        if γ0 is None:
-            rng = np.random.default_rng(seed)
-            γ0 = [rng.integers(1, 101, size=(self.K[m], self.V[m])).astype(np.float64) for m in range(self.M)]
-        g = np.concatenate([np.asarray(γ0[m], dtype=np.float64).reshape(self.K[m], self.V[m]).ravel() for m in range(self.M)])
+        def draw(sd):
+            rng = np.random.default_rng(sd)
+            return [rng.integers(1, 101, size=(self.K[m], self.V[m])).astype(np.float64) for m in range(self.M)]
+
+        def flat(g0):
+            return np.concatenate([np.asarray(g0[m], dtype=np.float64).reshape(self.K[m], self.V[m]).ravel() for m in range(self.M)])
+        if restarts is None:
+            g = flat(draw(seed) if γ0 is None else γ0)
+        else:
+            # one model per restart: γ0 = list of R inits, or seeds seed, seed+1, ... (fit_restart, scripts/run_mmctm.jl:77-84)
+            R = int(restarts)
+            if γ0 is None:
+                γ0 = [draw(None if seed is None else seed + r) for r in range(R)]
+            if len(γ0) != R:
+                raise ValueError("restarts=%d but %d initialisations given" % (R, len(γ0)))
+            g = np.stack([flat(x) for x in γ0])
         self._create(self.V, self.α, g)
 
     def _topic_span(self, name, path):
@@ -254,7 +284,7 @@ class IMMCTM(_CTM):
     α: per modality scalar (IMMCTM.jl:81-88) or per-feature vector.  γ0: flat init in the layout [m][k][i][j]."""
     _immctm = True
 
-    def __init__(self, k, α, features, X, γ0=None, seed=None, ctx=None, xtol_rule=0, max_eval=0):
+    def __init__(self, k, α, features, X, γ0=None, seed=None, ctx=None, xtol_rule=0, max_eval=0, restarts=None):
         self._init_common(k, X, ctx, xtol_rule, max_eval)
         feats = [np.asarray(f, dtype=np.int64) for f in features]
         self.features = feats
@@ -269,10 +299,19 @@ class IMMCTM(_CTM):
         self._mgoff = np.concatenate([[0], np.cumsum([self.K[m] * self._SJ[m] for m in range(self.M)])]).astype(np.int64)
         self._GM = int(self._mgoff[-1]); self._GT = int(sum(self.K[m] * self.V[m] for m in range(self.M)))
         self._nalpha = int(sum(self.I))
-        if γ0 is None:
-            γ0 = np.random.default_rng(seed).integers(1, 101, size=self._GM).astype(np.float64)
+        if restarts is None:
+            if γ0 is None:
+                γ0 = np.random.default_rng(seed).integers(1, 101, size=self._GM).astype(np.float64)
+            γ0 = np.asarray(γ0, dtype=np.float64).ravel()
+        else:
+            R = int(restarts)
+            if γ0 is None:
+                γ0 = [np.random.default_rng(None if seed is None else seed + r).integers(1, 101, size=self._GM) for r in range(R)]
+            γ0 = np.stack([np.asarray(x, dtype=np.float64).ravel() for x in γ0])
+            if γ0.shape[0] != R:
+                raise ValueError("restarts=%d but %d initialisations given" % (R, γ0.shape[0]))
         featflat = np.concatenate([(f - 1).T.ravel() for f in feats]).astype(np.int32)
-        self._create(self.V, np.concatenate(self.α), np.asarray(γ0, dtype=np.float64).ravel(),
+        self._create(self.V, np.concatenate(self.α), γ0,
                      nfeat=np.asarray(self.I), J=np.concatenate([np.asarray(j) for j in self.J]), features=featflat)
 
     def _topic_span(self, name, path):
@@ -354,3 +393,30 @@ def _fit_ctm(model, maxiter, tol, verbose, autoα=False, updateΣ=True):
             print("%d\tLog-likelihoods: %s" % (i + 1, ", ".join(repr(float(x)) for x in v)))
     model.converged = bool(cv.value); model.elbo = el.value; model.ll = hist[-1].copy()
     return hist
+
+
+def fit_restarts(model, maxiter=100, tol=1e-4, verbose=False, updateΣ=True):
+    """`fit!` of every restart of a batch model (constructed with `restarts=R` or R stacked γ0), all restarts advancing
+    together on the GPU -- what `fit_seed_models` (scripts/run_mmctm.jl:97-109) gets from `pmap(fit_restart, seeds)`.
+    Returns the list of per-restart ll histories ([n_iter_r, M] each); per-restart results are kept on the model as
+    `restart_ll` ([R, M] final ll), `restart_elbo`, `restart_converged`, `restart_iters`."""
+    R, M = model.R, model.M
+    maxiter = int(maxiter)
+    ll = np.zeros(R * maxiter * M); ni = np.zeros(R, dtype=np.int32); cv = np.zeros(R, dtype=np.int32); el = np.zeros(R)
+    check(lib().mmm_ctm_fit_batch(model._h, maxiter, float(tol), 1 if updateΣ else 0, ll.ctypes.data, ni.ctypes.data, cv.ctypes.data, el.ctypes.data),
+          model.ctx.h, "fit_restarts(::%s)" % type(model).__name__)
+    ll = ll.reshape(R, maxiter, M)
+    hists = [ll[r, :ni[r]].copy() for r in range(R)]
+    model.restart_ll = np.stack([h[-1] for h in hists])
+    model.restart_elbo = el.copy(); model.restart_converged = cv.astype(bool); model.restart_iters = ni.copy()
+    if verbose:
+        for r in range(R):
+            print("restart %d	%d iterations	Log-likelihoods: %s" % (r, ni[r], ", ".join(repr(float(x)) for x in hists[r][-1])))
+    s = model.selected
+    model.converged = bool(cv[s]); model.elbo = float(el[s]); model.ll = hists[s][-1].copy()
+    return hists
+
+
+def pick_optimal_modality_models(model):
+    """Index of the best restart per modality by final log-likelihood -- scripts/run_mmctm.jl:86-95."""
+    return [int(i) for i in np.argmax(model.restart_ll, axis=0)]
