@@ -57,3 +57,35 @@ def test_config3_mmctm_77_brca_snv_sv(mmm, oracle):
     pe = np.abs(g._get("props") - o.props)
     print("config 3 after %d passes: props abs err median %.2e max %.2e; ll %s" % (n, np.median(pe), pe.max(), ll_g[-1]))
     assert np.median(pe) < 2e-4 and pe.max() < 5e-2
+
+
+def test_restart_driver_on_brca(mmm):
+    """`fit_model` of scripts/run_mmctm.jl:163-182 on the shipped tables: 6 restarts in one batch, per-modality selection,
+    seeded second-stage fit.  The batched stage 1 must pick what R separate fits pick, and stage 2 must start from the
+    selected topics."""
+    from multimodalmusig_jl_amd import restarts as rs
+    samples, snv, sv = _tables(mmm)
+    X = mmm.format_counts_mmctm([snv, sv], samples)
+    K, alpha, V = [7, 7], [0.1, 0.1], [96, 48]
+    seeds = [11, 12, 13, 14, 15, 16]
+    kw = dict(maxiter=25, tol=1e-3)
+    opt_gamma, opt_ll, all_ll = rs.fit_seed_models(X, K, alpha, V, seeds, **kw)
+    # the same sweep in two chunks of three, and restart by restart
+    og2, ol2, al2 = rs.fit_seed_models(X, K, alpha, V, seeds, batch_size=3, **kw)
+    np.testing.assert_array_equal(all_ll, al2)
+    np.testing.assert_array_equal(opt_ll, ol2)
+    for m in range(2):
+        np.testing.assert_array_equal(opt_gamma[m], og2[m])
+    for i, s in enumerate(seeds[:2]):
+        rng = np.random.default_rng(s)
+        g0 = [rng.integers(1, 101, size=(K[m], V[m])).astype(np.float64) for m in range(2)]
+        single = mmm.MMCTM(K, alpha, V, X, γ0=g0)
+        mmm.fit(single, verbose=False, **kw)
+        np.testing.assert_array_equal(single.ll, all_ll[i])
+    assert np.all(opt_ll == all_ll.max(axis=0))
+    model = rs.seed_and_fit_restart(X, K, alpha, V, opt_gamma, maxiter=15, tol=1e-5)
+    # stage 2 starts from the selected topics: its log-likelihood is at least as good as the per-modality optimum
+    # it was seeded with, up to the slack of mixing two models' topics
+    assert np.all(np.isfinite(model.ll)) and np.isfinite(model.elbo)
+    assert np.all(model.ll > all_ll.mean(axis=0) - 0.05)
+    print("restart driver: stage-1 ll per restart\n%s\nbest per modality %s, stage-2 ll %s" % (all_ll, opt_ll, model.ll))
