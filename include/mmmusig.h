@@ -111,6 +111,13 @@ int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n);
 /* fit!(model; maxiter, tol) -- LDA.jl:198-224: iterate until |dll|/|ll| < tol after > 10 passes, then ELBO. */
 int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged,
                 double* elbo);
+/* Frozen-topic inference on a model whose topics were uploaded with mmm_lda_set: the loop of
+ * transform(model, X) LDA.jl:233-263 (unsmoothed = 1: unsmoothed_update_ϕ!, phi ∝ exp(Elnθ)·β, needs BETA) or of
+ * fit_heldout(Xheldout, model) LDA.jl:265-295 (unsmoothed = 0: update_ϕ! with Elnβ, needs ELNBETA and BETA):
+ * { update_γ!; (unsmoothed_)update_ϕ!; update_θ!; ll } until the stopping rule fires after > 10 passes.  Topics are
+ * not touched; γ, Elnθ, θ, ϕ of the handle's documents are the result. */
+int mmm_lda_infer(mmm_lda* m, int unsmoothed, int maxiter, double tol, double* ll_hist, int* n_iter,
+                  int* converged);
 
 /* ---- MMCTM (src/MMCTM.jl) and IMMCTM (src/IMMCTM.jl) -------------------------------------------------------- */
 typedef struct {
@@ -162,6 +169,16 @@ int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma);
 int mmm_ctm_ll_history(mmm_ctm* m, double* ll /* M*max_n */, int max_n, int* n);
 int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
                 int* n_iter, int* converged, double* elbo);
+
+/* Frozen-topic inference on a model whose globals were uploaded with mmm_ctm_set.  Every pass runs the document loop
+ * { update_ζ!; update_θ!; update_ν!; update_λ! }, update_props! and the log-likelihoods; the stopping rule applies after
+ * > 10 passes.  flags = 0: fit_heldout / predict_modality_η (MMCTM.jl:554-634, IMMCTM.jl:468-545; needs MU, SIGMA,
+ * INVSIGMA, GAMMA, ELNPHI, PHI).  MMM_INFER_UNSMOOTHED: unsmoothed_update_θ! instead of update_θ! (θ ∝ exp(λ)·ϕ,
+ * MMCTM.jl:496-509; needs PHI) -- with it, transform (MMCTM.jl:511-552).  MMM_INFER_FIT_GAUSSIAN: also update_μ! and
+ * update_Σ! every pass (transform's fit_gaussian).  Topics are not touched. */
+enum { MMM_INFER_UNSMOOTHED = 1, MMM_INFER_FIT_GAUSSIAN = 2 };
+int mmm_ctm_infer(mmm_ctm* m, int flags, int maxiter, double tol, double* ll_hist /* M*maxiter */, int* n_iter,
+                  int* converged);
 
 /* Restart batching -- scripts/run_mmctm.jl:77-134 fits the same corpus from several random initialisations and
  * keeps the best.  A batch handle holds R independent models ("replicas") over ONE resident corpus; the batched

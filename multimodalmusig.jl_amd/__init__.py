@@ -9,8 +9,9 @@ from .models import (LDA, calculate_elbo, calculate_loglikelihood, fit, fit_bang
                      update_λ, update_ϕ)
 from .ctm import (IMMCTM, MMCTM, calculate_loglikelihoods, fit_restarts, fitdoc, pick_optimal_modality_models, update_Elnϕ, update_props, update_Σ, update_ζ, update_μ,
                   update_ν)
+from .inference import fit_heldout, predict_modality_η, transform
 from .utils import (format_counts_ctm, format_counts_lda, format_counts_mmctm, make_count_matrix, pack_lda,
                     pack_mm, read_counts_tsv, shard_documents)
 
 __all__ = ["IMMCTM", "MMCTM", "LDA", "fit", "fit_bang", "format_counts_lda", "format_counts_ctm", "format_counts_mmctm", "Context",
-           "MmmError", "build", "fit_restarts"]
+           "MmmError", "build", "fit_restarts", "transform", "fit_heldout", "predict_modality_η"]

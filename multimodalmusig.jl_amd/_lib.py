@@ -67,6 +67,7 @@ _SIGS = {
     "mmm_lda_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_lda_fit": (C.c_int, [vp, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_solver_opts_default": (None, [C.POINTER(SolverOpts)]),
+    "mmm_lda_infer": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmm_ctm_create": (C.c_int, [vp, C.c_int, C.c_int, i32p, i32p, f64p, i64p, vp, vp, vp, vp, vp, f64p, C.POINTER(SolverOpts), C.POINTER(vp)]),
     "mmm_ctm_destroy": (C.c_int, [vp]),
     "mmm_ctm_get": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
@@ -88,6 +89,7 @@ _SIGS = {
     "mmm_ctm_iterate": (C.c_int, [vp, C.c_int, C.c_int]),
     "mmm_ctm_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_ctm_fit": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "mmm_ctm_infer": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmm_ctm_create_batch": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, f64p, i64p, vp, vp, vp, vp, vp, f64p, C.POINTER(SolverOpts), C.POINTER(vp)]),
     "mmm_ctm_replicas": (C.c_int, [vp]),
     "mmm_ctm_select": (C.c_int, [vp, C.c_int]),

@@ -632,6 +632,39 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
     }
 }
 
+// effective tables from UPLOADED topic fields (fit_heldout copies γ and Elnϕ, MMCTM.jl:561-562), one block per topic:
+// Elnphi != NULL: Eeff / exp(Eeff) from it; gamma != NULL (IMMCTM, whose ll normalises γ itself, IMMCTM.jl:417-420): phieff
+__global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmTopics tp, const double* Elnphi, double* Eeff, double* expEeff,
+                                                                const double* gamma, double* phieff)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    int m = 0;
+    while (m + 1 < dm.M && (int)blockIdx.x >= dm.koff[m + 1]) ++m;
+    const int k = blockIdx.x - dm.koff[m];
+    const int Vm = dm.V[m], go = dm.goff[m];
+    if (!tp.immctm) {
+        if (Elnphi) for (int v = tid; v < Vm; v += nt) { const double el = Elnphi[go + k * Vm + v]; Eeff[go + k * Vm + v] = el; expEeff[go + k * Vm + v] = exp(el); }
+    } else {
+        const int mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
+        const int* feat = tp.features + tp.foff[m];
+        for (int v = tid; v < Vm; v += nt) {
+            double se = 0.0, pp = 1.0; int jo = 0;
+            for (int i = 0; i < nf; ++i) {
+                const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
+                if (Elnphi) se += Elnphi[mg + k * SJ + jo + f];
+                if (gamma) {
+                    double cs = 0.0;
+                    for (int j = 0; j < Ji; ++j) cs += gamma[mg + k * SJ + jo + j];
+                    pp *= gamma[mg + k * SJ + jo + f] / cs;
+                }
+                jo += Ji;
+            }
+            if (Elnphi) { Eeff[go + k * Vm + v] = se; expEeff[go + k * Vm + v] = exp(se); }
+            if (gamma) phieff[go + k * Vm + v] = pp;
+        }
+    }
+}
+
 // props = softmax(lambda block) (MMCTM.jl:145-154) and per-modality ll numerators (MMCTM.jl:384-418); wave per document.
 // llpart[block][M]
 __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
@@ -1102,6 +1135,42 @@ int fused_pass(mmm_ctm* m, Scope sc, int update_sigma)
     return MMM_OK;
 }
 
+// one frozen-topic pass for the selected replica: the document loop of transform (MMCTM.jl:521-528; unsmoothed theta reads phi)
+// or of fit_heldout / predict_modality_η (MMCTM.jl:565-569: fitdoc!), optional update_μ!/update_Σ! (fit_gaussian, :530-533),
+// update_props! and the log-likelihoods.  Topics (gamma, Elnphi, phi) are not touched.
+int frozen_pass(mmm_ctm* m, Scope sc, int flags)
+{
+    mmm_ctx* ctx = m->ctx;
+    const CtmDims& dm = m->dm;
+    int rc;
+    const double* table = (flags & MMM_INFER_UNSMOOTHED) ? m->phieff.p : m->expEeff.p;
+    if ((rc = copy_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK()))) return rc;
+    if ((rc = copy_rep(m, sc, m->expEeff_prev.p, table, (size_t)dm.GT))) return rc;
+    { ProfSpan span(ctx); rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA, m->lambda.p, m->lambda.p, table); }
+    if (rc) return rc;
+    if (flags & MMM_INFER_FIT_GAUSSIAN) {
+        const size_t r0 = sc.rep0;
+        hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
+                           m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
+        MMM_LAUNCH_CHECK(ctx);
+        if ((rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats))) return rc;
+        if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
+        if ((rc = run_mstep(m, sc, 1, 1, 0, 0))) return rc;
+    }
+    if ((rc = ensure_hist(m, 1))) return rc;
+    int nh = 0;
+    for (int i = 0; i < sc.nrep; ++i)
+        if (!sc.active || m->h_active[sc.rep0 + i]) nh = std::max(nh, m->n_hist[sc.rep0 + i]);
+    if ((rc = run_loglik(m, sc, m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + nh) * dm.M, (size_t)m->cap_hist * dm.M, true))) return rc;
+    for (int i = 0; i < sc.nrep; ++i) {
+        const int r = sc.rep0 + i;
+        if (sc.active && !m->h_active[r]) continue;
+        m->n_hist[r]++; m->theta_state[r] = 1;
+        if (m->theta_rep == r) m->theta_rep = -1;
+    }
+    return MMM_OK;
+}
+
 int prep(mmm_ctm* m) { MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return MMM_OK; }
 
 int upload_active(mmm_ctm* m)
@@ -1366,6 +1435,17 @@ int mmm_ctm_set(mmm_ctm* m, int field, const double* host, size_t n)
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (field == MMM_CTM_THETA) { m->theta_rep = m->sel; m->theta_state[m->sel] = 2; }
+    const size_t r = m->sel, GT = m->dm.GT;
+    if (field == MMM_CTM_ELNPHI || (field == MMM_CTM_GAMMA && m->immctm)) {
+        // the uploaded Elnphi is what update_θ! reads from now on (MMCTM.jl:190); IMMCTM's ll normalises the uploaded gamma
+        const bool e = field == MMM_CTM_ELNPHI;
+        hipLaunchKernelGGL(k_ctm_tables_from_Elnphi, dim3(m->dm.MK), dim3(256), 0, ctx->stream, m->dm, m->tp, e ? m->Elnphi.p + r * m->GM : nullptr,
+                           m->Eeff.p + r * GT, m->expEeff.p + r * GT, e ? nullptr : m->gamma.p + r * m->GM, m->phieff.p + r * GT);
+        MMM_LAUNCH_CHECK(ctx);
+    }
+    if (field == MMM_CTM_PHI && !m->immctm)   // ... and the uploaded phi what the ll and unsmoothed_update_θ! read
+        MMM_HIP(ctx, hipMemcpyAsync(m->phieff.p + r * GT, m->phi.p + r * m->GM, sizeof(double) * GT, hipMemcpyDeviceToDevice, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
 }
 
@@ -1596,7 +1676,8 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
 
 // fit! for the replicas of a scope, in lock step: every pass advances all still-active replicas; a replica leaves when
 // its stopping rule fires (MMCTM.jl:485 + common.jl:48-51).  ll_hist: [nrep][maxiter][M].
-static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged)
+static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged,
+                     int infer_flags = -1)
 {
     mmm_ctx* ctx = m->ctx;
     const int M = m->dm.M, nrep = sc.nrep;
@@ -1614,7 +1695,8 @@ static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_s
     while (pass < maxiter && nactive > 0) {
         // the stopping rule needs > 10 values: the first 11 passes run without a host check
         const int chunk = (pass == 0) ? std::min(maxiter, 11) : 1;
-        for (int i = 0; i < chunk; ++i) if ((rc = fused_pass(m, sc, update_sigma))) return rc;
+        for (int i = 0; i < chunk; ++i)
+            if ((rc = infer_flags < 0 ? fused_pass(m, sc, update_sigma) : frozen_pass(m, sc, infer_flags))) return rc;
         for (int i = 0; i < nrep; ++i) {
             const int r = sc.rep0 + i;
             if (batch && !m->h_active[r]) continue;
@@ -1656,6 +1738,17 @@ int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* l
     if (rc || (rc = fit_scope(m, one(m), maxiter, tol, update_sigma, ll_hist, n_iter, converged))) return rc;
     if (elbo) return mmm_ctm_elbo(m, elbo, nullptr);
     return MMM_OK;
+}
+
+int mmm_ctm_infer(mmm_ctm* m, int flags, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged)
+{
+    if (!m || !n_iter || !converged) return MMM_ERR_ARG;
+    MMM_CHECK(m->ctx, maxiter >= 1, "mmm_ctm_infer: maxiter < 1");
+    MMM_CHECK(m->ctx, (flags & ~(MMM_INFER_UNSMOOTHED | MMM_INFER_FIT_GAUSSIAN)) == 0, "mmm_ctm_infer: unknown flags %d", flags);
+    MMM_CHECK(m->ctx, !((flags & MMM_INFER_UNSMOOTHED) && m->immctm), "mmm_ctm_infer: IMMCTM has no phi field, hence no unsmoothed_update_θ! (IMMCTM.jl)");
+    int rc = prep(m);
+    if (rc) return rc;
+    return fit_scope(m, one(m), maxiter, tol, 1, ll_hist, n_iter, converged, flags);
 }
 
 int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter, int* converged, double* elbo)

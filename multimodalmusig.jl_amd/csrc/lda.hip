@@ -389,6 +389,32 @@ __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double et
     if (k == 0 && lane == 0) lda_pass_tail(r);
 }
 
+// Frozen-topic passes (transform / fit_heldout, LDA.jl:233-295): the E-step kernel runs with fixed tables and evaluates
+// the ll of the SAME pass (theta_t and beta are both known); this kernel sums the per-block numerators (phase & 1), and
+// (phase & 2) records ll_t, applies the stopping rule (LDA.jl:252 / :285) and advances the pass counter.
+__global__ __launch_bounds__(64) void k_lda_infer_tail(ReduceArgs r, int phase)
+{
+    if (r.ctl->stop) return;
+    const int lane = threadIdx.x;
+    if (phase & 1) {
+        double v = 0.0;
+        for (int i = lane; i < r.nslab; i += 64) v += r.llpart[i];
+        v = wave_sum(v);
+        if (lane == 0) r.stats[r.VK] = v;
+    }
+    if ((phase & 2) && lane == 0) {
+        const int n = r.ctl->n_hist;
+        const double ll = r.stats[r.VK] / r.Nglobal;
+        r.ll_hist[n] = ll;
+        r.ctl->n_hist = n + 1;
+        if (n + 1 - r.conv_base > 10) {
+            const double prev = r.ll_hist[n - 1];
+            if (fabs(prev - ll) / fabs(ll) < r.tol) { r.ctl->stop = 1; r.ctl->stop_iter = r.t; }
+        }
+        r.ctl->t = r.t;           // the state of the stopping pass is kept (its ll is not lagged)
+    }
+}
+
 // topic state of the current pass from its reduced statistics (same arithmetic as the E-step prologue)
 template <int KP>
 __global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_finalize(int K, int V, double eta, const double* sums, double* gl,
@@ -678,6 +704,8 @@ struct mmm_lda {
     bool stats_valid = false;    // stats[t&1] are the M-step statistics of the current state
     bool attr_e[2] = {false, false}, attr_m = false;
     bool stop_seen = false;     // the device stop flag may be set
+    bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
+    bool phi_table_beta = false; // phi of the current state is exp(Elntheta) .* beta normalised (unsmoothed_update_ϕ!, LDA.jl:226)
     bool single_step = false;   // one step per wave: the grid covers every document
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
@@ -793,7 +821,7 @@ int sync_ctl(mmm_lda* m)
     if (stopped) m->stop_seen = true;
     m->t = h.t; m->n_hist = h.n_hist;
     m->inflight = false;
-    m->ll_pending = !stopped;          // after a stop the ll of the kept iteration is already recorded
+    m->ll_pending = m->lag_ll && !stopped;   // after a stop the ll of the kept iteration is already recorded
     return MMM_OK;
 }
 
@@ -806,7 +834,8 @@ int materialise_phi(mmm_lda* m)
     if (rc) return rc;
     if (m->phi_valid) return MMM_OK;
     const int c = m->cur(), p = (m->t + 2) % 3;
-    if ((rc = launch_phi(m, m->Elntheta[c].p, m->phi_from_prev ? m->expElnbeta[p].p : m->expElnbeta[c].p))) return rc;
+    const double* table = m->phi_from_prev ? (m->phi_table_beta ? m->beta[p].p : m->expElnbeta[p].p) : m->expElnbeta[c].p;
+    if ((rc = launch_phi(m, m->Elntheta[c].p, table))) return rc;
     m->phi_valid = true;
     return MMM_OK;
 }
@@ -894,9 +923,53 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         m->ll_pending = true;
     }
     if (n_iter > 0) {
-        m->inflight = true;
+        m->inflight = true; m->lag_ll = true; m->phi_table_beta = false;
         m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
         m->topics_pending = false; m->stats_valid = true;
+    }
+    return MMM_OK;
+}
+
+// n_iter frozen-topic passes: update_γ!, (unsmoothed_)update_ϕ!, update_θ!, ll (LDA.jl:241-247 / :274-279).  The topic state
+// must be replicated in the three ring slots (mmm_lda_infer does that once).
+int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_base)
+{
+    mmm_ctx* ctx = m->ctx;
+    int rc;
+    if ((rc = ensure_hist(m, n_iter))) return rc;
+    if (!m->gnext_valid) {
+        if ((rc = materialise_phi(m))) return rc;
+        hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
+        MMM_LAUNCH_CHECK(ctx);
+        m->gnext_valid = true;
+    }
+    const int VK = m->V * m->K;
+    const bool comm = mmm_comm_active(ctx);
+    for (int it = 0; it < n_iter; ++it) {
+        const int t = m->t + 1;
+        // theta_t = gamma_t / sum gamma_t feeds the ll of this pass: the "previous gamma" slot of the kernel is gamma_t itself
+        Ring g = m->ring(m->gamma);
+        g.s[(t + 2) % 3] = g.s[t % 3];
+        EstepArgs a{m->dev(), m->ctl.p, g, m->ring(m->Elntheta), unsmoothed ? m->ring(m->beta) : m->ring(m->expElnbeta), m->ring(m->beta),
+                    m->partial.p, m->llpart.p, 1, t, 0, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
+        { ProfSpan span(ctx); rc = launch_estep(m, a); }
+        if (rc) return rc;
+        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, 1, conv_base, 1};
+        if (!comm) hipLaunchKernelGGL(k_lda_infer_tail, dim3(1), dim3(64), 0, ctx->stream, r, 3);
+        else {
+            hipLaunchKernelGGL(k_lda_infer_tail, dim3(1), dim3(64), 0, ctx->stream, r, 1);
+            MMM_LAUNCH_CHECK(ctx);
+            if ((rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p + VK, 1))) return rc;
+            hipLaunchKernelGGL(k_lda_infer_tail, dim3(1), dim3(64), 0, ctx->stream, r, 2);
+        }
+        MMM_LAUNCH_CHECK(ctx);
+        m->n_hist++;
+        m->t = t;
+    }
+    if (n_iter > 0) {
+        m->inflight = true; m->lag_ll = false; m->ll_pending = false; m->phi_table_beta = unsmoothed != 0;
+        m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
+        m->topics_pending = false; m->stats_valid = false;
     }
     return MMM_OK;
 }
@@ -1260,6 +1333,46 @@ int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_ite
     *n_iter = n;
     if (ll_hist) memcpy(ll_hist, ll.data(), sizeof(double) * n);
     if (elbo) return mmm_lda_elbo(m, elbo, nullptr);
+    return MMM_OK;
+}
+
+int mmm_lda_infer(mmm_lda* m, int unsmoothed, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged)
+{
+    if (!m || !n_iter || !converged) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    MMM_CHECK(ctx, maxiter >= 1, "mmm_lda_infer: maxiter < 1");
+    int rc = prepare_call(m);
+    if (rc || (rc = flush_ll(m, nullptr))) return rc;
+    if (!m->gnext_valid && (rc = materialise_phi(m))) return rc;
+    hipLaunchKernelGGL(k_ctl_clear_stop, dim3(1), dim3(1), 0, ctx->stream, m->ctl.p);
+    MMM_LAUNCH_CHECK(ctx);
+    m->stop_seen = false;
+    // the topics do not change: every ring slot holds them, whichever slot a pass calls "current"
+    const int c = m->cur();
+    const size_t VKb = sizeof(double) * m->V * m->K;
+    for (int s = 0; s < 3; ++s) {
+        if (s == c) continue;
+        MMM_HIP(ctx, hipMemcpyAsync(m->lambda[s].p, m->lambda[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(m->Elnbeta[s].p, m->Elnbeta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(m->expElnbeta[s].p, m->expElnbeta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(m->beta[s].p, m->beta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    *converged = 0;
+    const int base = m->n_hist;
+    int done = 0;
+    bool stopped = false;
+    while (done < maxiter && !stopped) {
+        const int chunk = std::min(maxiter - done, done == 0 ? 12 : 8);
+        if ((rc = frozen_passes(m, chunk, unsmoothed, tol, base))) return rc;
+        if ((rc = sync_ctl(m))) return rc;
+        stopped = m->stop_seen;
+        done = m->n_hist - base;
+    }
+    if (stopped) *converged = 1;
+    const int n = m->n_hist - base;
+    *n_iter = n;
+    if (ll_hist && n > 0) MMM_HIP(ctx, hipMemcpyAsync(ll_hist, m->ll_hist.p + base, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
 }
 

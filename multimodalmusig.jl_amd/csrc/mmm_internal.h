@@ -88,15 +88,20 @@ struct DevBuf {
     void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
 
+// true when mmm_allreduce_sum really communicates.  A one-rank communicator is only exercised on request
+// (MMM_FORCE_RCCL=1: lets a single-GPU box run the RCCL path)
+inline bool mmm_comm_active(const mmm_ctx* ctx)
+{
+    if (!ctx->comm) return false;
+    if (ctx->nranks > 1) return true;
+    static const bool force = getenv("MMM_FORCE_RCCL") != nullptr;
+    return force;
+}
+
 // sum-all-reduce of a packed double buffer across the ranks of ctx (no-op for a single rank)
 inline int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
 {
-    if (!ctx->comm) return MMM_OK;
-    if (ctx->nranks <= 1) {
-        // a one-rank communicator is only exercised on request (MMM_FORCE_RCCL=1: lets a single-GPU box run the RCCL path)
-        static const bool force = getenv("MMM_FORCE_RCCL") != nullptr;
-        if (!force) return MMM_OK;
-    }
+    if (!mmm_comm_active(ctx)) return MMM_OK;
     MMM_NCCL(ctx, ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     return MMM_OK;
 }

@@ -475,6 +475,53 @@ int orc_lda_fit(int D, int V, int K, double alpha, double eta, const int64_t* do
     return 0;
 }
 
+/* unsmoothed_update_ϕ!  LDA.jl:226-231: phi[d] = exp.(Elntheta[:, d]) .* beta[X[d][:, 1], :]' normalised per term */
+void orc_lda_unsmoothed_update_phi(int K, int D, int V, const int64_t* doc_ptr, const int32_t* term,
+                                   const double* Elntheta, const double* beta, double* phi)
+{
+    for (int d = 0; d < D; ++d) {
+        double* ph = phi + (size_t)K * doc_ptr[d];
+        int64_t W = doc_ptr[d + 1] - doc_ptr[d];
+        for (int64_t w = 0; w < W; ++w) {
+            int v = term[doc_ptr[d] + w];
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) {
+                double e = exp(Elntheta[k + (size_t)K * d]) * beta[v + (size_t)V * k];
+                ph[k + (size_t)K * w] = e; s += e;
+            }
+            for (int k = 0; k < K; ++k) ph[k + (size_t)K * w] /= s;
+        }
+    }
+}
+
+/* The loops of transform (LDA.jl:233-263, unsmoothed = 1, uses beta) and fit_heldout (LDA.jl:265-295, unsmoothed = 0,
+ * uses Elnbeta) on a freshly constructed model (LDA.jl:41-49: gamma = 1, phi = 1/K) whose topics were copied in. */
+int orc_lda_infer(int D, int V, int K, double alpha, const int64_t* doc_ptr, const int32_t* term,
+                  const int32_t* count, int unsmoothed, int maxiter, double tol, const double* Elnbeta,
+                  const double* beta, double* gamma, double* Elntheta, double* theta, double* phi,
+                  double* ll_hist, int* n_iter, int* converged)
+{
+    int64_t nnz = doc_ptr[D];
+    for (size_t i = 0; i < (size_t)K * D; ++i) gamma[i] = 1.0;
+    orc_lda_update_Elntheta(K, D, gamma, Elntheta);
+    for (size_t i = 0; i < (size_t)K * nnz; ++i) phi[i] = 1.0 / K;
+    *converged = 0;
+    int it = 0;
+    for (int iter = 1; iter <= maxiter; ++iter) {
+        orc_lda_update_gamma(K, D, alpha, doc_ptr, count, phi, gamma, Elntheta);
+        if (unsmoothed) orc_lda_unsmoothed_update_phi(K, D, V, doc_ptr, term, Elntheta, beta, phi);
+        else orc_lda_update_phi(K, D, V, doc_ptr, term, Elntheta, Elnbeta, phi);
+        orc_lda_update_theta(K, D, gamma, theta);
+        ll_hist[it++] = orc_lda_loglik(K, D, V, doc_ptr, term, count, theta, beta);
+        if (it > 10) {
+            double rel = fabs(ll_hist[it - 2] - ll_hist[it - 1]) / fabs(ll_hist[it - 1]);
+            if (rel < tol) { *converged = 1; break; }
+        }
+    }
+    *n_iter = it;
+    return 0;
+}
+
 /* ============================================================================================== */
 /* MMCTM / IMMCTM                                                                                 */
 /* ============================================================================================== */
@@ -921,5 +968,55 @@ int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* l
     }
     *n_iter = it;
     if (elbo) *elbo = orc_ctm_elbo(m, NULL);
+    return 0;
+}
+
+/* unsmoothed_update_θ!  MMCTM.jl:496-509: theta[k, w] = exp(lambda[k]) * phi[m][k][v], normalised per term */
+void orc_ctm_unsmoothed_update_theta(orc_ctm* m, int d)
+{
+    const double* lam = m->lambda + (size_t)m->MK * d;
+    int offset = 0;
+    for (int mod = 0; mod < m->M; ++mod) {
+        const int64_t* dp = m->doc_ptr + (size_t)mod * (m->D + 1);
+        int Km = m->K[mod];
+        size_t go = ctm_goff(m, mod);
+        for (int64_t e = dp[d]; e < dp[d + 1]; ++e) {
+            int v = m->term[e];
+            double* th = ctm_theta(m, mod, e);
+            double s = 0.0;
+            for (int k = 0; k < Km; ++k) { th[k] = exp(lam[offset + k]) * m->phi[go + (size_t)k * m->V[mod] + v]; s += th[k]; }
+            for (int k = 0; k < Km; ++k) th[k] /= s;
+        }
+        offset += Km;
+    }
+}
+
+/* The loops of transform (MMCTM.jl:521-549; flags & 1: unsmoothed theta, flags & 2: fit_gaussian) and of fit_heldout /
+ * predict_modality_η (MMCTM.jl:565-583, :605-621; IMMCTM.jl:479-495, :516-532; flags = 0) on a constructor-initialised
+ * model whose globals were copied in by the caller.  props are refreshed every pass for MMCTM (transform and fit_heldout
+ * do; MMCTM's predict_modality_η reads them uninitialised -- the IMMCTM twin recomputes them, which is what is done here). */
+int orc_ctm_infer(orc_ctm* m, int flags, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged)
+{
+    *converged = 0; int it = 0;
+    for (int iter = 1; iter <= maxiter; ++iter) {
+        for (int d = 0; d < m->D; ++d) {
+            orc_ctm_update_zeta(m, d);
+            if (flags & 1) orc_ctm_unsmoothed_update_theta(m, d); else orc_ctm_update_theta(m, d);
+            orc_ctm_update_nu(m, d);
+            orc_ctm_update_lambda(m, d);
+        }
+        if (flags & 2) { orc_ctm_update_mu(m); orc_ctm_update_Sigma(m); }
+        if (!m->n_feat) orc_ctm_update_props(m);
+        orc_ctm_loglik(m, ll_hist + (size_t)m->M * it); ++it;
+        if (it > 10) {
+            double rel = 0.0;
+            for (int mod = 0; mod < m->M; ++mod) {
+                double a = ll_hist[(size_t)m->M * (it - 2) + mod], b = ll_hist[(size_t)m->M * (it - 1) + mod];
+                double r = fabs(a - b) / fabs(b); if (r > rel) rel = r;
+            }
+            if (rel < tol) { *converged = 1; break; }
+        }
+    }
+    *n_iter = it;
     return 0;
 }

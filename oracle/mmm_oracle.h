@@ -86,6 +86,15 @@ int orc_lda_fit(int D, int V, int K, double alpha, double eta, const int64_t* do
                 double* beta, double* phi, double* ll_hist, int* n_iter, int* converged,
                 double* elbo);
 
+/* frozen-topic inference: unsmoothed_update_ϕ! (LDA.jl:226-231) and the loops of transform (LDA.jl:233-263) /
+ * fit_heldout (LDA.jl:265-295) on constructor state with the trained topics (Elnbeta, beta) given */
+void orc_lda_unsmoothed_update_phi(int K, int D, int V, const int64_t* doc_ptr, const int32_t* term,
+                                   const double* Elntheta, const double* beta, double* phi);
+int orc_lda_infer(int D, int V, int K, double alpha, const int64_t* doc_ptr, const int32_t* term,
+                  const int32_t* count, int unsmoothed, int maxiter, double tol, const double* Elnbeta,
+                  const double* beta, double* gamma, double* Elntheta, double* theta, double* phi,
+                  double* ll_hist, int* n_iter, int* converged);
+
 /* ---- MMCTM / IMMCTM (src/MMCTM.jl, src/IMMCTM.jl) ------------------------------------------------ */
 typedef struct {
     int D, M, MK;
@@ -132,6 +141,13 @@ void orc_ctm_estep_range(orc_ctm* m, int d0, int d1);
 void orc_ctm_init(orc_ctm* m);
 int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
                 int* n_iter, int* converged, double* elbo);
+
+/* frozen-topic inference: unsmoothed_update_θ! (MMCTM.jl:496-509); loops of transform (flags & 1 unsmoothed theta,
+ * flags & 2 fit_gaussian; MMCTM.jl:511-552) and fit_heldout / predict_modality_η (flags 0; MMCTM.jl:554-634,
+ * IMMCTM.jl:468-545) */
+void orc_ctm_unsmoothed_update_theta(orc_ctm* m, int d);
+int orc_ctm_infer(orc_ctm* m, int flags, int maxiter, double tol, double* ll_hist /* M*maxiter */, int* n_iter,
+                  int* converged);
 
 /* dense helper: inverse + log|det| of a column-major n x n matrix by LU with partial pivoting */
 int orc_inv_logdet(int n, const double* A, double* Ainv, double* logabsdet, int* sign);

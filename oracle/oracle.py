@@ -80,6 +80,9 @@ def lib():
     L.orc_lda_fit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, i32p, i32p,
                               C.c_int, C.c_double, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p,
                               C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.orc_lda_unsmoothed_update_phi.argtypes = [C.c_int, C.c_int, C.c_int, i64p, i32p, f64p, f64p, f64p]
+    L.orc_lda_infer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, i64p, i32p, i32p, C.c_int, C.c_int, C.c_double,
+                                f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     P = C.POINTER(OrcCtm)
     for name in ("update_zeta", "update_theta", "update_nu", "update_lambda", "fitdoc"):
         getattr(L, "orc_ctm_" + name).argtypes = [P, C.c_int]
@@ -93,6 +96,8 @@ def lib():
     L.orc_ctm_estep_range.argtypes = [P, C.c_int, C.c_int]
     L.orc_ctm_fit.argtypes = [P, C.c_int, C.c_double, C.c_int, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_double)]
+    L.orc_ctm_unsmoothed_update_theta.argtypes = [P, C.c_int]
+    L.orc_ctm_infer.argtypes = [P, C.c_int, C.c_int, C.c_double, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _LIB = L
     return L
 
@@ -241,6 +246,32 @@ class LdaOracle:
         self.ll_hist = ll[:ni.value].copy()
         return self.ll_hist
 
+    # ---- frozen-topic inference (LDA.jl:226-295) ---------------------------------------------------------------------
+    def unsmoothed_update_phi(self):
+        lib().orc_lda_unsmoothed_update_phi(self.K, self.D, self.V, self.doc_ptr, self.term, self.Elntheta, self.beta, self.phi)
+
+    def _infer(self, unsmoothed, maxiter, tol):
+        ll = np.zeros(maxiter); ni = C.c_int(); cv = C.c_int()
+        lib().orc_lda_infer(self.D, self.V, self.K, self.alpha, self.doc_ptr, self.term, self.count, int(unsmoothed), maxiter, tol,
+                            self.Elnbeta, self.beta, self.gamma, self.Elntheta, self.theta, self.phi, ll, C.byref(ni), C.byref(cv))
+        self.converged = bool(cv.value); self.ll_hist = ll[:ni.value].copy()
+        return self.ll_hist
+
+    def transform(self, X, maxiter=1000, tol=1e-4):
+        """transform(model::LDA, X) LDA.jl:233-263 -> (theta [K x D_new] column-major flat, new oracle model)."""
+        new = LdaOracle(self.K, self.alpha, self.eta, X, V=self.V, seed=1)
+        new.beta[:] = self.beta                                        # :237
+        new._infer(True, maxiter, tol)
+        return new.theta, new
+
+    def fit_heldout(self, X, maxiter=100):
+        """fit_heldout(Xheldout, model::LDA) LDA.jl:265-295."""
+        new = LdaOracle(self.K, self.alpha, self.eta, X, V=self.V, seed=1)
+        new.lam[:] = self.lam; new.beta[:] = self.beta; new.Elnbeta[:] = self.Elnbeta          # :269-271
+        new._infer(False, maxiter, 1e-4)
+        new.elbo_value = new.elbo()[0]; new.ll = new.ll_hist[-1]
+        return new
+
     def phi_doc(self, d):
         W = self.doc_ptr[d + 1] - self.doc_ptr[d]
         return self.phi[self.K * self.doc_ptr[d]:self.K * self.doc_ptr[d + 1]].reshape(W, self.K).T  # K x W
@@ -351,6 +382,16 @@ class CtmOracle:
         ll = np.zeros(self.M * maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
         lib().orc_ctm_fit(C.byref(self.s), maxiter, tol, int(update_sigma), ll, C.byref(ni), C.byref(cv), C.byref(el))
         self.converged = bool(cv.value); self.elbo_value = el.value
+        self.ll_hist = ll[:self.M * ni.value].reshape(ni.value, self.M).copy()
+        return self.ll_hist
+
+    # ---- frozen-topic inference (MMCTM.jl:496-634, IMMCTM.jl:468-545) ---------------------------------------------------
+    def unsmoothed_update_theta(self, d): lib().orc_ctm_unsmoothed_update_theta(C.byref(self.s), d)
+
+    def infer(self, flags, maxiter, tol):
+        ll = np.zeros(self.M * maxiter); ni = C.c_int(); cv = C.c_int()
+        lib().orc_ctm_infer(C.byref(self.s), int(flags), maxiter, tol, ll, C.byref(ni), C.byref(cv))
+        self.converged = bool(cv.value)
         self.ll_hist = ll[:self.M * ni.value].reshape(ni.value, self.M).copy()
         return self.ll_hist
 
