@@ -145,3 +145,65 @@ def test_mmctm_fit_runs_and_xtol_rules_agree_loosely(oracle):
     assert la.shape[1] == 2 and len(la) >= 11 and np.all(np.isfinite(la))
     np.testing.assert_allclose(la[-1], lb[-1], rtol=2e-3)   # the two NLopt stopping rules differ only at the 1e-4 level
     assert np.isfinite(a.elbo_value)
+
+
+# ---- frozen-topic inference restatements (LDA.jl:226-295, MMCTM.jl:496-552) against plain numpy ----------------------
+def test_lda_unsmoothed_phi_and_transform_loop(oracle):
+    X, lam0 = np_ref.synth_lda(30, 20, 4, seed=8, mean_n=300)
+    K, V = 4, 20
+    m = oracle.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
+    m.fit(maxiter=5, tol=0.0)
+    Xn, _ = np_ref.synth_lda(12, V, K, seed=80, mean_n=200)
+    theta, new = m.transform(Xn, maxiter=15, tol=0.0)
+    beta = m.beta.reshape(V, K, order="F")
+    # numpy replay of LDA.jl:241-247
+    from scipy.special import digamma
+    gamma = np.ones((K, len(Xn))); phi = [np.full((K, x.shape[0]), 1.0 / K) for x in Xn]
+    lls = []
+    for _ in range(15):
+        for d, x in enumerate(Xn):
+            gamma[:, d] = 0.1 + phi[d] @ x[:, 1]                                  # update_γ! LDA.jl:82-90
+        Eln = digamma(gamma) - digamma(gamma.sum(axis=0))
+        for d, x in enumerate(Xn):
+            p = np.exp(Eln[:, d])[:, None] * beta[x[:, 0] - 1, :].T               # unsmoothed_update_ϕ! LDA.jl:226-231
+            phi[d] = p / p.sum(axis=0)
+        th = gamma / gamma.sum(axis=0)
+        num = sum(float(x[:, 1] @ np.log(beta[x[:, 0] - 1, :] @ th[:, d])) for d, x in enumerate(Xn))
+        lls.append(num / sum(int(x[:, 1].sum()) for x in Xn))
+    np.testing.assert_allclose(theta.reshape(len(Xn), K).T, th, rtol=1e-11)
+    np.testing.assert_allclose(new.ll_hist, lls, rtol=1e-11)
+    for d in range(len(Xn)):
+        np.testing.assert_allclose(new.phi_doc(d), phi[d], rtol=1e-10, atol=1e-300)
+    # fit_heldout differs only in the smoothed phi (LDA.jl:274-276)
+    h = m.fit_heldout(Xn, maxiter=15)
+    assert len(h.ll_hist) >= 11 and np.isfinite(h.elbo_value)
+    assert not np.allclose(h.theta, theta)
+
+
+def test_mmctm_unsmoothed_theta_and_transform_flags(oracle):
+    _, _, _, X, _, m = _mm_setup(oracle)
+    m.fit(maxiter=2, tol=0.0)
+    K = [int(k) for k in m.K]
+    new = oracle.CtmOracle(K, m.alpha, X, V=[int(v) for v in m.V], seed=9)
+    new.phi[:] = m.phi
+    rng = np.random.default_rng(0)
+    new.lam[:] = rng.standard_normal(new.lam.size)
+    for d in range(new.D):
+        new.unsmoothed_update_theta(d)
+    off = 0
+    for mod in range(new.M):
+        ph = m.phi[m.goff[mod]:m.goff[mod + 1]].reshape(K[mod], -1)
+        for d in (0, 3, new.D - 1):
+            x = X[d][mod]
+            if x.shape[0] == 0:
+                continue
+            t = np.exp(new.lam[new.MK * d + off:new.MK * d + off + K[mod]])[:, None] * ph[:, x[:, 0] - 1]     # MMCTM.jl:496-509
+            np.testing.assert_allclose(new.theta_dm(d, mod), t / t.sum(axis=0), rtol=1e-12)
+        off += K[mod]
+    # transform without fit_gaussian leaves Sigma alone, with it refits it (test/mmctm.jl:390-406)
+    a = oracle.CtmOracle(K, m.alpha, X, V=[int(v) for v in m.V], seed=9); a.phi[:] = m.phi; a.mu[:] = m.mu; a.Sigma[:] = m.Sigma
+    a.infer(1, 2, 1e4)
+    np.testing.assert_array_equal(a.Sigma, m.Sigma)
+    b = oracle.CtmOracle(K, m.alpha, X, V=[int(v) for v in m.V], seed=9); b.phi[:] = m.phi
+    ll = b.infer(3, 12, 1e4)
+    assert ll.shape == (11, new.M) and b.converged and not np.allclose(b.Sigma, m.Sigma)
