@@ -153,6 +153,7 @@ int mmm_ctm_update_mu(mmm_ctm* m);      /* update_μ!                    MMCTM.j
 int mmm_ctm_update_Sigma(mmm_ctm* m);   /* update_Σ!                    MMCTM.jl:204-212              */
 int mmm_ctm_update_gamma(mmm_ctm* m);   /* update_γ! (+ update_Elnϕ!)   MMCTM.jl:224-242,214-222      */
 int mmm_ctm_update_Elnphi(mmm_ctm* m);  /* update_Elnϕ!                 MMCTM.jl:214-222 / IMMCTM.jl:188-197 */
+int mmm_ctm_update_alpha(mmm_ctm* m);   /* update_α! (1-D LD_MMA per α) MMCTM.jl:252-269, IMMCTM.jl:225-244 */
 int mmm_ctm_update_props(mmm_ctm* m);   /* update_props!                MMCTM.jl:145-154              */
 int mmm_ctm_update_phi(mmm_ctm* m);     /* update_ϕ!                    MMCTM.jl:244-250              */
 int mmm_ctm_loglik(mmm_ctm* m, double* ll /* M */);                /* calculate_loglikelihoods MMCTM.jl:384-448 */
@@ -165,9 +166,12 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
 int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped,
                          int* per_doc_nu, int* per_doc_lambda);
 /* Fused hot path: n_iter passes of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) */
-int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int update_sigma);
+/* fit_flags: keyword arguments of fit! (MMCTM.jl:457-458): MMM_FIT_UPDATE_SIGMA = updateΣ (IMMCTM always updates Σ,
+ * IMMCTM.jl:445), MMM_FIT_AUTO_ALPHA = autoα (update_α! after update_γ!, MMCTM.jl:472-474) */
+enum { MMM_FIT_UPDATE_SIGMA = 1, MMM_FIT_AUTO_ALPHA = 2 };
+int mmm_ctm_iterate(mmm_ctm* m, int n_iter, int fit_flags);
 int mmm_ctm_ll_history(mmm_ctm* m, double* ll /* M*max_n */, int max_n, int* n);
-int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
+int mmm_ctm_fit(mmm_ctm* m, int maxiter, double tol, int fit_flags, double* ll_hist /* M*maxiter */,
                 int* n_iter, int* converged, double* elbo);
 
 /* Frozen-topic inference on a model whose globals were uploaded with mmm_ctm_set.  Every pass runs the document loop
@@ -196,7 +200,7 @@ int mmm_ctm_select(mmm_ctm* m, int r);
 /* fit! of every replica, in lock step; a replica stops when its own stopping rule fires (common.jl:48-51).
  * ll_hist: [R][maxiter][M]; n_iter, converged: [R]; elbo: [R] or NULL.  All replicas must have the same number
  * of earlier passes. */
-int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter,
+int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int fit_flags, double* ll_hist, int* n_iter,
                       int* converged, double* elbo);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ from . import _lib
 from ._lib import Context, MmmError, build, comm_unique_id, default_context, lib
 from .models import (LDA, calculate_elbo, calculate_loglikelihood, fit, fit_bang, update_β, update_γ, update_θ,
                      update_λ, update_ϕ)
-from .ctm import (IMMCTM, MMCTM, calculate_loglikelihoods, fit_restarts, fitdoc, pick_optimal_modality_models, update_Elnϕ, update_props, update_Σ, update_ζ, update_μ,
+from .ctm import (IMMCTM, MMCTM, calculate_loglikelihoods, fit_restarts, fitdoc, pick_optimal_modality_models, update_Elnϕ, update_props, update_α, update_Σ, update_ζ, update_μ,
                   update_ν)
 from .inference import fit_heldout, predict_modality_η, transform
 from .utils import (format_counts_ctm, format_counts_lda, format_counts_mmctm, make_count_matrix, pack_lda,

@@ -81,6 +81,7 @@ _SIGS = {
     "mmm_ctm_update_gamma": (C.c_int, [vp]),
     "mmm_ctm_update_Elnphi": (C.c_int, [vp]),
     "mmm_ctm_update_props": (C.c_int, [vp]),
+    "mmm_ctm_update_alpha": (C.c_int, [vp]),
     "mmm_ctm_update_phi": (C.c_int, [vp]),
     "mmm_ctm_loglik": (C.c_int, [vp, f64p]),
     "mmm_ctm_elbo": (C.c_int, [vp, C.POINTER(C.c_double), vp]),

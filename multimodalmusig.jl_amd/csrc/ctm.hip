@@ -475,6 +475,7 @@ struct MstepArgs {
     int* status;            // 0 ok, 1 singular Sigma
     int do_mu, do_sigma, do_gamma, gamma_from_stats;
     size_t stats_stride; int GM; const int* active;      // batched launches
+    int nalpha;
 };
 
 __device__ __forceinline__ bool mstep_replica(MstepArgs& a)
@@ -485,6 +486,7 @@ __device__ __forceinline__ bool mstep_replica(MstepArgs& a)
     a.stats += r * a.stats_stride; a.mu += r * MK; a.Sigma += r * MK * MK; a.invSigma += r * MK * MK;
     a.gamma += r * GM; a.Elnphi += r * GM; if (a.phi) a.phi += r * GM;
     a.Eeff += r * GT; a.expEeff += r * GT; a.phieff += r * GT; a.status += r;
+    a.tp.alpha += r * a.nalpha;
     return true;
 }
 
@@ -630,6 +632,76 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             a.Eeff[go + k * Vm + v] = se; a.expEeff[go + k * Vm + v] = exp(se); a.phieff[go + k * Vm + v] = pp;
         }
     }
+}
+
+// update_α! (MMCTM.jl:252-269 / IMMCTM.jl:225-244): one block per Dirichlet parameter α[m] (MMCTM) / α[m][i] (IMMCTM);
+// the block sums Elnϕ over the K_m topics and the V_m (J_mi) values, lane 0 runs the 1-D LD_MMA maximisation of
+// α_objective (common.jl:38-46) from the current α with lower bound 1e-7 and xtol_rel = xtol_abs = 1e-5.
+__global__ __launch_bounds__(64) void k_ctm_update_alpha(CtmDims dm, CtmTopics tp, const double* Elnphi, double* alpha, int GM, int nalpha,
+                                                         int xtol_rule, int max_eval, const int* active)
+{
+    if (active && !active[blockIdx.y]) return;
+    Elnphi += (size_t)blockIdx.y * GM; alpha += (size_t)blockIdx.y * nalpha;
+    const int lane = threadIdx.x, a = blockIdx.x;
+    int m = 0, i = 0, Km, n, stride, base;
+    if (!tp.immctm) { m = a; Km = dm.K[m]; n = dm.V[m]; stride = n; base = dm.goff[m]; }
+    else {
+        while (a >= tp.aoff[m + 1]) ++m;
+        i = a - tp.aoff[m];
+        int jo = 0;
+        for (int q = 0; q < i; ++q) jo += tp.J[tp.aoff[m] + q];
+        Km = dm.K[m]; n = tp.J[a]; stride = tp.SJ[m]; base = tp.mgoff[m] + jo;
+    }
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) { double c = 0.0; for (int k = 0; k < Km; ++k) c += Elnphi[base + k * stride + j]; s += c; }
+    s = wave_sum(s);
+    if (lane != 0) return;
+    const double K = Km, V = n, lb = 1e-7, xtol = 1e-5;
+    // minimise f = -α_objective; m = 0 constraints, one coordinate, sigma = 1 (infinite upper bound)
+    auto eval = [&](double x, double& g) {
+        g = -(K * V * (dev_digamma(V * x) - dev_digamma(x)) + s);
+        return -(K * (lgamma(V * x) - V * lgamma(x)) + x * s);
+    };
+    double x = alpha[a], sigma = 1.0, rho = 1.0, dfdx, dfdx_cur, xcur = x, xprev = x, xprevprev = x;
+    double fbest = eval(x, dfdx), fcur = fbest;
+    int nev = 1, k = 0;
+    bool capped = false;
+    for (;;) {
+        if (nev >= max_eval) break;
+        if (++k > 1) xprevprev = xprev;
+        xprev = xcur;
+        for (;;) {
+            const double g = dfdx, sigma2 = sigma * sigma, u = g * sigma2, v = fabs(g) * sigma + 0.5 * rho;
+            const double q = u / (v * sigma);
+            double dx = (u / v) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+            double xc = x + dx;
+            if (xc < lb) xc = lb;
+            if (xc > x + 0.9 * sigma) xc = x + 0.9 * sigma; else if (xc < x - 0.9 * sigma) xc = x - 0.9 * sigma;
+            xcur = xc;
+            dx = xc - x;
+            const double dx2 = dx * dx, denominv = 1.0 / (sigma2 - dx2);
+            const double gval = fbest + (g * (sigma2 * dx) + (fabs(g) * sigma + 0.5 * rho) * dx2) * denominv;
+            const double wval = 0.5 * dx2 * denominv;
+            fcur = eval(xcur, dfdx_cur); ++nev;
+            const bool inner_done = gval >= fcur;
+            if (fcur < fbest) { fbest = fcur; x = xcur; dfdx = dfdx_cur; }
+            if (nev >= max_eval) { capped = true; break; }
+            if (inner_done) break;
+            if (fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + (fcur - gval) / wval));
+        }
+        if (capped) break;
+        const double ad = fabs(xcur - xprev);
+        bool stop;
+        if (xtol_rule == 0) stop = (ad < xtol * fabs(xcur)) || (ad < xtol);
+        else stop = ad < xtol || ad < xtol * (fabs(xcur) + fabs(xprev)) * 0.5 || xcur == xprev;
+        if (stop) break;
+        rho = fmax(0.1 * rho, 1e-5);
+        if (k > 1) {
+            const double d2 = (xcur - xprev) * (xprev - xprevprev);
+            sigma *= d2 < 0 ? 0.7 : (d2 > 0 ? 1.2 : 1.0);
+        }
+    }
+    alpha[a] = x;
 }
 
 // effective tables from UPLOADED topic fields (fit_heldout copies γ and Elnϕ, MMCTM.jl:561-562), one block per topic:
@@ -904,7 +976,7 @@ struct mmm_ctm {
     int theta_rep = -1;                       // replica whose theta is in the theta buffer (-1: none)
     int cap_hist = 0;
     int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1, grid_v = 1, waves_s = 4;
-    int nmom = 0; size_t s_stats = 0, s_llnum = 0;
+    int nmom = 0, nalpha = 0; size_t s_stats = 0, s_llnum = 0;
     std::vector<double> hNm;
     CtmDev dev() const { return CtmDev{dm, doc_ptr.p, tc.p, Ndm.p}; }
     size_t sDMK() const { return (size_t)dm.D * dm.MK; }
@@ -986,7 +1058,8 @@ int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int g
     const size_t r0 = sc.rep0, MK = m->dm.MK, GT = m->dm.GT, GM = m->GM;
     MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
                 m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
-                m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active};
+                m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha};
+    a.tp.alpha += r0 * m->nalpha;
     const size_t lds = sizeof(double) * 2 * MK * MK;
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1098,8 +1171,18 @@ int copy_rep(mmm_ctm* m, Scope sc, double* dst, const double* src, size_t n)
 
 // one pass of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) for every replica of the scope.  All replicas of the
 // scope must have the same history length (they do: a batched fit advances its active replicas in lock step).
-int fused_pass(mmm_ctm* m, Scope sc, int update_sigma)
+int run_update_alpha(mmm_ctm* m, Scope sc)
 {
+    hipLaunchKernelGGL(k_ctm_update_alpha, dim3(m->nalpha, sc.nrep), dim3(64), 0, m->ctx->stream, m->dm, m->tp, m->Elnphi.p + (size_t)sc.rep0 * m->GM,
+                       m->alpha.p + (size_t)sc.rep0 * m->nalpha, m->GM, m->nalpha, m->opt.xtol_rule, m->opt.max_eval, sc.active);
+    MMM_LAUNCH_CHECK(m->ctx);
+    return MMM_OK;
+}
+
+// fit_flags: MMM_FIT_UPDATE_SIGMA | MMM_FIT_AUTO_ALPHA (updateΣ / autoα of fit!, MMCTM.jl:457-458)
+int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
+{
+    const int update_sigma = fit_flags & MMM_FIT_UPDATE_SIGMA;
     mmm_ctx* ctx = m->ctx;
     const CtmDims& dm = m->dm;
     int rc;
@@ -1119,6 +1202,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int update_sigma)
     if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
     // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!
     if ((rc = run_mstep(m, sc, 1, (update_sigma || m->immctm) ? 1 : 0, 1, 1))) return rc;
+    if ((fit_flags & MMM_FIT_AUTO_ALPHA) && (rc = run_update_alpha(m, sc))) return rc;      // MMCTM.jl:472-474
     // update_props! and the log-likelihoods
     if ((rc = ensure_hist(m, 1))) return rc;
     const int M = dm.M;
@@ -1276,12 +1360,12 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     m->grid_m = std::max(1, std::min((D + 127) / 128, 512));
     const size_t MK = dm.MK, DMK = (size_t)D * MK, Rz = (size_t)R;
-    m->nmom = 2 * dm.MK + dm.MK * dm.MK;
+    m->nmom = 2 * dm.MK + dm.MK * dm.MK; m->nalpha = nalpha;
     m->s_stats = (size_t)m->nmom + dm.GT + 16;
     m->s_llnum = (size_t)M + 8;
     m->h_active.assign(R, 1); m->n_hist.assign(R, 0); m->theta_state.assign(R, 0); m->theta_spill.resize(R);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
-    A(doc_ptr, (size_t)M * (D + 1)); A(tc, (size_t)nnz); A(Ndm, (size_t)D * M); A(features, featv.size()); A(alpha, (size_t)nalpha);
+    A(doc_ptr, (size_t)M * (D + 1)); A(tc, (size_t)nnz); A(Ndm, (size_t)D * M); A(features, featv.size()); A(alpha, Rz * nalpha);
     A(lambda, Rz * DMK); A(lambda_prev, Rz * DMK); A(nu, Rz * DMK); A(sumth, Rz * DMK); A(zeta, Rz * D * M); A(props, Rz * DMK); A(theta, (size_t)toff);
     A(mu, Rz * MK); A(Sigma, Rz * MK * MK); A(invSigma, Rz * MK * MK); A(gamma, Rz * GM); A(Elnphi, Rz * GM); A(phi, Rz * GM);
     A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
@@ -1294,7 +1378,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
     if (D) MMM_HIP(ctx, hipMemcpyAsync(m->Ndm.p, Ndm.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
     if (!featv.empty()) MMM_HIP(ctx, hipMemcpyAsync(m->features.p, featv.data(), sizeof(int) * featv.size(), hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->alpha.p, alpha, sizeof(double) * nalpha, hipMemcpyHostToDevice, st));
+    for (size_t r = 0; r < Rz; ++r) MMM_HIP(ctx, hipMemcpyAsync(m->alpha.p + r * nalpha, alpha, sizeof(double) * nalpha, hipMemcpyHostToDevice, st));
     MMM_HIP(ctx, hipMemcpyAsync(m->gamma.p, gamma0, sizeof(double) * Rz * GM, hipMemcpyHostToDevice, st));
     MMM_HIP(ctx, hipMemsetAsync(m->status.p, 0, sizeof(int) * R, st));
     MMM_HIP(ctx, hipMemsetAsync(m->nev_nu.p, 0, sizeof(int) * std::max<size_t>(Rz * D, 1), st));
@@ -1393,7 +1477,7 @@ static int ctm_field(mmm_ctm* m, int field, double** p, size_t* n)
         case MMM_CTM_ZETA: *p = m->zeta.p + r * D * m->dm.M; *n = D * m->dm.M; break;
         case MMM_CTM_PROPS: *p = m->props.p + r * D * MK; *n = D * MK; break;
         case MMM_CTM_THETA: *p = m->theta.p; *n = (size_t)m->theta_n; break;
-        case MMM_CTM_ALPHA: *p = m->alpha.p; *n = m->immctm ? m->tp.aoff[m->dm.M] : m->dm.M; break;
+        case MMM_CTM_ALPHA: *p = m->alpha.p + r * m->nalpha; *n = (size_t)m->nalpha; break;
         default: return mmm_fail(m->ctx, MMM_ERR_ARG, "unknown CTM field %d", field);
     }
     return MMM_OK;
@@ -1541,6 +1625,14 @@ int mmm_ctm_update_Elnphi(mmm_ctm* m)
     return run_mstep(m, one(m), 0, 0, 1, 0);
 }
 
+int mmm_ctm_update_alpha(mmm_ctm* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prep(m);
+    if (rc) return rc;
+    return run_update_alpha(m, one(m));
+}
+
 int mmm_ctm_update_props(mmm_ctm* m)
 {
     if (!m) return MMM_ERR_ARG;
@@ -1653,7 +1745,9 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     hipLaunchKernelGGL(k_sum_columns, dim3(5, 1), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc, (size_t)0, (const int*)nullptr);
     const size_t lds2 = sizeof(double) * 2 * MKz * MKz;
     if (lds2 > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_topics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, m->tp, m->gamma.p + r * m->GM, m->Elnphi.p + r * m->GM,
+    CtmTopics tpr = m->tp;
+    tpr.alpha += r * m->nalpha;
+    hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, tpr, m->gamma.p + r * m->GM, m->Elnphi.p + r * m->GM,
                        m->invSigma.p + r * MKz * MKz, acc + 5);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;

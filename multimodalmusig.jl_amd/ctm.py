@@ -105,7 +105,17 @@ class _CTM:
         """Make restart `r` the model the fields and the per-model functions act on."""
         check(lib().mmm_ctm_select(self._h, int(r)), self.ctx.h, "select")
         self._sel = int(r)
+        self._refresh_alpha()
         return self
+
+    def _refresh_alpha(self):
+        """model.α mirrors the device value of the selected restart (it changes under update_α! / autoα)."""
+        a = self._get("alpha")
+        if self._immctm:
+            off = np.concatenate([[0], np.cumsum(self.I)])
+            self.α = [a[off[m]:off[m + 1]].copy() for m in range(self.M)]
+        else:
+            self.α = a.copy()
 
     @property
     def selected(self):
@@ -362,6 +372,11 @@ def update_Elnϕ(model):           # MMCTM.jl:214-222 / IMMCTM.jl:188-197
     _call(model, "mmm_ctm_update_Elnphi", "update_Elnϕ!")
 
 
+def update_α(model):              # MMCTM.jl:252-269 / IMMCTM.jl:225-244
+    _call(model, "mmm_ctm_update_alpha", "update_α!")
+    model._refresh_alpha()
+
+
 def update_props(model):          # MMCTM.jl:145-154
     _call(model, "mmm_ctm_update_props", "update_props!")
 
@@ -380,22 +395,26 @@ def calculate_loglikelihoods(model):   # MMCTM.jl:446-448 / IMMCTM.jl:408-428
     return out
 
 
+def _fit_flags(autoα, updateΣ):
+    return (1 if updateΣ else 0) | (2 if autoα else 0)      # MMM_FIT_UPDATE_SIGMA | MMM_FIT_AUTO_ALPHA
+
+
 def _fit_ctm(model, maxiter, tol, verbose, autoα=False, updateΣ=True):
-    if autoα:
-        raise NotImplementedError("autoα (update_α!, MMCTM.jl:252-269) is outside the hot-path scope (SURVEY.md §2a)")
     maxiter = 100 if maxiter is None else int(maxiter)
     ll = np.zeros(maxiter * model.M); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
-    check(lib().mmm_ctm_fit(model._h, maxiter, float(tol), 1 if updateΣ else 0, ll.ctypes.data, C.byref(ni), C.byref(cv), C.byref(el)),
+    check(lib().mmm_ctm_fit(model._h, maxiter, float(tol), _fit_flags(autoα, updateΣ), ll.ctypes.data, C.byref(ni), C.byref(cv), C.byref(el)),
           model.ctx.h, "fit!(::%s)" % type(model).__name__)
     hist = ll[:ni.value * model.M].reshape(ni.value, model.M).copy()
     if verbose:
         for i, v in enumerate(hist):
             print("%d\tLog-likelihoods: %s" % (i + 1, ", ".join(repr(float(x)) for x in v)))
     model.converged = bool(cv.value); model.elbo = el.value; model.ll = hist[-1].copy()
+    if autoα:
+        model._refresh_alpha()
     return hist
 
 
-def fit_restarts(model, maxiter=100, tol=1e-4, verbose=False, updateΣ=True):
+def fit_restarts(model, maxiter=100, tol=1e-4, verbose=False, updateΣ=True, autoα=False):
     """`fit!` of every restart of a batch model (constructed with `restarts=R` or R stacked γ0), all restarts advancing
     together on the GPU -- what `fit_seed_models` (scripts/run_mmctm.jl:97-109) gets from `pmap(fit_restart, seeds)`.
     Returns the list of per-restart ll histories ([n_iter_r, M] each); per-restart results are kept on the model as
@@ -403,7 +422,7 @@ def fit_restarts(model, maxiter=100, tol=1e-4, verbose=False, updateΣ=True):
     R, M = model.R, model.M
     maxiter = int(maxiter)
     ll = np.zeros(R * maxiter * M); ni = np.zeros(R, dtype=np.int32); cv = np.zeros(R, dtype=np.int32); el = np.zeros(R)
-    check(lib().mmm_ctm_fit_batch(model._h, maxiter, float(tol), 1 if updateΣ else 0, ll.ctypes.data, ni.ctypes.data, cv.ctypes.data, el.ctypes.data),
+    check(lib().mmm_ctm_fit_batch(model._h, maxiter, float(tol), _fit_flags(autoα, updateΣ), ll.ctypes.data, ni.ctypes.data, cv.ctypes.data, el.ctypes.data),
           model.ctx.h, "fit_restarts(::%s)" % type(model).__name__)
     ll = ll.reshape(R, maxiter, M)
     hists = [ll[r, :ni[r]].copy() for r in range(R)]
@@ -412,6 +431,8 @@ def fit_restarts(model, maxiter=100, tol=1e-4, verbose=False, updateΣ=True):
     if verbose:
         for r in range(R):
             print("restart %d	%d iterations	Log-likelihoods: %s" % (r, ni[r], ", ".join(repr(float(x)) for x in hists[r][-1])))
+    if autoα:
+        model._refresh_alpha()
     s = model.selected
     model.converged = bool(cv[s]); model.elbo = float(el[s]); model.ll = hists[s][-1].copy()
     return hists

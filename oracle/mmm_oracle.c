@@ -929,6 +929,52 @@ double orc_ctm_elbo(const orc_ctm* m, double* terms)
     return t[0] + t[1] + t[2] + t[3] - t[4] - t[5] - t[6];
 }
 
+/* α_objective  common.jl:38-46 (value returned, gradient written when grad != NULL; the objective is MAXIMISED) */
+double orc_alpha_objective(double alpha, double* grad, double sum_Elnphi, int K, int V)
+{
+    if (grad) *grad = (double)K * V * (orc_digamma(V * alpha) - orc_digamma(alpha)) + sum_Elnphi;
+    return K * (orc_lgamma(V * alpha) - V * orc_lgamma(alpha)) + alpha * sum_Elnphi;
+}
+
+typedef struct { double s; int K, V; } alpha_ctx;
+static double cb_alpha(int n, const double* x, double* grad, void* p)
+{
+    const alpha_ctx* c = (const alpha_ctx*)p; double g;
+    double v = orc_alpha_objective(x[0], &g, c->s, c->K, c->V);
+    if (grad) grad[0] = -g;
+    return -v;
+}
+
+/* update_α!  MMCTM.jl:252-269 / IMMCTM.jl:225-244: 1-D LD_MMA, lower bound 1e-7, xtol_rel = xtol_abs = 1e-5, start = alpha */
+void orc_ctm_update_alpha(orc_ctm* m)
+{
+    const double lb = 1e-7;
+    for (int mod = 0; mod < m->M; ++mod) {
+        size_t go = ctm_goff(m, mod); int Km = m->K[mod];
+        if (!m->n_feat) {
+            int V = m->V[mod];
+            /* sum(sum(Elnϕ[m][k] for k in 1:K)): the K vectors are added elementwise, then summed over v */
+            double s = 0.0;
+            for (int v = 0; v < V; ++v) { double c = 0.0; for (int k = 0; k < Km; ++k) c += m->Elnphi[go + (size_t)k * V + v]; s += c; }
+            alpha_ctx c = { s, Km, V };
+            double x = m->alpha[mod];
+            orc_mma_minimize(1, cb_alpha, &c, &lb, NULL, &x, NULL, 1e-5, 1e-5, m->xtol_rule, m->max_eval, NULL);
+            m->alpha[mod] = x;
+        } else {
+            int SJ = ctm_SJ(m, mod), ao = ctm_aoff(m, mod), jo = 0;
+            for (int i = 0; i < m->n_feat[mod]; ++i) {
+                int Ji = m->J[ao + i]; double s = 0.0;
+                for (int j = 0; j < Ji; ++j) { double c = 0.0; for (int k = 0; k < Km; ++k) c += m->Elnphi[go + (size_t)k * SJ + jo + j]; s += c; }
+                alpha_ctx c = { s, Km, Ji };
+                double x = m->alpha[ao + i];
+                orc_mma_minimize(1, cb_alpha, &c, &lb, NULL, &x, NULL, 1e-5, 1e-5, m->xtol_rule, m->max_eval, NULL);
+                m->alpha[ao + i] = x;
+                jo += Ji;
+            }
+        }
+    }
+}
+
 /* constructor state: MMCTM.jl:44-86 / IMMCTM.jl:47-73 (gamma must already hold the random init) */
 void orc_ctm_init(orc_ctm* m)
 {
@@ -946,7 +992,7 @@ void orc_ctm_init(orc_ctm* m)
 }
 
 /* MMCTM.jl:457-494 / IMMCTM.jl:437-466 */
-int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist, int* n_iter,
+int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, int auto_alpha, double* ll_hist, int* n_iter,
                 int* converged, double* elbo)
 {
     *converged = 0; int it = 0;
@@ -955,6 +1001,7 @@ int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* l
         orc_ctm_update_mu(m);
         if (update_sigma || m->n_feat) orc_ctm_update_Sigma(m);
         orc_ctm_update_gamma(m);
+        if (auto_alpha) orc_ctm_update_alpha(m);                 /* MMCTM.jl:472-474 / IMMCTM.jl:448-450 */
         if (!m->n_feat) { orc_ctm_update_props(m); orc_ctm_update_phi(m); }
         orc_ctm_loglik(m, ll_hist + (size_t)m->M * it); ++it;
         if (it > 10) { /* common.jl:48-51 */

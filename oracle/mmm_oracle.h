@@ -139,7 +139,9 @@ void orc_ctm_estep_range(orc_ctm* m, int d0, int d1);
 /* fit!: MMCTM.jl:457-494 / IMMCTM.jl:437-466. State must be constructor-initialised by the caller
  * via orc_ctm_init (lambda=0, nu=1, mu=0, Sigma=I, theta=1/K, Elnphi from gamma, zeta). */
 void orc_ctm_init(orc_ctm* m);
-int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, double* ll_hist /* M*maxiter */,
+double orc_alpha_objective(double alpha, double* grad, double sum_Elnphi, int K, int V);   /* common.jl:38-46 */
+void orc_ctm_update_alpha(orc_ctm* m);                     /* update_α!  MMCTM.jl:252-269 / IMMCTM.jl:225-244 */
+int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, int auto_alpha, double* ll_hist /* M*maxiter */,
                 int* n_iter, int* converged, double* elbo);
 
 /* frozen-topic inference: unsmoothed_update_θ! (MMCTM.jl:496-509); loops of transform (flags & 1 unsmoothed theta,

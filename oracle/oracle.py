@@ -94,7 +94,10 @@ def lib():
     L.orc_ctm_loglik.argtypes = [P, f64p]
     L.orc_ctm_elbo.argtypes = [P, f64p]; L.orc_ctm_elbo.restype = C.c_double
     L.orc_ctm_estep_range.argtypes = [P, C.c_int, C.c_int]
-    L.orc_ctm_fit.argtypes = [P, C.c_int, C.c_double, C.c_int, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+    L.orc_alpha_objective.restype = C.c_double
+    L.orc_alpha_objective.argtypes = [C.c_double, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_int]
+    L.orc_ctm_update_alpha.argtypes = [P]
+    L.orc_ctm_fit.argtypes = [P, C.c_int, C.c_double, C.c_int, C.c_int, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_double)]
     L.orc_ctm_unsmoothed_update_theta.argtypes = [P, C.c_int]
     L.orc_ctm_infer.argtypes = [P, C.c_int, C.c_int, C.c_double, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -141,6 +144,12 @@ def mma_minimize(fun, x0, lb=None, ub=None, xtol_rel=1e-4, xtol_abs=1e-4, rule=0
                                  ubp.ctypes.data if ubp is not None else None,
                                  x, C.byref(minf), xtol_rel, xtol_abs, rule, max_eval, C.byref(no))
     return x, minf.value, nev, no.value
+
+
+def alpha_objective(alpha, sum_Elnphi, K, V):
+    g = C.c_double()
+    v = lib().orc_alpha_objective(float(alpha), C.byref(g), float(sum_Elnphi), int(K), int(V))
+    return v, g.value
 
 
 def lambda_objective(lam, nu, Ndivzeta, sumtheta, mu, invSigma):
@@ -378,9 +387,11 @@ class CtmOracle:
     def elbo(self):
         t = np.empty(7); e = lib().orc_ctm_elbo(C.byref(self.s), t); return e, t
 
-    def fit(self, maxiter=100, tol=1e-4, update_sigma=True):
+    def update_alpha(self): lib().orc_ctm_update_alpha(C.byref(self.s))
+
+    def fit(self, maxiter=100, tol=1e-4, update_sigma=True, auto_alpha=False):
         ll = np.zeros(self.M * maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
-        lib().orc_ctm_fit(C.byref(self.s), maxiter, tol, int(update_sigma), ll, C.byref(ni), C.byref(cv), C.byref(el))
+        lib().orc_ctm_fit(C.byref(self.s), maxiter, tol, int(update_sigma), int(auto_alpha), ll, C.byref(ni), C.byref(cv), C.byref(el))
         self.converged = bool(cv.value); self.elbo_value = el.value
         self.ll_hist = ll[:self.M * ni.value].reshape(ni.value, self.M).copy()
         return self.ll_hist

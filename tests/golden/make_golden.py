@@ -211,6 +211,17 @@ out["digamma"] = {"x": [float(mp.mpf(s)) for s in xs], "psi": [f(psi(mp.mpf(floa
 xs2 = ["0.1", "0.4", "1", "9.6", "96.5", "23029.1"]
 out["lgamma"] = {"x": [float(mp.mpf(s)) for s in xs2], "lgamma": [f(mp.loggamma(mp.mpf(float(mp.mpf(s))))) for s in xs2]}
 
+# ---- α_objective (common.jl:38-46), test/mmctm.jl:268-279 and test/immctm.jl:273-284: the test evaluates
+# L = K (lgamma(V α) - V lgamma(α)) + α ΣElnϕ and dL/dα = K V (ψ(V α) - ψ(α)) + ΣElnϕ for the toy model (K = 2, V = 4,
+# α = 0.1; IMMCTM: K = 2, J = 2); ΣElnϕ depends on the random init there, so fixed values are used here
+cases = []
+for (al, s_, K_, V_) in [("0.1", "-25.5", 2, 4), ("0.1", "-9.25", 2, 2), ("0.37", "-40.125", 3, 4), ("2.5", "-310.0", 7, 96), ("1e-3", "-50.0", 10, 48)]:
+    a_ = mp.mpf(float(mp.mpf(al))); ss = mp.mpf(float(mp.mpf(s_)))
+    L = K_ * (mp.loggamma(V_ * a_) - V_ * mp.loggamma(a_)) + a_ * ss
+    g = K_ * V_ * (psi(V_ * a_) - psi(a_)) + ss
+    cases.append({"alpha": float(a_), "sum_Elnphi": float(ss), "K": K_, "V": V_, "L": f(L), "grad": f(g)})
+out["alpha_objective"] = {"ref": "test/mmctm.jl:268-279; test/immctm.jl:273-284; common.jl:38-46", "cases": cases}
+
 here = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(here, "reference_kats.json"), "w") as fh:
     json.dump(out, fh, indent=1, sort_keys=True)

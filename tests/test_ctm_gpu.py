@@ -315,3 +315,55 @@ def test_unsupported_shapes_are_reported(mmm):
         mmm.MMCTM([16] * 5, [0.1] * 5, [4] * 5, [[np.array([[1, 3]])] * 5], seed=0)
     with pytest.raises(mmm.MmmError, match="not supported"):
         mmm.LDA(40, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)
+
+
+# ------------------------------------------------------------------------------------------ update_α! / autoα
+@pytest.mark.parametrize("imm", [False, True])
+def test_update_alpha_reference_test(mmm, kats, oracle, imm):      # test/mmctm.jl:268-293; test/immctm.jl:273-294
+    model = _toy(mmm, kats, imm)
+    a0 = np.concatenate([np.atleast_1d(x) for x in model.α]).copy()
+    E = model._get("Elnphi")
+    mmm.update_α(model)
+    a1 = np.concatenate([np.atleast_1d(x) for x in model.α])
+    assert not np.allclose(a1, a0) and np.all(a1 >= 1e-7)
+    # the same optimisation by the oracle from the same Elnϕ
+    c = kats["corpora"]
+    X = [[arr(xm).astype(np.int64).reshape(-1, 2) for xm in xd] for xd in c["X_mm"]]
+    o = oracle.CtmOracle(c["K_mm"], c["alpha_mm"], X, features=c["features"] if imm else None, seed=1)
+    o.Elnphi[:] = E
+    o.update_alpha()
+    np.testing.assert_allclose(a1, o.alpha, rtol=1e-6)
+    # L_after > L_before for every α (the reference's assertion)
+    i = 0
+    for m in range(model.M):
+        blk = E[o.goff[m]:o.goff[m + 1]].reshape(model.K[m], -1)
+        widths = [model.V[m]] if not imm else model.J[m]
+        jo = 0
+        for w in widths:
+            s = blk[:, jo:jo + w].sum(); jo += w
+            assert oracle.alpha_objective(a1[i], s, model.K[m], w)[0] > oracle.alpha_objective(a0[i], s, model.K[m], w)[0]
+            i += 1
+
+
+@pytest.mark.parametrize("case", ["mm", "imm"])
+def test_fit_autoalpha_matches_oracle(mmm, oracle, case):
+    if case == "mm":
+        X, g, o = _pair(mmm, oracle, 80, [5, 4], [40, 24], seed=5, means=[600, 80])
+    else:
+        X, g, o = _pair(mmm, oracle, 70, [6], [96], seed=6, means=[1500], imm_features=SNV3)
+    ll_g = mmm.fit(g, maxiter=14, tol=1e-9, verbose=False, autoα=True)
+    ll_o = o.fit(maxiter=14, tol=1e-9, auto_alpha=True)
+    assert len(ll_g) == len(ll_o)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-5)
+    a = np.concatenate([np.atleast_1d(x) for x in g.α])
+    assert not np.allclose(a, 0.1)
+    np.testing.assert_allclose(a, o.alpha, rtol=1e-3)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-5)
+    # a batch with autoα keeps one α per restart
+    if case == "mm":
+        g0 = [[np.random.default_rng(s).integers(1, 101, size=(k, v)).astype(np.float64) for k, v in zip([5, 4], [40, 24])] for s in (1, 2)]
+        b = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], X, γ0=g0, restarts=2)
+        mmm.fit_restarts(b, maxiter=6, tol=0.0, autoα=True)
+        a0 = b.select(0).α.copy(); a1 = b.select(1).α.copy()
+        s0 = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], X, γ0=g0[0]); mmm.fit(s0, maxiter=6, tol=0.0, verbose=False, autoα=True)
+        assert np.array_equal(a0, s0.α) and not np.array_equal(a0, a1)
