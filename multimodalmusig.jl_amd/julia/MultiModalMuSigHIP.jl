@@ -223,18 +223,85 @@ end
 
 # fit!(model; maxiter, tol, verbose, autoα, updateΣ) -- MMCTM.jl:457-494
 function fit!(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true)
-    autoα && error("autoα (update_α!) is not part of the HIP backend")
     M = model.M
     ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
-                model.h, maxiter, tol, updateΣ ? 1 : 0, ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
+                model.h, maxiter, tol, (updateΣ ? 1 : 0) | (autoα ? 2 : 0),      # MMM_FIT_UPDATE_SIGMA | MMM_FIT_AUTO_ALPHA
+                ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
     hist = [ll[(i - 1) * M + 1:i * M] for i in 1:n[]]
     if verbose
         for (iter, v) in enumerate(hist) println("$iter\tLog-likelihoods: ", join(v, ", ")) end
     end
     model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = hist[end]
+    autoα && (model.α = ctm_get(model, 11, M))
     download!(model)
     return hist
+end
+
+# ---- restart batch: what scripts/run_mmctm.jl:97-109 gets from `pmap(fit_restart, seeds)`, in one handle -----------
+# γ0s[r][m][k] = rand(1:100, V[m]) of restart r (MMCTM.jl:60-63).  Returns (handle, ll[r][iter][m], converged[r], elbo[r]);
+# `select_restart!(model, h, r)` then downloads restart r into `model`.
+function fit_restarts(k::Vector{Int}, α::Vector{Float64}, V::Vector{Int}, X::Vector{Vector{Matrix{Int}}}, γ0s; maxiter=1000, tol=1e-4,
+                      ctx::Context=default_context())
+    R = length(γ0s); M = length(k); D = length(X)
+    doc_ptr, term, count = pack_mm(X, M)
+    g0 = Float64[]
+    for r in 1:R, m in 1:M, kk in 1:k[m] append!(g0, Float64.(γ0s[r][m][kk])) end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mmm_ctm_create_batch, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cint}, Ptr{Cint}, Ptr{Int32},
+                 Ptr{Cdouble}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                ctx.h, R, D, M, Cint.(k), Cint.(V), α, doc_ptr, term, count, C_NULL, C_NULL, C_NULL, g0, C_NULL, h), ctx, "mmm_ctm_create_batch")
+    ll = Vector{Float64}(undef, R * maxiter * M); n = Vector{Cint}(undef, R); cv = Vector{Cint}(undef, R); elbo = Vector{Cdouble}(undef, R)
+    check(ccall((:mmm_ctm_fit_batch, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}, Ptr{Cdouble}),
+                h[], maxiter, tol, 1, ll, n, cv, elbo), ctx, "mmm_ctm_fit_batch")
+    hist = [[ll[((r - 1) * maxiter + (i - 1)) * M + 1:((r - 1) * maxiter + i) * M] for i in 1:n[r]] for r in 1:R]
+    return h[], hist, cv .!= 0, elbo
+end
+
+function select_restart!(model::MMCTM, h::Ptr{Cvoid}, r::Int)
+    check(ccall((:mmm_ctm_select, LIB), Cint, (Ptr{Cvoid}, Cint), h, r - 1), model.ctx, "mmm_ctm_select")
+    old = model.h; model.h = h
+    download!(model)
+    model.h = old
+    return model
+end
+
+# ---- frozen-topic inference (MMCTM.jl:496-586): fresh model on X, copied globals, passes on the GPU --------------------
+function ctm_set(model, field::Int, v::Vector{Float64})
+    check(ccall((:mmm_ctm_set, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, v, length(v)), model.ctx, "mmm_ctm_set")
+end
+
+function ctm_infer!(model, flags::Int, maxiter::Int, tol::Float64)
+    M = model.M
+    ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0)
+    check(ccall((:mmm_ctm_infer, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}),
+                model.h, flags, maxiter, tol, ll, n, cv), model.ctx, "mmm_ctm_infer")
+    model.converged = cv[] != 0
+    return [ll[(i - 1) * M + 1:i * M] for i in 1:n[]]
+end
+
+flat(nested) = vcat((vcat(x...) for x in nested)...)
+
+function transform(model::MMCTM, X::Vector{Vector{Matrix{Int}}}; maxiter=1000, tol=1e4, fit_gaussian=false, verbose=false)   # MMCTM.jl:511-552
+    newmodel = MMCTM(model.K, model.α, model.V, X; ctx=model.ctx)
+    ctm_set(newmodel, 5, flat(model.ϕ))                                   # :516
+    if !fit_gaussian
+        ctm_set(newmodel, 0, model.μ); ctm_set(newmodel, 1, vec(model.Σ))   # :518-521 (invΣ stays I, as upstream)
+    end
+    ll = ctm_infer!(newmodel, 1 | (fit_gaussian ? 2 : 0), maxiter, Float64(tol))
+    newmodel.ll = ll[end]
+    download!(newmodel)
+    return newmodel
+end
+
+function fit_heldout(Xheldout::Vector{Vector{Matrix{Int}}}, model::MMCTM; maxiter=100, verbose=false)                     # MMCTM.jl:554-586
+    heldout_model = MMCTM(model.K, model.α, model.V, Xheldout; ctx=model.ctx)
+    ctm_set(heldout_model, 0, model.μ); ctm_set(heldout_model, 1, vec(model.Σ)); ctm_set(heldout_model, 2, vec(model.invΣ))
+    ctm_set(heldout_model, 3, flat(model.γ)); ctm_set(heldout_model, 4, flat(model.Elnϕ)); ctm_set(heldout_model, 5, flat(model.ϕ))
+    ctm_infer!(heldout_model, 0, maxiter, 1e-4)
+    download!(heldout_model)
+    return heldout_model
 end
 
 # IMMCTM(k, α, features, X) -- IMMCTM.jl:29-88: same handle type on the C side (mmm_ctm_create with n_feat/J/features);
@@ -281,16 +348,19 @@ function IMMCTM(k::Vector{Int}, α::Vector{Float64}, features::Vector{Matrix{Int
 end
 
 function fit!(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false)    # IMMCTM.jl:437-466
-    autoα && error("autoα (update_α!) is not part of the HIP backend")
     M = model.M
     ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
-                model.h, maxiter, tol, 1, ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
+                model.h, maxiter, tol, 1 | (autoα ? 2 : 0), ll, n, cv, elbo), model.ctx, "mmm_ctm_fit")
     hist = [ll[(i - 1) * M + 1:i * M] for i in 1:n[]]
     if verbose
         for (iter, v) in enumerate(hist) println("$iter\tLog-likelihoods: ", join(v, ", ")) end
     end
     model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = hist[end]
+    if autoα
+        a = ctm_get(model, 11, sum(model.I)); off = cumsum([0; model.I])
+        model.α = [a[off[m] + 1:off[m + 1]] for m in 1:M]
+    end
     MK = sum(model.K); D = model.D
     model.μ = ctm_get(model, 0, MK); model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK); model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
     lam = reshape(ctm_get(model, 6, D * MK), MK, D); nu = reshape(ctm_get(model, 7, D * MK), MK, D)
