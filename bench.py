@@ -154,7 +154,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "LDA K=10 alpha=eta=0.1, %d docs x 96 SNV terms per GPU (BASELINE configs[1]), "
                                    "nnz/GPU=%d, one EM iteration per step" % (D, nnz),
-                       "docs_per_gpu": D, "terms": V, "topics": K, "sharding": "docs x%d" % world},
+                       "docs_per_gpu": D, "terms": V, "topics": K, "sharding": "docs x%d" % world,
+                       "allreduce": ctx.transport},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_lda_estep<10,16,true,96>", "launches": n_launch, "avg_us": avg_s * 1e6,

@@ -76,6 +76,20 @@ int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 int mmm_comm_unique_id(char out[MMM_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId   */
 int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id[MMM_UNIQUE_ID_BYTES]);
 int mmm_comm_nranks(const mmm_ctx* ctx);
+/* The all-reduce transport.  The payload is 1-20 KB once per iteration, so latency decides: after mmm_comm_init_rank the
+ * library all-reduces through per-rank MAILBOXES in fine-grained device memory that the peers write directly over xGMI
+ * (one kernel per call, sums in rank order: same bits on every rank), provided the IPC mappings could be made and a
+ * known-answer rehearsal passed on every rank; otherwise, and for payloads above the mailbox capacity, ncclAllReduce.
+ * MMM_P2P=0 in the environment keeps RCCL.  mmm_comm_transport: "p2p", "rccl" or "none".
+ * The mailbox path can also be set up without RCCL: every rank calls mmm_p2p_local_handle, the host exchanges the
+ * handles (nranks x MMM_P2P_HANDLE_BYTES, rank-major), every rank calls mmm_p2p_attach and mmm_p2p_selftest, and all
+ * ranks call mmm_p2p_enable(ctx, 0) unless every rank's rehearsal passed. */
+#define MMM_P2P_HANDLE_BYTES 64
+const char* mmm_comm_transport(const mmm_ctx* ctx);
+int mmm_p2p_local_handle(mmm_ctx* ctx, int nranks, char out[MMM_P2P_HANDLE_BYTES]);
+int mmm_p2p_attach(mmm_ctx* ctx, int nranks, int rank, const char* handles);
+int mmm_p2p_selftest(mmm_ctx* ctx, int* ok);
+int mmm_p2p_enable(mmm_ctx* ctx, int on);
 
 /* ---- LDA (src/LDA.jl) ----------------------------------------------------------------------------------- */
 enum { /* field ids for mmm_lda_get / mmm_lda_set; sizes in doubles */

@@ -51,6 +51,11 @@ _SIGS = {
     "mmm_ctx_profile_end": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
+    "mmm_comm_transport": (C.c_char_p, [vp]),
+    "mmm_p2p_local_handle": (C.c_int, [vp, C.c_int, C.c_char_p]),
+    "mmm_p2p_attach": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
+    "mmm_p2p_selftest": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "mmm_p2p_enable": (C.c_int, [vp, C.c_int]),
     "mmm_comm_nranks": (C.c_int, [vp]),
     "mmm_lda_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, vp, vp, f64p, C.POINTER(vp)]),
     "mmm_lda_destroy": (C.c_int, [vp]),
@@ -166,6 +171,34 @@ class Context:
     def init_comm(self, nranks, rank, unique_id):
         check(lib().mmm_comm_init_rank(self.h, int(nranks), int(rank), unique_id), self.h, "mmm_comm_init_rank")
         self.nranks, self.rank = int(nranks), int(rank)
+
+    @property
+    def transport(self):
+        """'p2p' (xGMI mailboxes), 'rccl' or 'none': what the per-iteration all-reduce uses."""
+        return lib().mmm_comm_transport(self.h).decode()
+
+    def init_p2p(self, nranks, rank, allgather, allmin):
+        """Mailbox all-reduce without an RCCL communicator.  allgather(bytes) -> list of every rank's bytes (rank order),
+        allmin(int) -> minimum over ranks; both are collective calls of the host's own transport (gloo, MPI, ...)."""
+        nranks, rank = int(nranks), int(rank)
+        mine = C.create_string_buffer(64)
+        check(lib().mmm_p2p_local_handle(self.h, nranks, mine), self.h, "mmm_p2p_local_handle")
+        handles = b"".join(allgather(mine.raw))
+        ok = 1
+        try:
+            check(lib().mmm_p2p_attach(self.h, nranks, rank, handles), self.h, "mmm_p2p_attach")
+        except MmmError:
+            ok = 0
+        if not allmin(ok):
+            if ok:
+                lib().mmm_p2p_enable(self.h, 0)
+            raise MmmError("p2p mailboxes could not be mapped on every rank")
+        good = C.c_int(0)
+        check(lib().mmm_p2p_selftest(self.h, C.byref(good)), self.h, "mmm_p2p_selftest")
+        if not allmin(good.value):
+            lib().mmm_p2p_enable(self.h, 0)
+            raise MmmError("p2p all-reduce rehearsal failed on some rank")
+        self.nranks, self.rank = nranks, rank
 
     def close(self):
         if self.h:

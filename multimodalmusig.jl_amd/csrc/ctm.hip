@@ -1076,6 +1076,7 @@ int check_status(mmm_ctm* m, Scope sc)
     std::vector<int> h((size_t)sc.nrep, 0);
     MMM_HIP(m->ctx, hipMemcpyAsync(h.data(), m->status.p + sc.rep0, sizeof(int) * sc.nrep, hipMemcpyDeviceToHost, m->ctx->stream));
     MMM_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    { int rc = mmm_p2p_check(m->ctx); if (rc) return rc; }
     for (int i = 0; i < sc.nrep; ++i)
         if (h[i]) return mmm_fail(m->ctx, MMM_ERR_NUMERIC, "update_Σ!: Sigma is singular (inv failed) in replica %d", sc.rep0 + i);
     return MMM_OK;

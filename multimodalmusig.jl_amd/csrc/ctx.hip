@@ -45,6 +45,8 @@ int mmm_ctx_destroy(mmm_ctx* ctx)
     if (!ctx) return MMM_OK;
     (void)hipSetDevice(ctx->device);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    mmm_p2p_release(ctx);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
@@ -57,7 +59,7 @@ int mmm_ctx_synchronize(mmm_ctx* ctx)
 {
     if (!ctx) return MMM_ERR_ARG;
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return MMM_OK;
+    return mmm_p2p_check(ctx);
 }
 
 void* mmm_ctx_stream(mmm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -117,7 +119,8 @@ int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id_bytes[M
     memcpy(&id, id_bytes, sizeof id);
     MMM_NCCL(ctx, ncclCommInitRank(&ctx->comm, nranks, id, rank));
     ctx->nranks = nranks; ctx->rank = rank;
-    return MMM_OK;
+    // the per-iteration all-reduce goes over the xGMI mailboxes when they can be set up and rehearse correctly on every rank
+    return mmm_p2p_setup_over_rccl(ctx);
 }
 
 int mmm_comm_nranks(const mmm_ctx* ctx) { return ctx ? ctx->nranks : 0; }

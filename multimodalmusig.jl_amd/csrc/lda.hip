@@ -817,6 +817,7 @@ int sync_ctl(mmm_lda* m)
     LdaCtl h;
     MMM_HIP(ctx, hipMemcpyAsync(&h, m->ctl.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int rc = mmm_p2p_check(ctx); if (rc) return rc; }
     const bool stopped = h.stop != 0;
     if (stopped) m->stop_seen = true;
     m->t = h.t; m->n_hist = h.n_hist;
@@ -1090,7 +1091,7 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     double hd[2] = {0.0, (double)D};
     MMM_HIP(ctx, hipMemcpyAsync(&hd[0], ncount, sizeof(double), hipMemcpyDeviceToHost, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));
-    if (ctx->comm) {
+    if (mmm_comm_active(ctx)) {
         MMM_HIP(ctx, hipMemcpyAsync(ncount, hd, sizeof hd, hipMemcpyHostToDevice, st));
         int rc = mmm_allreduce_sum(ctx, ncount, 2);
         if (rc) { delete m; return rc; }

@@ -15,11 +15,15 @@
 
 #include "../../include/mmmusig.h"
 
+struct mmm_p2p;      // p2p.hip: mailbox all-reduce over xGMI
+
 struct mmm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    mmm_p2p* p2p = nullptr;       // mailbox + peer mappings (NULL: not set up)
+    bool p2p_on = false;          // all-reduces of <= mailbox capacity go through the p2p kernel
     int num_cu = 256;
     std::string err;
     char arch[64] = {0};
@@ -92,16 +96,15 @@ struct DevBuf {
 // (MMM_FORCE_RCCL=1: lets a single-GPU box run the RCCL path)
 inline bool mmm_comm_active(const mmm_ctx* ctx)
 {
+    if (ctx->nranks > 1 && (ctx->p2p_on || ctx->comm)) return true;
     if (!ctx->comm) return false;
-    if (ctx->nranks > 1) return true;
     static const bool force = getenv("MMM_FORCE_RCCL") != nullptr;
     return force;
 }
 
-// sum-all-reduce of a packed double buffer across the ranks of ctx (no-op for a single rank)
-inline int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
-{
-    if (!mmm_comm_active(ctx)) return MMM_OK;
-    MMM_NCCL(ctx, ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-    return MMM_OK;
-}
+// sum-all-reduce of a packed double buffer across the ranks of ctx, on the ctx stream (no-op for a single rank): the p2p
+// mailbox kernel when it is set up and the payload fits, ncclAllReduce otherwise (p2p.hip)
+int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count);
+int mmm_p2p_setup_over_rccl(mmm_ctx* ctx);
+int mmm_p2p_check(mmm_ctx* ctx);
+void mmm_p2p_release(mmm_ctx* ctx);

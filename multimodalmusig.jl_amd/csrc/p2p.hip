@@ -1,0 +1,288 @@
+// p2p.hip -- the per-iteration all-reduce of the packed sufficient statistics, over xGMI without a collective library.
+//
+// The payload is 1-20 KB of doubles once per EM iteration: latency is everything, bandwidth nothing.  RCCL's ring costs
+// tens of microseconds at this size, i.e. more than the whole 28 us iteration it sits in.  Here every rank owns a MAILBOX in
+// fine-grained (uncached, peer-visible) device memory, [2 slots][nranks][cap] cells of 16 bytes; one kernel per call
+//   1. stores its own contribution into every peer's mailbox, directly over xGMI, and
+//   2. polls its own mailbox for the peers' contributions and sums them in RANK ORDER (same bits on every rank, deterministic).
+// A cell carries one double as two 8-byte words {low half | seq} {high half | seq}: 8-byte stores are atomic, so a cell is
+// complete exactly when both words show the sequence number of this call -- no fence, no flag, no ordering requirement
+// between stores (the "LL" idea of collective libraries).  seq is a per-context call counter (identical on all ranks, which
+// issue the same calls in the same order); slot = seq & 1 suffices because a rank cannot start call s+2 before every rank
+// has finished reading call s (it needs their s+1 contributions, which they send after their call-s kernel has ended).
+// Every poll loop has a wall-clock exit (default 2 s): on expiry the kernel records the failure and ends, and the next
+// host synchronisation point reports it -- a lost peer cannot hang the GPU.
+//
+// Set-up is transport-agnostic: mmm_p2p_local_handle / mmm_p2p_attach exchange 64-byte IPC handles by whatever the host has.
+// mmm_comm_init_rank does it over the RCCL communicator, then runs a self-test against known sums; if anything fails on any
+// rank, all ranks keep using ncclAllReduce.
+#include "mmm_internal.h"
+
+namespace {
+
+constexpr int kP2PMaxRanks = 16;
+constexpr size_t kP2PCap = 8192;            // doubles per call (LDA: 961; CTM cfg 4: 2,450)
+
+struct P2PArgs {
+    unsigned long long* peer[kP2PMaxRanks];   // mailbox base of every rank (peer[rank] = the local one)
+    int nranks, rank;
+    size_t cap;
+    int* err;                                 // device word: sequence number of a call that timed out (0 = none)
+    unsigned long long timeout_ticks;         // s_memrealtime ticks (100 MHz)
+};
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, double* buf, int count, unsigned int seq)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int n = a.nranks, me = a.rank;
+    const size_t slot = seq & 1u;
+    const double mine = buf[e];
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    const unsigned long long w0 = (bits & 0xffffffffull) | tag, w1 = (bits >> 32) | tag;
+    for (int p = 0; p < n; ++p) {
+        if (p == me) continue;
+        unsigned long long* dst = a.peer[p] + ((slot * n + me) * a.cap + e) * 2;
+        __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    double sum = 0.0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool failed = false;
+    for (int r = 0; r < n; ++r) {
+        double v = mine;
+        if (r != me) {
+            const unsigned long long* src = a.peer[me] + ((slot * n + r) * a.cap + e) * 2;
+            unsigned long long x0, x1;
+            for (;;) {
+                x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned int)(x0 >> 32) == seq && (unsigned int)(x1 >> 32) == seq) break;
+                if (failed || __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            v = __longlong_as_double((long long)((x0 & 0xffffffffull) | (x1 << 32)));
+        }
+        sum += v;
+    }
+    if (failed) atomicExch(a.err, (int)seq);
+    buf[e] = sum;
+}
+
+} // namespace
+
+struct mmm_p2p {
+    P2PArgs args{};
+    void* local = nullptr;
+    void* opened[kP2PMaxRanks] = {nullptr};
+    int* err = nullptr;
+    unsigned int seq = 0;
+    size_t bytes = 0;
+};
+
+static size_t p2p_bytes(int nranks) { return sizeof(unsigned long long) * 2 * 2 * (size_t)nranks * kP2PCap; }
+
+// the mailbox has to exist before its handle can be handed out; nranks is fixed at that point
+static int p2p_alloc(mmm_ctx* ctx, int nranks)
+{
+    if (ctx->p2p) return MMM_OK;
+    MMM_CHECK(ctx, nranks >= 2 && nranks <= kP2PMaxRanks, "p2p: nranks %d not in 2..%d", nranks, kP2PMaxRanks);
+    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    mmm_p2p* p = new mmm_p2p();
+    p->bytes = p2p_bytes(nranks);
+    hipError_t e = hipExtMallocWithFlags(&p->local, p->bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { delete p; return mmm_fail(ctx, MMM_ERR_HIP, "p2p: fine-grained allocation of %zu bytes: %s", p->bytes, hipGetErrorString(e)); }
+    e = hipMalloc((void**)&p->err, sizeof(int));
+    if (e != hipSuccess) { (void)hipFree(p->local); delete p; return mmm_fail(ctx, MMM_ERR_HIP, "p2p: %s", hipGetErrorString(e)); }
+    MMM_HIP(ctx, hipMemset(p->local, 0, p->bytes));
+    MMM_HIP(ctx, hipMemset(p->err, 0, sizeof(int)));
+    MMM_HIP(ctx, hipDeviceSynchronize());
+    p->args.nranks = nranks; p->args.cap = kP2PCap; p->args.err = p->err;
+    double secs = 2.0;
+    if (const char* s = getenv("MMM_P2P_TIMEOUT_S")) secs = std::max(0.001, atof(s));
+    p->args.timeout_ticks = (unsigned long long)(secs * 1e8);
+    ctx->p2p = p;
+    return MMM_OK;
+}
+
+void mmm_p2p_release(mmm_ctx* ctx)
+{
+    mmm_p2p* p = ctx->p2p;
+    if (!p) return;
+    (void)hipSetDevice(ctx->device);
+    for (int r = 0; r < kP2PMaxRanks; ++r) if (p->opened[r]) (void)hipIpcCloseMemHandle(p->opened[r]);
+    if (p->local) (void)hipFree(p->local);
+    if (p->err) (void)hipFree(p->err);
+    delete p;
+    ctx->p2p = nullptr; ctx->p2p_on = false;
+}
+
+// a timed-out call leaves its sequence number in the error word; called wherever the host synchronises anyway
+int mmm_p2p_check(mmm_ctx* ctx)
+{
+    if (!ctx->p2p || !ctx->p2p_on) return MMM_OK;
+    int h = 0;
+    MMM_HIP(ctx, hipMemcpyAsync(&h, ctx->p2p->err, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) return mmm_fail(ctx, MMM_ERR_RCCL, "p2p all-reduce #%d timed out waiting for a peer (rank %d of %d)", h, ctx->rank, ctx->nranks);
+    return MMM_OK;
+}
+
+static int p2p_launch(mmm_ctx* ctx, double* dev, size_t count)
+{
+    mmm_p2p* p = ctx->p2p;
+    const unsigned int seq = ++p->seq;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, p->args, dev, (int)count, seq);
+    MMM_LAUNCH_CHECK(ctx);
+    return MMM_OK;
+}
+
+int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
+{
+    if (!mmm_comm_active(ctx) || count == 0) return MMM_OK;
+    if (ctx->p2p_on && count <= kP2PCap) return p2p_launch(ctx, dev, count);
+    MMM_CHECK(ctx, ctx->comm != nullptr, "all-reduce of %zu doubles: no RCCL communicator and the payload exceeds the p2p mailbox (%zu)", count, kP2PCap);
+    MMM_NCCL(ctx, ncclAllReduce(dev, dev, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    return MMM_OK;
+}
+
+// known-answer rehearsal: small integers (exact in any summation order), 160 calls with the payload sizes of the real
+// path (1 .. the mailbox capacity), so both slots are reused many times before the first real call
+static int p2p_selftest(mmm_ctx* ctx, bool* ok)
+{
+    *ok = false;
+    const int n = ctx->nranks, me = ctx->rank, rounds = 160;
+    static const int sizes[] = {1, 2, 961, 2450, 17, (int)kP2PCap, 333, 1500};
+    DevBuf<double> buf;
+    MMM_HIP(ctx, buf.alloc(kP2PCap));
+    std::vector<double> h(kP2PCap);
+    bool good = true;
+    for (int it = 0; it < rounds && good; ++it) {
+        const int count = sizes[it % 8];
+        for (int e = 0; e < count; ++e) h[e] = (double)((me + 1) * (e % 7 + 1) + it);
+        MMM_HIP(ctx, hipMemcpyAsync(buf.p, h.data(), sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+        int rc = p2p_launch(ctx, buf.p, count);
+        if (rc) return rc;
+        MMM_HIP(ctx, hipMemcpyAsync(h.data(), buf.p, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int e = 0; e < count; ++e) {
+            const double want = (double)(n * (n + 1) / 2 * (e % 7 + 1) + n * it);
+            if (h[e] != want) { good = false; break; }
+        }
+    }
+    int herr = 0;
+    MMM_HIP(ctx, hipMemcpy(&herr, ctx->p2p->err, sizeof herr, hipMemcpyDeviceToHost));
+    if (herr) { good = false; MMM_HIP(ctx, hipMemset(ctx->p2p->err, 0, sizeof(int))); }
+    *ok = good;
+    return MMM_OK;
+}
+
+extern "C" {
+
+int mmm_p2p_local_handle(mmm_ctx* ctx, int nranks, char out[MMM_P2P_HANDLE_BYTES])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) <= MMM_P2P_HANDLE_BYTES, "hipIpcMemHandle_t larger than the ABI slot");
+    if (!ctx || !out) return MMM_ERR_ARG;
+    int rc = p2p_alloc(ctx, nranks);
+    if (rc) return rc;
+    hipIpcMemHandle_t h;
+    MMM_HIP(ctx, hipIpcGetMemHandle(&h, ctx->p2p->local));
+    memset(out, 0, MMM_P2P_HANDLE_BYTES);
+    memcpy(out, &h, sizeof h);
+    return MMM_OK;
+}
+
+int mmm_p2p_attach(mmm_ctx* ctx, int nranks, int rank, const char* handles)
+{
+    if (!ctx || !handles) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, ctx->p2p && ctx->p2p->args.nranks == nranks, "mmm_p2p_attach: call mmm_p2p_local_handle(ctx, %d, ...) first", nranks);
+    MMM_CHECK(ctx, rank >= 0 && rank < nranks, "mmm_p2p_attach: rank %d out of range", rank);
+    MMM_CHECK(ctx, ctx->comm == nullptr || (ctx->nranks == nranks && ctx->rank == rank), "mmm_p2p_attach: rank/nranks differ from the RCCL communicator's");
+    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    mmm_p2p* p = ctx->p2p;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { p->args.peer[r] = (unsigned long long*)p->local; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * MMM_P2P_HANDLE_BYTES, sizeof h);
+        void* q = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return mmm_fail(ctx, MMM_ERR_HIP, "mmm_p2p_attach: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+        p->opened[r] = q; p->args.peer[r] = (unsigned long long*)q;
+    }
+    p->args.rank = rank;
+    ctx->nranks = nranks; ctx->rank = rank;
+    ctx->p2p_on = true;
+    return MMM_OK;
+}
+
+// every rank calls this after mmm_p2p_attach (it communicates): 0/1 in *ok; a failed rehearsal switches the path off locally --
+// the caller must make the decision unanimous (mmm_comm_init_rank does, with an RCCL min-reduction)
+int mmm_p2p_selftest(mmm_ctx* ctx, int* ok)
+{
+    if (!ctx || !ok) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, ctx->p2p && ctx->p2p_on, "mmm_p2p_selftest: not attached");
+    bool good = false;
+    int rc = p2p_selftest(ctx, &good);
+    if (rc) return rc;
+    *ok = good ? 1 : 0;
+    return MMM_OK;
+}
+
+int mmm_p2p_enable(mmm_ctx* ctx, int on)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, !on || (ctx->p2p && ctx->p2p->args.peer[ctx->rank]), "mmm_p2p_enable: not attached");
+    ctx->p2p_on = on != 0;
+    return MMM_OK;
+}
+
+/* "p2p" | "rccl" | "none" */
+const char* mmm_comm_transport(const mmm_ctx* ctx)
+{
+    if (!ctx) return "none";
+    if (ctx->p2p_on && ctx->nranks > 1) return "p2p";
+    return mmm_comm_active(ctx) ? "rccl" : "none";
+}
+
+} // extern "C"
+
+// RCCL-bootstrapped set-up used by mmm_comm_init_rank: all-gather the handles, attach, rehearse, agree
+int mmm_p2p_setup_over_rccl(mmm_ctx* ctx)
+{
+    if (ctx->nranks < 2 || ctx->nranks > kP2PMaxRanks) return MMM_OK;
+    if (const char* s = getenv("MMM_P2P")) if (atoi(s) == 0) return MMM_OK;
+    const int n = ctx->nranks;
+    char mine[MMM_P2P_HANDLE_BYTES];
+    int ok_local = 1;
+    int rc = mmm_p2p_local_handle(ctx, n, mine);
+    if (rc) ok_local = 0;
+    DevBuf<char> send, recv;
+    MMM_HIP(ctx, send.alloc(MMM_P2P_HANDLE_BYTES)); MMM_HIP(ctx, recv.alloc((size_t)n * MMM_P2P_HANDLE_BYTES));
+    MMM_HIP(ctx, hipMemcpyAsync(send.p, mine, MMM_P2P_HANDLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    MMM_NCCL(ctx, ncclAllGather(send.p, recv.p, MMM_P2P_HANDLE_BYTES, ncclChar, ctx->comm, ctx->stream));
+    std::vector<char> all((size_t)n * MMM_P2P_HANDLE_BYTES);
+    MMM_HIP(ctx, hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ok_local && mmm_p2p_attach(ctx, n, ctx->rank, all.data()) != MMM_OK) ok_local = 0;
+    // unanimous decision no. 1: everybody attached?  (a rank that could not must not leave the others polling)
+    DevBuf<double> flag;
+    MMM_HIP(ctx, flag.alloc(1));
+    auto agree = [&](int v, int* out) -> int {
+        double d = v;
+        MMM_HIP(ctx, hipMemcpyAsync(flag.p, &d, sizeof d, hipMemcpyHostToDevice, ctx->stream));
+        MMM_NCCL(ctx, ncclAllReduce(flag.p, flag.p, 1, ncclDouble, ncclMin, ctx->comm, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(&d, flag.p, sizeof d, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *out = d > 0.5 ? 1 : 0;
+        return MMM_OK;
+    };
+    int all_ok = 0;
+    if ((rc = agree(ok_local, &all_ok))) return rc;
+    if (!all_ok) { mmm_p2p_release(ctx); ctx->err.clear(); return MMM_OK; }
+    bool good = false;
+    if ((rc = p2p_selftest(ctx, &good))) good = false;
+    if ((rc = agree(good ? 1 : 0, &all_ok))) return rc;
+    if (!all_ok) { ctx->p2p_on = false; ctx->err.clear(); }
+    return MMM_OK;
+}
