@@ -13,12 +13,13 @@ ap.add_argument("--restarts", type=int, default=100)
 ap.add_argument("--k", type=int, nargs="+", default=[7, 7])
 ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--out", default="", help="directory for sigs.tsv, props.tsv, mean.tsv, cov.tsv, cor.tsv (run_mmctm.jl:272-290)")
 args = ap.parse_args()
 mmm = mmm_pkg.load()
 from multimodalmusig_jl_amd import restarts as rs  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
-_, samples, snv = mmm.read_counts_tsv(os.path.join(GOLD, "brca-eu_snv_counts.tsv"))
-_, _, sv = mmm.read_counts_tsv(os.path.join(GOLD, "brca-eu_sv_counts.tsv"))
+terms_snv, samples, snv = mmm.read_counts_tsv(os.path.join(GOLD, "brca-eu_snv_counts.tsv"))
+terms_sv, _, sv = mmm.read_counts_tsv(os.path.join(GOLD, "brca-eu_sv_counts.tsv"))
 X = mmm.format_counts_mmctm([{s: snv[:, i] for i, s in enumerate(samples)}, {s: sv[:, i] for i, s in enumerate(samples)}], samples)
 K, V = args.k, [96, 48]
 alpha = [0.1, 0.1]
@@ -29,6 +30,14 @@ g, best, all_ll = rs.fit_seed_models(X, K, alpha, V, seeds, batch_size=args.batc
 t1 = time.perf_counter()
 model = rs.seed_and_fit_restart(X, K, alpha, V, g)
 t2 = time.perf_counter()
+if args.out:
+    from multimodalmusig_jl_amd import io as mio
+    os.makedirs(args.out, exist_ok=True)
+    mio.write_sigs(os.path.join(args.out, "sigs.tsv"), model, [terms_snv, terms_sv], ["snv", "sv"])
+    mio.write_props(os.path.join(args.out, "props.tsv"), model, samples, ["snv", "sv"])
+    mio.write_matrix(os.path.join(args.out, "mean.tsv"), model.μ)
+    mio.write_matrix(os.path.join(args.out, "cov.tsv"), model.Σ)
+    mio.write_matrix(os.path.join(args.out, "cor.tsv"), mio.cov2cor(model.Σ))
 print(json.dumps({"restarts": args.restarts, "K": K, "docs": len(X), "stage1_s": t1 - t0, "stage2_s": t2 - t1,
                   "stage1_best_ll": best.tolist(), "stage1_ll_spread": [float(all_ll[:, m].min()) for m in range(2)],
                   "stage2_ll": model.ll.tolist(), "stage2_converged": bool(model.converged), "stage2_elbo": model.elbo}))
