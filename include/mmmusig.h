@@ -99,13 +99,24 @@ enum { /* field ids for mmm_lda_get / mmm_lda_set; sizes in doubles */
     MMM_LDA_GAMMA = 3,    /* K*D  */
     MMM_LDA_ELNTHETA = 4, /* K*D  */
     MMM_LDA_THETA = 5,    /* K*D  */
-    MMM_LDA_PHI = 6       /* K*nnz */
+    MMM_LDA_PHI = 6,      /* K*nnz */
+    /* ILDA handles (mmm_ilda_create): the factor arrays of ILDA.jl:6-9, lambda[i] J_i x K column-major at K*sum_{q<i} J_q;
+     * for such handles ELNBETA / BETA above are the effective V x K tables sum_i Elnβ[i][f_vi,k] / prod_i β[i][f_vi,k] */
+    MMM_ILDA_LAMBDA = 7, MMM_ILDA_ELNBETA = 8, MMM_ILDA_BETA = 9      /* sum(J)*K */
 };
 /* Constructor LDA(k, alpha, eta, V, X) -- LDA.jl:24-54.  lambda0 (V*K) is the random init the shim draws with
  * rand(1:100, V, K) (LDA.jl:36); the ctor state gamma=1, phi=1/K, Elnbeta, Elntheta is built on the GPU.
  * With an RCCL communicator on ctx, (D, doc_ptr, term, count) is THIS RANK'S shard of the documents. */
 int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr,
                    const int32_t* term, const int32_t* count, const double* lambda0, mmm_lda** out);
+/* Constructor ILDA(k, alpha, eta::Vector, features, X) -- ILDA.jl:25-56: the topic-term distribution factorises over the I
+ * features of a term (features: [i*V + v], 0-based values < J[i]).  lambda0: rand(1:100, J_i, K) per feature (ILDA.jl:36).
+ * The handle is an mmm_lda: every mmm_lda_* entry point works on it (update_ϕ!/γ!/λ!/β! ILDA.jl:65-130, ll :203-239,
+ * ELBO :132-201 -- including the reference's ElnQβ, which keeps only the last feature's term, :175-182 --, fit! :246-272,
+ * and the frozen-topic passes of fit_heldout :320-353). */
+int mmm_ilda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, int I, const int* J, const double* eta,
+                    const int32_t* features, const int64_t* doc_ptr, const int32_t* term, const int32_t* count,
+                    const double* lambda0, mmm_lda** out);
 int mmm_lda_destroy(mmm_lda* m);
 int mmm_lda_get(mmm_lda* m, int field, double* host, size_t n);
 int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n);

@@ -58,6 +58,7 @@ _SIGS = {
     "mmm_p2p_enable": (C.c_int, [vp, C.c_int]),
     "mmm_comm_nranks": (C.c_int, [vp]),
     "mmm_lda_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, vp, vp, f64p, C.POINTER(vp)]),
+    "mmm_ilda_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, i32p, f64p, i32p, i64p, vp, vp, f64p, C.POINTER(vp)]),
     "mmm_lda_destroy": (C.c_int, [vp]),
     "mmm_lda_get": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
     "mmm_lda_set": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),

@@ -54,6 +54,7 @@ struct LdaCtl {
 };
 
 struct Ring { double* s[3]; };
+constexpr int kIldaMaxI = 8, kIldaMaxSJ = 512;
 
 struct EstepArgs {
     LdaDev c;
@@ -389,6 +390,69 @@ __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double et
     if (k == 0 && lane == 0) lda_pass_tail(r);
 }
 
+// ---- ILDA (src/ILDA.jl): LDA whose topic-term distribution factorises over I features of the term, beta_kv = prod_i
+// beta[i][f_vi, k].  The E-step, ll and ELBO document kernels run unchanged on EFFECTIVE V x K tables (Elnbeta_eff[v,k] =
+// sum_i Elnbeta[i][f_vi, k], exp of it, beta_eff = prod_i beta[i][f_vi, k]); only the topic M-step differs: the V x K
+// statistics are folded onto the feature values.  Model layout: lambda[i] is J_i x K column-major at K * sum_{q<i} J_q.
+struct IldaDesc {
+    int I, V, K, SJ;
+    int J[kIldaMaxI], joff[kIldaMaxI + 1];     // joff = prefix sums of J
+    double eta[kIldaMaxI];
+    const int* features;                       // [i*V + v], 0-based feature values
+};
+
+// mode 0: lambda = eta + folded sums (update_λ!, ILDA.jl:107-126); 1: from the stored lambda (update_Elnβ!/update_β!,
+// :97-104,128-130); 2: effective tables only, from the stored Elnbeta / beta (after an upload).  One wave per topic.
+__global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const double* sums, double* ilam, double* iEln, double* ibeta,
+                                                   double* Eeff, double* expEeff, double* beff, const int* stop, int write_beta_only)
+{
+    __shared__ double sE[kIldaMaxSJ], sB[kIldaMaxSJ];
+    if (stop && *stop) return;
+    const int k = blockIdx.x, lane = threadIdx.x, V = ds.V, K = ds.K;
+    for (int i = 0; i < ds.I; ++i) {
+        const int Ji = ds.J[i];
+        const size_t base = (size_t)K * ds.joff[i] + (size_t)Ji * k;
+        const int* f = ds.features + (size_t)i * V;
+        double part = 0.0;
+        for (int j0 = 0; j0 < Ji; j0 += 64) {
+            const int j = j0 + lane;
+            double l = 0.0;
+            if (j < Ji) {
+                if (mode == 0) {
+                    l = ds.eta[i];
+                    for (int v = 0; v < V; ++v) if (f[v] == j) l += sums[(size_t)k * V + v];
+                    ilam[base + j] = l;
+                } else l = ilam[base + j];
+            }
+            part += l;
+        }
+        const double cs = wave_sum(part);
+        const double psi = dev_digamma_pos(cs);
+        for (int j0 = 0; j0 < Ji; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < Ji) {
+                double el, b;
+                if (mode == 2) { el = iEln[base + j]; b = ibeta[base + j]; }
+                else {
+                    const double l = ilam[base + j];
+                    el = dev_digamma_pos(l) - psi; b = l / cs;
+                    if (!write_beta_only) iEln[base + j] = el;
+                    ibeta[base + j] = b;
+                }
+                sE[ds.joff[i] + j] = el; sB[ds.joff[i] + j] = b;
+            }
+        }
+    }
+    __syncthreads();
+    for (int v = lane; v < V; v += 64) {
+        double e = 0.0, b = 1.0;
+        for (int i = 0; i < ds.I; ++i) { const int j = ds.features[(size_t)i * V + v]; e += sE[ds.joff[i] + j]; b *= sB[ds.joff[i] + j]; }
+        const size_t o = (size_t)k * V + v;
+        if (!write_beta_only) { Eeff[o] = e; expEeff[o] = exp(e); }
+        beff[o] = b;
+    }
+}
+
 // Frozen-topic passes (transform / fit_heldout, LDA.jl:233-295): the E-step kernel runs with fixed tables and evaluates
 // the ll of the SAME pass (theta_t and beta are both known); this kernel sums the per-block numerators (phase & 1), and
 // (phase & 2) records ll_t, applies the stopping rule (LDA.jl:252 / :285) and advances the pass counter.
@@ -414,6 +478,8 @@ __global__ __launch_bounds__(64) void k_lda_infer_tail(ReduceArgs r, int phase)
         r.ctl->t = r.t;           // the state of the stopping pass is kept (its ll is not lagged)
     }
 }
+
+__global__ void k_lda_tail_only(ReduceArgs r) { if (!r.ctl->stop) lda_pass_tail(r); }
 
 // topic state of the current pass from its reduced statistics (same arithmetic as the E-step prologue)
 template <int KP>
@@ -663,6 +729,31 @@ __global__ __launch_bounds__(256) void k_lda_elbo_topics(int V, int K, const dou
     if (threadIdx.x == 0) { out[0] = sE; out[1] = q; }
 }
 
+// topic-side ELBO pieces of ILDA: out[0] = sum_i (eta_i - 1) sum Elnbeta[i]  (ElnPβ without its constant, ILDA.jl:132-141);
+// out[1] = ElnQβ as the reference computes it -- `lnq =` inside the loop (ILDA.jl:175-182) keeps only the LAST feature.
+__global__ __launch_bounds__(256) void k_ilda_elbo_topics(IldaDesc ds, const double* ilam, const double* iEln, double* out)
+{
+    __shared__ double sh[4];
+    double p = 0.0, q = 0.0;
+    for (int i = 0; i < ds.I; ++i) {
+        const int Ji = ds.J[i];
+        double qi = 0.0, pe = 0.0;
+        for (int k = 0; k < ds.K; ++k) {
+            const size_t base = (size_t)ds.K * ds.joff[i] + (size_t)Ji * k;
+            double cs = 0.0, a = 0.0;
+            for (int j = threadIdx.x; j < Ji; j += 256) {
+                const double l = ilam[base + j], e = iEln[base + j];
+                cs += l; a += lgamma(l) - (l - 1.0) * e; pe += e;
+            }
+            cs = block_sum_256(cs, sh);
+            qi += block_sum_256(a, sh) - lgamma(cs);
+        }
+        p += (ds.eta[i] - 1.0) * block_sum_256(pe, sh);
+        q = qi;
+    }
+    if (threadIdx.x == 0) { out[0] = p; out[1] = q; }
+}
+
 __global__ void k_fill(double* p, size_t n, double v)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -709,6 +800,11 @@ struct mmm_lda {
     bool single_step = false;   // one step per wave: the grid covers every document
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
+    // ILDA (src/ILDA.jl): feature-factorised topics; the V x K rings then hold the effective tables
+    bool ilda = false;
+    IldaDesc ids{};
+    DevBuf<int> features;
+    DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
     LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
@@ -884,6 +980,12 @@ int run_topic_update(mmm_lda* m, bool from_sums)
     mmm_ctx* ctx = m->ctx;
     const int c = m->cur();
     if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->scratch.p, (size_t)m->V * m->K); if (rc) return rc; }
+    if (m->ilda) {
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, from_sums ? 0 : 1, m->scratch.p, m->ilam[c].p, m->iEln[c].p,
+                           m->ibeta[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 0);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, ctx->stream, m->V, m->eta, from_sums ? m->scratch.p : nullptr,
                        m->lambda[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, 0);
     MMM_LAUNCH_CHECK(ctx);
@@ -915,8 +1017,14 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         hipLaunchKernelGGL(k_lda_reduce, dim3((VK + 15) / 16), dim3(16, 64), 0, ctx->stream, r);
         MMM_LAUNCH_CHECK(ctx);
         if ((rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
-        hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
-                           m->ring(m->expElnbeta), m->ring(m->beta));
+        if (m->ilda) {
+            const int c = t % 3;
+            hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+                               m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0);
+            hipLaunchKernelGGL(k_lda_tail_only, dim3(1), dim3(1), 0, ctx->stream, r);
+        } else
+            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+                               m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
         if (do_ll) m->n_hist++;
@@ -1013,11 +1121,22 @@ extern "C" int mmm_diag_lda_stamps(unsigned long long out[16])
 
 extern "C" {
 
-int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr, const int32_t* term,
-                   const int32_t* count, const double* lambda0, mmm_lda** out)
+static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr, const int32_t* term,
+                           const int32_t* count, const double* lambda0, int I, const int* J, const double* eta_i, const int32_t* features,
+                           mmm_lda** out)
 {
     if (!ctx) return MMM_ERR_ARG;
     MMM_CHECK(ctx, out && doc_ptr && lambda0, "mmm_lda_create: NULL argument");
+    const bool ilda = I > 0;
+    int SJ = 0;
+    if (ilda) {
+        MMM_CHECK(ctx, J && eta_i && features, "mmm_ilda_create: NULL argument");
+        if (I > kIldaMaxI) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ilda_create: I=%d features (max %d)", I, kIldaMaxI);
+        for (int i = 0; i < I; ++i) { MMM_CHECK(ctx, J[i] >= 1, "mmm_ilda_create: J[%d] < 1", i); SJ += J[i]; }
+        if (SJ > kIldaMaxSJ) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ilda_create: sum(J)=%d (max %d)", SJ, kIldaMaxSJ);
+        for (int i = 0; i < I; ++i) for (int v = 0; v < V; ++v)
+            MMM_CHECK(ctx, features[(size_t)i * V + v] >= 0 && features[(size_t)i * V + v] < J[i], "mmm_ilda_create: feature value out of range (i=%d v=%d)", i, v);
+    }
     MMM_CHECK(ctx, D >= 0 && V >= 1 && K >= 1, "mmm_lda_create: bad sizes D=%d V=%d K=%d", D, V, K);
     *out = nullptr;
     const int KP = pick_kp(K);
@@ -1068,16 +1187,32 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     A(theta, KD); A(phi, (size_t)K * nnz);
     A(partial, (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1);
+    if (ilda) {
+        A(features, (size_t)I * V);
+        for (int i = 0; i < 3; ++i) { A(ilam[i], (size_t)SJ * K); A(iEln[i], (size_t)SJ * K); A(ibeta[i], (size_t)SJ * K); }
+    }
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * (D + 1), hipMemcpyHostToDevice, st));
     if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
-    MMM_HIP(ctx, hipMemcpyAsync(m->lambda[0].p, lambda0, sizeof(double) * VK, hipMemcpyHostToDevice, st));
+    if (!ilda) MMM_HIP(ctx, hipMemcpyAsync(m->lambda[0].p, lambda0, sizeof(double) * VK, hipMemcpyHostToDevice, st));
+    else {
+        m->ilda = true;
+        IldaDesc& ds = m->ids;
+        ds.I = I; ds.V = V; ds.K = K; ds.SJ = SJ; ds.joff[0] = 0;
+        for (int i = 0; i < I; ++i) { ds.J[i] = J[i]; ds.joff[i + 1] = ds.joff[i] + J[i]; ds.eta[i] = eta_i[i]; }
+        ds.features = m->features.p;
+        MMM_HIP(ctx, hipMemcpyAsync(m->features.p, features, sizeof(int) * (size_t)I * V, hipMemcpyHostToDevice, st));
+        MMM_HIP(ctx, hipMemcpyAsync(m->ilam[0].p, lambda0, sizeof(double) * (size_t)SJ * K, hipMemcpyHostToDevice, st));
+        for (int i = 0; i < 3; ++i) MMM_HIP(ctx, hipMemsetAsync(m->lambda[i].p, 0, sizeof(double) * VK, st));      // unused for ILDA
+    }
     MMM_HIP(ctx, hipMemsetAsync(m->ctl.p, 0, sizeof(LdaCtl), st));
     if (KD) MMM_HIP(ctx, hipMemsetAsync(m->theta.p, 0, sizeof(double) * KD, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
-    hipLaunchKernelGGL(k_lda_topic, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda[0].p, m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, 0);
+    if (!ilda) hipLaunchKernelGGL(k_lda_topic, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda[0].p, m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, 0);
+    else hipLaunchKernelGGL(k_ilda_mstep, dim3(K), dim3(64), 0, st, m->ids, 1, (const double*)nullptr, m->ilam[0].p, m->iEln[0].p, m->ibeta[0].p,
+                            m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, (const int*)nullptr, 0);      // ILDA.jl:36-40 (+ tables)
     if (KD) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma[0].p, KD, 1.0);
         hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
@@ -1104,6 +1239,20 @@ int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, 
     return MMM_OK;
 }
 
+int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr, const int32_t* term,
+                   const int32_t* count, const double* lambda0, mmm_lda** out)
+{
+    return lda_create_impl(ctx, D, V, K, alpha, eta, doc_ptr, term, count, lambda0, 0, nullptr, nullptr, nullptr, out);
+}
+
+int mmm_ilda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, int I, const int* J, const double* eta, const int32_t* features,
+                    const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const double* lambda0, mmm_lda** out)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, I >= 1, "mmm_ilda_create: I < 1");
+    return lda_create_impl(ctx, D, V, K, alpha, eta ? eta[0] : 0.0, doc_ptr, term, count, lambda0, I, J, eta, features, out);
+}
+
 int mmm_lda_destroy(mmm_lda* m)
 {
     if (!m) return MMM_OK;
@@ -1125,6 +1274,10 @@ static int lda_field(mmm_lda* m, int field, double** p, size_t* n)
         case MMM_LDA_ELNTHETA: *p = m->Elntheta[c].p; *n = KD; break;
         case MMM_LDA_THETA: *p = m->theta.p; *n = KD; break;
         case MMM_LDA_PHI: *p = m->phi.p; *n = (size_t)m->K * m->nnz; break;
+        case MMM_ILDA_LAMBDA: case MMM_ILDA_ELNBETA: case MMM_ILDA_BETA:
+            if (!m->ilda) return mmm_fail(m->ctx, MMM_ERR_ARG, "field %d exists for ILDA handles only", field);
+            *p = field == MMM_ILDA_LAMBDA ? m->ilam[c].p : (field == MMM_ILDA_ELNBETA ? m->iEln[c].p : m->ibeta[c].p);
+            *n = (size_t)m->ids.SJ * m->K; break;
         default: return mmm_fail(m->ctx, MMM_ERR_ARG, "unknown LDA field %d", field);
     }
     return MMM_OK;
@@ -1166,6 +1319,12 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
     if (field == MMM_LDA_ELNBETA && n) {
         hipLaunchKernelGGL(k_exp_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)n, m->Elnbeta[m->cur()].p, m->expElnbeta[m->cur()].p);
+        MMM_LAUNCH_CHECK(ctx);
+    }
+    if (field == MMM_ILDA_ELNBETA || field == MMM_ILDA_BETA) {      // effective tables follow the uploaded factors
+        const int c = m->cur();
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 2, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, field == MMM_ILDA_BETA ? 1 : 0);
         MMM_LAUNCH_CHECK(ctx);
     }
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1214,6 +1373,10 @@ int mmm_lda_update_beta(mmm_lda* m)
     int rc = prepare_call(m);
     if (rc) return rc;
     const int c = m->cur();
+    if (m->ilda)
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, m->ctx->stream, m->ids, 1, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 1);
+    else
     hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, m->ctx->stream, m->V, m->eta, (const double*)nullptr, m->lambda[c].p,
                        (double*)nullptr, (double*)nullptr, m->beta[c].p, 1);
     MMM_LAUNCH_CHECK(m->ctx);
@@ -1282,7 +1445,8 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7])
     double* acc = m->elbopart.p + (size_t)m->grid_s * 5;      // [0..4] doc sums, [5..6] topic sums
     hipLaunchKernelGGL(k_lda_elbo_docs, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p, m->Elnbeta[c].p, m->elbopart.p);
     hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc);
-    hipLaunchKernelGGL(k_lda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->V, m->K, m->lambda[c].p, m->Elnbeta[c].p, acc + 5);
+    if (m->ilda) hipLaunchKernelGGL(k_ilda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->ids, m->ilam[c].p, m->iEln[c].p, acc + 5);
+    else hipLaunchKernelGGL(k_lda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->V, m->K, m->lambda[c].p, m->Elnbeta[c].p, acc + 5);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
     double h[7];
@@ -1291,6 +1455,10 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7])
     const double K = m->K, V = m->V, al = m->alpha, et = m->eta;
     double t[7];
     t[0] = K * (lgamma(V * et) - V * lgamma(et)) + (et - 1.0) * h[5];            // LDA.jl:114-118
+    if (m->ilda) {                                                               // ILDA.jl:132-141
+        t[0] = h[5];
+        for (int i = 0; i < m->ids.I; ++i) t[0] += K * (lgamma(m->ids.J[i] * m->ids.eta[i]) - m->ids.J[i] * lgamma(m->ids.eta[i]));
+    }
     t[1] = m->Dglobal * (lgamma(K * al) - K * lgamma(al)) + (al - 1.0) * h[0];   // LDA.jl:120-124
     t[2] = h[1]; t[3] = h[2]; t[4] = h[6]; t[5] = h[4]; t[6] = h[3];
     if (terms) memcpy(terms, t, sizeof t);
@@ -1357,6 +1525,12 @@ int mmm_lda_infer(mmm_lda* m, int unsmoothed, int maxiter, double tol, double* l
         MMM_HIP(ctx, hipMemcpyAsync(m->Elnbeta[s].p, m->Elnbeta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
         MMM_HIP(ctx, hipMemcpyAsync(m->expElnbeta[s].p, m->expElnbeta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
         MMM_HIP(ctx, hipMemcpyAsync(m->beta[s].p, m->beta[c].p, VKb, hipMemcpyDeviceToDevice, ctx->stream));
+        if (m->ilda) {
+            const size_t SJb = sizeof(double) * m->ids.SJ * m->K;
+            MMM_HIP(ctx, hipMemcpyAsync(m->ilam[s].p, m->ilam[c].p, SJb, hipMemcpyDeviceToDevice, ctx->stream));
+            MMM_HIP(ctx, hipMemcpyAsync(m->iEln[s].p, m->iEln[c].p, SJb, hipMemcpyDeviceToDevice, ctx->stream));
+            MMM_HIP(ctx, hipMemcpyAsync(m->ibeta[s].p, m->ibeta[c].p, SJb, hipMemcpyDeviceToDevice, ctx->stream));
+        }
     }
     *converged = 0;
     const int base = m->n_hist;

@@ -17,7 +17,7 @@ import numpy as np
 
 from ._lib import check, lib
 from .ctm import IMMCTM, MMCTM
-from .models import LDA, calculate_elbo
+from .models import ILDA, LDA, calculate_elbo
 
 UNSMOOTHED, FIT_GAUSSIAN = 1, 2      # MMM_INFER_* of include/mmmusig.h
 
@@ -61,6 +61,9 @@ def _new_like(model, X, K=None, α=None, mods=None, seed=None):
 def transform(model, X, maxiter=1000, tol=None, fit_gaussian=False, verbose=False, seed=None):
     """`transform(model, X)`.  LDA (LDA.jl:233-263): returns θ (K x D) of the new documents under the trained β.
     MMCTM (MMCTM.jl:511-552): returns the new model (λ, ν, θ, props, ll of the new documents under the trained ϕ)."""
+    if isinstance(model, ILDA):
+        # ILDA.jl:289-318 builds `LDA(model.K, model.α, model.η, X)` with a vector η: a MethodError upstream
+        raise TypeError("transform(::ILDA) is a MethodError in the reference (ILDA.jl:293); use fit_heldout")
     if isinstance(model, LDA):
         tol = 1e-4 if tol is None else tol
         new = LDA(model.K, model.α, model.η, model.V, X, seed=seed, ctx=model.ctx)
@@ -87,6 +90,14 @@ def transform(model, X, maxiter=1000, tol=None, fit_gaussian=False, verbose=Fals
 def fit_heldout(Xheldout, model, maxiter=100, verbose=False, seed=None):
     """`fit_heldout(Xheldout, model)` -- LDA.jl:265-295, MMCTM.jl:554-586, IMMCTM.jl:468-497: the variational document
     parameters of held-out documents under the trained topics (smoothed update_ϕ!/update_θ!), tol = 1e-4."""
+    if isinstance(model, ILDA):                                       # ILDA.jl:320-353
+        new = ILDA(model.K, model.α, model.η, model.features, Xheldout, seed=seed, ctx=model.ctx)
+        new._set("ilambda", model._get("ilambda")); new._set("ibeta", model._get("ibeta")); new._set("iElnbeta", model._get("iElnbeta"))
+        hist = _lda_infer(new, False, maxiter, 1e-4, verbose)
+        new.elbo = calculate_elbo(new)
+        new.ll = float(hist[-1])
+        new.ll_history = hist
+        return new
     if isinstance(model, LDA):
         new = LDA(model.K, model.α, model.η, model.V, Xheldout, seed=seed, ctx=model.ctx)
         new.λ = model.λ; new.β = model.β; new.Elnβ = model.Elnβ      # LDA.jl:269-271

@@ -15,7 +15,7 @@ from .utils import pack_lda, pack_mm
 
 # field ids of include/mmmusig.h (ASCII keys: Python NFKC-normalises identifiers, so `ϕ` typed as a keyword
 # would not equal the string "ϕ")
-_F = {"lambda": 0, "Elnbeta": 1, "beta": 2, "gamma": 3, "Elntheta": 4, "theta": 5, "phi": 6}
+_F = {"lambda": 0, "Elnbeta": 1, "beta": 2, "gamma": 3, "Elntheta": 4, "theta": 5, "phi": 6, "ilambda": 7, "iElnbeta": 8, "ibeta": 9}
 
 
 class _PerDocView:
@@ -139,6 +139,75 @@ class LDA:
             self.close()
         except Exception:
             pass
+
+
+class _FactorList:
+    """`model.λ` / `model.Elnβ` / `model.β` of an ILDA: list over features of J_i x K matrices; item assignment writes through."""
+
+    def __init__(self, model, name):
+        self._m, self._name = model, name
+
+    def __len__(self):
+        return self._m.I
+
+    def __getitem__(self, i):
+        m = self._m
+        flat = m._get(self._name)
+        return flat[m._ioff[i]:m._ioff[i + 1]].reshape(m.J[i], m.K, order="F").copy()
+
+    def __setitem__(self, i, value):
+        m = self._m
+        flat = m._get(self._name)
+        value = np.asarray(value, dtype=np.float64)
+        if value.shape != (m.J[i], m.K):
+            raise ValueError("%s[%d] must be J_i x K" % (self._name, i))
+        flat[m._ioff[i]:m._ioff[i + 1]] = value.ravel(order="F")
+        m._set(self._name, flat)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+class ILDA(LDA):
+    """`ILDA(k, α, η, features, X)` -- ILDA.jl:25-63: LDA whose topic-term distribution factorises over the I features of a
+    term.  features: V x I matrix of 1-based feature values; η: scalar or length-I vector.  `λ0`: list over features of
+    J_i x K matrices (default `rand(1:100, J_i, K)`, ILDA.jl:36).  The per-function API and `fit` are LDA's (same C handle)."""
+
+    def __init__(self, k, α, η, features, X, λ0=None, seed=None, ctx=None):
+        f = np.asarray(features, dtype=np.int64)
+        self.features = f
+        self.K, self.α, self.X = int(k), float(α), X
+        self.I = int(f.shape[1]); self.V = int(f.shape[0])
+        self.J = [int(x) for x in f.max(axis=0)]                          # ILDA.jl:35
+        self.η = np.full(self.I, float(η)) if np.ndim(η) == 0 else np.asarray(η, dtype=np.float64).copy()
+        self.D = len(X)
+        self._doc_ptr, self._term, self._count = pack_lda(X)
+        self.N = np.array([int(self._count[self._doc_ptr[d]:self._doc_ptr[d + 1]].sum()) for d in range(self.D)], dtype=np.int64)
+        self._ioff = np.concatenate([[0], np.cumsum([j * self.K for j in self.J])]).astype(np.int64)
+        if λ0 is None:
+            rng = np.random.default_rng(seed)
+            λ0 = [rng.integers(1, 101, size=(j, self.K)).astype(np.float64) for j in self.J]
+        lam0 = np.concatenate([np.asarray(λ0[i], dtype=np.float64).reshape(self.J[i], self.K).ravel(order="F") for i in range(self.I)])
+        self.ctx = ctx or _lib.default_context()
+        self._h = C.c_void_p()
+        tp = self._term.ctypes.data if self._term.size else None
+        cp = self._count.ctypes.data if self._count.size else None
+        feat = np.ascontiguousarray((f - 1).T.ravel(), dtype=np.int32)                         # [i*V + v], 0-based
+        check(lib().mmm_ilda_create(self.ctx.h, self.D, self.V, self.K, self.α, self.I, np.ascontiguousarray(self.J, dtype=np.int32),
+                                    np.ascontiguousarray(self.η), feat, self._doc_ptr, tp, cp, lam0, C.byref(self._h)), self.ctx.h, "mmm_ilda_create")
+        _lib.track(self)
+        self.converged = False
+        self.elbo = float("nan")
+        self.ll = float("nan")
+
+    def _size(self, name):
+        if name in ("ilambda", "iElnbeta", "ibeta"):
+            return int(self._ioff[-1])
+        return LDA._size(self, name)
+
+    λ = property(lambda s: _FactorList(s, "ilambda"), lambda s, v: [_FactorList(s, "ilambda").__setitem__(i, x) for i, x in enumerate(v)] and None)
+    Elnβ = property(lambda s: _FactorList(s, "iElnbeta"), lambda s, v: [_FactorList(s, "iElnbeta").__setitem__(i, x) for i, x in enumerate(v)] and None)
+    β = property(lambda s: _FactorList(s, "ibeta"), lambda s, v: [_FactorList(s, "ibeta").__setitem__(i, x) for i, x in enumerate(v)] and None)
 
 
 # ---- function API (the reference's free functions on a model; dispatch on the model type like Julia methods) ------------

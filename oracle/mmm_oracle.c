@@ -523,6 +523,177 @@ int orc_lda_infer(int D, int V, int K, double alpha, const int64_t* doc_ptr, con
 }
 
 /* ============================================================================================== */
+/* ILDA (src/ILDA.jl): lambda[i] is J_i x K column-major at K * sum_{q<i} J_q; features [i*V + v] 0-based */
+/* ============================================================================================== */
+static size_t ilda_off(int K, const int* J, int i) { size_t o = 0; for (int q = 0; q < i; ++q) o += (size_t)J[q] * K; return o; }
+
+/* ILDA.jl:97-104 */
+void orc_ilda_update_Elnbeta(int K, int I, const int* J, const double* lam, double* Eln)
+{
+    for (int i = 0; i < I; ++i) {
+        const double* l = lam + ilda_off(K, J, i); double* e = Eln + ilda_off(K, J, i);
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < J[i]; ++j) s += l[j + (size_t)J[i] * k];
+            double ps = orc_digamma(s);
+            for (int j = 0; j < J[i]; ++j) e[j + (size_t)J[i] * k] = orc_digamma(l[j + (size_t)J[i] * k]) - ps;
+        }
+    }
+}
+
+/* ILDA.jl:128-130 */
+void orc_ilda_update_beta(int K, int I, const int* J, const double* lam, double* beta)
+{
+    for (int i = 0; i < I; ++i) {
+        const double* l = lam + ilda_off(K, J, i); double* b = beta + ilda_off(K, J, i);
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < J[i]; ++j) s += l[j + (size_t)J[i] * k];
+            for (int j = 0; j < J[i]; ++j) b[j + (size_t)J[i] * k] = l[j + (size_t)J[i] * k] / s;
+        }
+    }
+}
+
+/* ILDA.jl:65-79 (smoothed; no max-subtraction, as the reference) and :274-287 (unsmoothed = 1: exp(Elntheta) .* prod beta) */
+void orc_ilda_update_phi(int K, int D, int V, int I, const int* J, const int32_t* features, const int64_t* doc_ptr,
+                         const int32_t* term, const double* Elntheta, const double* Eln_or_beta, int unsmoothed, double* phi)
+{
+    for (int d = 0; d < D; ++d) {
+        double* ph = phi + (size_t)K * doc_ptr[d];
+        int64_t W = doc_ptr[d + 1] - doc_ptr[d];
+        for (int64_t w = 0; w < W; ++w) {
+            int v = term[doc_ptr[d] + w];
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) {
+                double a = unsmoothed ? exp(Elntheta[k + (size_t)K * d]) : Elntheta[k + (size_t)K * d];
+                for (int i = 0; i < I; ++i) {
+                    int j = features[(size_t)i * V + v];
+                    double t = Eln_or_beta[ilda_off(K, J, i) + j + (size_t)J[i] * k];
+                    if (unsmoothed) a *= t; else a += t;
+                }
+                double e = unsmoothed ? a : exp(a);
+                ph[k + (size_t)K * w] = e; s += e;
+            }
+            for (int k = 0; k < K; ++k) ph[k + (size_t)K * w] /= s;
+        }
+    }
+}
+
+/* ILDA.jl:107-126 */
+void orc_ilda_update_lambda(int K, int D, int V, int I, const int* J, const double* eta, const int32_t* features,
+                            const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const double* phi,
+                            double* lam, double* Eln)
+{
+    for (int i = 0; i < I; ++i) { double* l = lam + ilda_off(K, J, i); for (size_t q = 0; q < (size_t)J[i] * K; ++q) l[q] = eta[i]; }
+    for (int d = 0; d < D; ++d) {
+        const double* ph = phi + (size_t)K * doc_ptr[d];
+        int64_t W = doc_ptr[d + 1] - doc_ptr[d];
+        for (int64_t w = 0; w < W; ++w) {
+            int v = term[doc_ptr[d] + w]; double n = (double)count[doc_ptr[d] + w];
+            for (int i = 0; i < I; ++i) {
+                int j = features[(size_t)i * V + v]; double* l = lam + ilda_off(K, J, i);
+                for (int k = 0; k < K; ++k) l[j + (size_t)J[i] * k] += ph[k + (size_t)K * w] * n;
+            }
+        }
+    }
+    orc_ilda_update_Elnbeta(K, I, J, lam, Eln);
+}
+
+/* ILDA.jl:203-231 */
+double orc_ilda_loglik(int K, int D, int V, int I, const int* J, const int32_t* features, const int64_t* doc_ptr,
+                       const int32_t* term, const int32_t* count, const double* theta, const double* beta)
+{
+    double ll = 0.0; int64_t N = 0;
+    for (int d = 0; d < D; ++d)
+        for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) {
+            int v = term[e]; double pw = 0.0;
+            N += count[e];
+            for (int k = 0; k < K; ++k) {
+                double t = theta[k + (size_t)K * d];
+                for (int i = 0; i < I; ++i) t *= beta[ilda_off(K, J, i) + features[(size_t)i * V + v] + (size_t)J[i] * k];
+                pw += t;
+            }
+            ll += (double)count[e] * log(pw);
+        }
+    return ll / (double)N;
+}
+
+/* ILDA.jl:132-201; terms as orc_lda_elbo.  ElnQβ follows the reference literally: `lnq = ...` inside the feature loop
+ * (ILDA.jl:175-182) discards every feature but the last. */
+double orc_ilda_elbo(int K, int D, int V, int I, const int* J, double alpha, const double* eta, const int32_t* features,
+                     const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const double* lam, const double* Eln,
+                     const double* gamma, const double* Elntheta, const double* phi, double* terms)
+{
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < I; ++i) {
+        const double* e = Eln + ilda_off(K, J, i); double se = 0.0;
+        for (size_t q = 0; q < (size_t)J[i] * K; ++q) se += e[q];
+        t[0] += K * (orc_lgamma(J[i] * eta[i]) - J[i] * orc_lgamma(eta[i])) + (eta[i] - 1) * se;
+    }
+    { double s = 0.0; for (size_t q = 0; q < (size_t)K * D; ++q) s += Elntheta[q];
+      t[1] = D * (orc_lgamma(K * alpha) - K * orc_lgamma(alpha)) + (alpha - 1) * s; }
+    for (int d = 0; d < D; ++d) {
+        const double* ph = phi + (size_t)K * doc_ptr[d];
+        int64_t W = doc_ptr[d + 1] - doc_ptr[d];
+        for (int64_t w = 0; w < W; ++w) {
+            int v = term[doc_ptr[d] + w]; double n = (double)count[doc_ptr[d] + w];
+            for (int k = 0; k < K; ++k) {
+                double p = ph[k + (size_t)K * w];
+                t[2] += p * Elntheta[k + (size_t)K * d] * n;
+                for (int i = 0; i < I; ++i) t[3] += p * n * Eln[ilda_off(K, J, i) + features[(size_t)i * V + v] + (size_t)J[i] * k];
+                t[6] += (p > 0.0) ? p * log(p) : 0.0;                 /* log(ϕ^ϕ), 0^0 = 1 */
+            }
+        }
+    }
+    for (int i = 0; i < I; ++i) {
+        const double* l = lam + ilda_off(K, J, i); const double* e = Eln + ilda_off(K, J, i);
+        double q = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double cs = 0.0;
+            for (int j = 0; j < J[i]; ++j) { double x = l[j + (size_t)J[i] * k]; q += orc_lgamma(x) - (x - 1) * e[j + (size_t)J[i] * k]; cs += x; }
+            q -= orc_lgamma(cs);
+        }
+        t[4] = q;      /* sic: overwritten, not accumulated */
+    }
+    for (int d = 0; d < D; ++d) {
+        double cs = 0.0;
+        for (int k = 0; k < K; ++k) { double x = gamma[k + (size_t)K * d]; t[5] += orc_lgamma(x) - (x - 1) * Elntheta[k + (size_t)K * d]; cs += x; }
+        t[5] -= orc_lgamma(cs);
+    }
+    if (terms) memcpy(terms, t, sizeof t);
+    return t[0] + t[1] + t[2] + t[3] - t[4] - t[5] - t[6];
+}
+
+/* constructor state (ILDA.jl:36-51) + fit! (ILDA.jl:246-272); frozen = 1: the loop of fit_heldout (ILDA.jl:330-348) with the
+ * given lambda / Elnbeta / beta held fixed.  lam is in/out (lambda0 on entry). */
+int orc_ilda_fit(int D, int V, int K, int I, const int* J, double alpha, const double* eta, const int32_t* features,
+                 const int64_t* doc_ptr, const int32_t* term, const int32_t* count, int frozen, int maxiter, double tol,
+                 double* lam, double* Eln, double* beta, double* gamma, double* Elntheta, double* theta, double* phi,
+                 double* ll_hist, int* n_iter, int* converged, double* elbo)
+{
+    int64_t nnz = doc_ptr[D];
+    if (!frozen) orc_ilda_update_Elnbeta(K, I, J, lam, Eln);
+    for (size_t q = 0; q < (size_t)K * D; ++q) gamma[q] = 1.0;
+    orc_lda_update_Elntheta(K, D, gamma, Elntheta);
+    for (size_t q = 0; q < (size_t)K * nnz; ++q) phi[q] = 1.0 / K;
+    *converged = 0; int it = 0;
+    for (int iter = 1; iter <= maxiter; ++iter) {
+        orc_lda_update_gamma(K, D, alpha, doc_ptr, count, phi, gamma, Elntheta);              /* ILDA.jl:85-93 == LDA's */
+        orc_ilda_update_phi(K, D, V, I, J, features, doc_ptr, term, Elntheta, Eln, 0, phi);
+        if (!frozen) { orc_ilda_update_lambda(K, D, V, I, J, eta, features, doc_ptr, term, count, phi, lam, Eln); orc_ilda_update_beta(K, I, J, lam, beta); }
+        orc_lda_update_theta(K, D, gamma, theta);
+        ll_hist[it++] = orc_ilda_loglik(K, D, V, I, J, features, doc_ptr, term, count, theta, beta);
+        if (it > 10) {
+            double rel = fabs(ll_hist[it - 2] - ll_hist[it - 1]) / fabs(ll_hist[it - 1]);
+            if (rel < tol) { *converged = 1; break; }
+        }
+    }
+    *n_iter = it;
+    if (elbo) *elbo = orc_ilda_elbo(K, D, V, I, J, alpha, eta, features, doc_ptr, term, count, lam, Eln, gamma, Elntheta, phi, NULL);
+    return 0;
+}
+
+/* ============================================================================================== */
 /* MMCTM / IMMCTM                                                                                 */
 /* ============================================================================================== */
 

@@ -95,6 +95,24 @@ int orc_lda_infer(int D, int V, int K, double alpha, const int64_t* doc_ptr, con
                   const double* beta, double* gamma, double* Elntheta, double* theta, double* phi,
                   double* ll_hist, int* n_iter, int* converged);
 
+/* ---- ILDA (src/ILDA.jl): lambda[i] J_i x K column-major at K*sum_{q<i} J_q; features [i*V + v], 0-based -------------- */
+void orc_ilda_update_Elnbeta(int K, int I, const int* J, const double* lam, double* Eln);
+void orc_ilda_update_beta(int K, int I, const int* J, const double* lam, double* beta);
+void orc_ilda_update_phi(int K, int D, int V, int I, const int* J, const int32_t* features, const int64_t* doc_ptr,
+                         const int32_t* term, const double* Elntheta, const double* Eln_or_beta, int unsmoothed, double* phi);
+void orc_ilda_update_lambda(int K, int D, int V, int I, const int* J, const double* eta, const int32_t* features,
+                            const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const double* phi,
+                            double* lam, double* Eln);
+double orc_ilda_loglik(int K, int D, int V, int I, const int* J, const int32_t* features, const int64_t* doc_ptr,
+                       const int32_t* term, const int32_t* count, const double* theta, const double* beta);
+double orc_ilda_elbo(int K, int D, int V, int I, const int* J, double alpha, const double* eta, const int32_t* features,
+                     const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const double* lam, const double* Eln,
+                     const double* gamma, const double* Elntheta, const double* phi, double* terms);
+int orc_ilda_fit(int D, int V, int K, int I, const int* J, double alpha, const double* eta, const int32_t* features,
+                 const int64_t* doc_ptr, const int32_t* term, const int32_t* count, int frozen, int maxiter, double tol,
+                 double* lam, double* Eln, double* beta, double* gamma, double* Elntheta, double* theta, double* phi,
+                 double* ll_hist, int* n_iter, int* converged, double* elbo);
+
 /* ---- MMCTM / IMMCTM (src/MMCTM.jl, src/IMMCTM.jl) ------------------------------------------------ */
 typedef struct {
     int D, M, MK;

@@ -83,6 +83,16 @@ def lib():
     L.orc_lda_unsmoothed_update_phi.argtypes = [C.c_int, C.c_int, C.c_int, i64p, i32p, f64p, f64p, f64p]
     L.orc_lda_infer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, i64p, i32p, i32p, C.c_int, C.c_int, C.c_double,
                                 f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_ilda_update_Elnbeta.argtypes = [C.c_int, C.c_int, i32p, f64p, f64p]
+    L.orc_ilda_update_beta.argtypes = [C.c_int, C.c_int, i32p, f64p, f64p]
+    L.orc_ilda_update_phi.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i64p, i32p, f64p, f64p, C.c_int, f64p]
+    L.orc_ilda_update_lambda.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p, f64p, i32p, i64p, i32p, i32p, f64p, f64p, f64p]
+    L.orc_ilda_loglik.restype = C.c_double
+    L.orc_ilda_loglik.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i64p, i32p, i32p, f64p, f64p]
+    L.orc_ilda_elbo.restype = C.c_double
+    L.orc_ilda_elbo.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.c_double, f64p, i32p, i64p, i32p, i32p, f64p, f64p, f64p, f64p, f64p, f64p]
+    L.orc_ilda_fit.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.c_double, f64p, i32p, i64p, i32p, i32p, C.c_int, C.c_int, C.c_double,
+                               f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     P = C.POINTER(OrcCtm)
     for name in ("update_zeta", "update_theta", "update_nu", "update_lambda", "fitdoc"):
         getattr(L, "orc_ctm_" + name).argtypes = [P, C.c_int]
@@ -284,6 +294,88 @@ class LdaOracle:
     def phi_doc(self, d):
         W = self.doc_ptr[d + 1] - self.doc_ptr[d]
         return self.phi[self.K * self.doc_ptr[d]:self.K * self.doc_ptr[d + 1]].reshape(W, self.K).T  # K x W
+
+
+# ------------------------------------------------------------------------------------------------------
+# ILDA
+# ------------------------------------------------------------------------------------------------------
+class IldaOracle:
+    """State container mirroring `mutable struct ILDA` (ILDA.jl:1-23).  lam / Elnbeta / beta: the I factor matrices (J_i x K,
+    column-major) concatenated; `mat(arr, i)` views one.  features: V x I matrix of 1-based values."""
+
+    def __init__(self, K, alpha, eta, features, X, lambda0=None, seed=0):
+        self.K, self.alpha = int(K), float(alpha)
+        f = np.asarray(features, dtype=np.int64)
+        self.V, self.I = int(f.shape[0]), int(f.shape[1])
+        self.J = np.ascontiguousarray(f.max(axis=0), dtype=np.int32)
+        self.eta = np.full(self.I, float(eta)) if np.ndim(eta) == 0 else np.asarray(eta, dtype=np.float64).copy()
+        self.features = np.ascontiguousarray((f - 1).T.ravel(), dtype=np.int32)          # [i*V + v]
+        self.doc_ptr, self.term, self.count = flatten_lda(X)
+        self.D = len(X); self.nnz = int(self.doc_ptr[-1])
+        self.off = np.concatenate([[0], np.cumsum(self.J.astype(np.int64) * self.K)])
+        n = int(self.off[-1])
+        if lambda0 is None:
+            lambda0 = np.random.default_rng(seed).integers(1, 101, size=n).astype(np.float64)
+        self.lam = np.ascontiguousarray(lambda0, dtype=np.float64).copy()
+        assert self.lam.size == n
+        self.Elnbeta = np.empty(n); self.beta = np.zeros(n)
+        lib().orc_ilda_update_Elnbeta(self.K, self.I, self.J, self.lam, self.Elnbeta)
+        self.gamma = np.ones(self.K * self.D); self.theta = np.zeros(self.K * self.D); self.Elntheta = np.empty(self.K * self.D)
+        lib().orc_lda_update_Elntheta(self.K, self.D, self.gamma, self.Elntheta)
+        self.phi = np.full(self.K * self.nnz, 1.0 / self.K)
+
+    def mat(self, arr, i):
+        return arr[self.off[i]:self.off[i + 1]].reshape(int(self.J[i]), self.K, order="F")
+
+    def update_gamma(self):
+        lib().orc_lda_update_gamma(self.K, self.D, self.alpha, self.doc_ptr, self.count, self.phi, self.gamma, self.Elntheta)
+
+    def update_phi(self):
+        lib().orc_ilda_update_phi(self.K, self.D, self.V, self.I, self.J, self.features, self.doc_ptr, self.term, self.Elntheta, self.Elnbeta, 0, self.phi)
+
+    def update_lambda(self):
+        lib().orc_ilda_update_lambda(self.K, self.D, self.V, self.I, self.J, self.eta, self.features, self.doc_ptr, self.term, self.count,
+                                     self.phi, self.lam, self.Elnbeta)
+
+    def update_beta(self):
+        lib().orc_ilda_update_beta(self.K, self.I, self.J, self.lam, self.beta)
+
+    def update_theta(self):
+        lib().orc_lda_update_theta(self.K, self.D, self.gamma, self.theta)
+
+    def loglik(self):
+        return lib().orc_ilda_loglik(self.K, self.D, self.V, self.I, self.J, self.features, self.doc_ptr, self.term, self.count, self.theta, self.beta)
+
+    def elbo(self):
+        t = np.empty(7)
+        e = lib().orc_ilda_elbo(self.K, self.D, self.V, self.I, self.J, self.alpha, self.eta, self.features, self.doc_ptr, self.term, self.count,
+                                self.lam, self.Elnbeta, self.gamma, self.Elntheta, self.phi, t)
+        return e, t
+
+    def _run(self, frozen, maxiter, tol):
+        ll = np.zeros(maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
+        lib().orc_ilda_fit(self.D, self.V, self.K, self.I, self.J, self.alpha, self.eta, self.features, self.doc_ptr, self.term, self.count,
+                           int(frozen), maxiter, tol, self.lam, self.Elnbeta, self.beta, self.gamma, self.Elntheta, self.theta, self.phi, ll,
+                           C.byref(ni), C.byref(cv), C.byref(el))
+        self.converged = bool(cv.value); self.elbo_value = el.value
+        self.ll_hist = ll[:ni.value].copy()
+        return self.ll_hist
+
+    def fit(self, maxiter=1000, tol=1e-4):
+        return self._run(False, maxiter, tol)
+
+    def fit_heldout(self, X, maxiter=100):
+        """fit_heldout(Xheldout, model::ILDA) ILDA.jl:320-353"""
+        f1 = self.features.reshape(self.I, self.V).T + 1
+        new = IldaOracle(self.K, self.alpha, self.eta, f1, X, seed=1)
+        new.lam[:] = self.lam; new.beta[:] = self.beta; new.Elnbeta[:] = self.Elnbeta
+        new._run(True, maxiter, 1e-4)
+        new.ll = new.ll_hist[-1]
+        return new
+
+    def phi_doc(self, d):
+        W = self.doc_ptr[d + 1] - self.doc_ptr[d]
+        return self.phi[self.K * self.doc_ptr[d]:self.K * self.doc_ptr[d + 1]].reshape(W, self.K).T
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -222,6 +222,45 @@ for (al, s_, K_, V_) in [("0.1", "-25.5", 2, 4), ("0.1", "-9.25", 2, 2), ("0.37"
     cases.append({"alpha": float(a_), "sum_Elnphi": float(ss), "K": K_, "V": V_, "L": f(L), "grad": f(g)})
 out["alpha_objective"] = {"ref": "test/mmctm.jl:268-279; test/immctm.jl:273-284; common.jl:38-46", "cases": cases}
 
+# ---- ILDA (test/ilda.jl): features 4 x 2, X = [[1 5; 2 8], [3 2; 4 5]], K = 2 ------------------------------------
+ILDA_FEATURES = [[1, 1], [1, 2], [2, 1], [2, 2]]
+X_ILDA = [[[1, 5], [2, 8]], [[3, 2], [4, 5]]]
+Elnth = [[mp.mpf("0.5"), mp.mpf("-1.1")], [mp.mpf("2.3"), mp.mpf("-0.7")]]                # [k][d]
+Elnb = [[[mp.mpf("-0.2"), mp.mpf("-0.9")], [mp.mpf("-1.1"), mp.mpf("0.3")]],              # [i][j][k]
+        [[mp.mpf("0.5"), mp.mpf("0.1")], [mp.mpf("-0.1"), mp.mpf("-0.4")]]]
+phis = []
+for d in range(2):
+    cols = []
+    for w in range(2):
+        v = X_ILDA[d][w][0] - 1
+        col = [mp.e ** (Elnth[k][d] + sum(Elnb[i][ILDA_FEATURES[v][i] - 1][k] for i in range(2))) for k in range(2)]
+        tot = sum(col)
+        cols.append([c / tot for c in col])
+    phis.append([[f(cols[w][k]) for w in range(2)] for k in range(2)])                    # K x W
+out["ilda_update_phi"] = {"ref": "test/ilda.jl:53-93", "Elntheta": [[0.5, -1.1], [2.3, -0.7]],
+                          "Elnbeta": [[[-0.2, -0.9], [-1.1, 0.3]], [[0.5, 0.1], [-0.1, -0.4]]], "phi": phis}
+eta_t = [mp.mpf("0.1"), mp.mpf("0.2")]
+phi_t = [[[mp.mpf("0.4"), mp.mpf("0.2")], [mp.mpf("0.6"), mp.mpf("0.8")]], [[mp.mpf("0.1"), mp.mpf("0.6")], [mp.mpf("0.9"), mp.mpf("0.4")]]]   # [d][k][w]
+lam_i = []
+Eln_i = []
+for i in range(2):
+    lam = [[eta_t[i] for _ in range(2)] for _ in range(2)]                                # [j][k]
+    for d in range(2):
+        for w in range(2):
+            v = X_ILDA[d][w][0] - 1; n = X_ILDA[d][w][1]
+            j = ILDA_FEATURES[v][i] - 1
+            for k in range(2):
+                lam[j][k] += phi_t[d][k][w] * n
+    lam_i.append([[f(lam[j][k]) for k in range(2)] for j in range(2)])
+    Eln_i.append([[f(psi(lam[j][k]) - psi(lam[0][k] + lam[1][k])) for k in range(2)] for j in range(2)])
+out["ilda_update_lambda"] = {"ref": "test/ilda.jl:114-160", "eta": [0.1, 0.2], "phi": [[[0.4, 0.2], [0.6, 0.8]], [[0.1, 0.6], [0.9, 0.4]]],
+                             "lambda": lam_i, "Elnbeta": Eln_i}
+g_t = [mp.mpf("0.1") + mp.mpf("0.4") * 5 + mp.mpf("0.2") * 8, mp.mpf("0.1") + mp.mpf("0.6") * 5 + mp.mpf("0.8") * 8]
+out["ilda_update_gamma"] = {"ref": "test/ilda.jl:95-112", "phi_doc1": [[0.4, 0.2], [0.6, 0.8]], "gamma_doc1": fl(g_t),
+                            "Elntheta_doc1": fl([psi(g_t[0]) - psi(g_t[0] + g_t[1]), psi(g_t[1]) - psi(g_t[0] + g_t[1])])}
+out["corpora"]["X_ilda"] = X_ILDA
+out["corpora"]["features_ilda"] = ILDA_FEATURES
+
 here = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(here, "reference_kats.json"), "w") as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
