@@ -341,11 +341,12 @@ __device__ void lda_pass_tail(const ReduceArgs& r)
 __global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
 {
     __shared__ double sm[64][17];
-    if (r.ctl->stop) return;
+    const int stop = r.ctl->stop;        // only the stores depend on it: the partial loads below are issued alongside this load
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int e = blockIdx.x * 16 + tx;
     double acc = 0.0;
     if (e < r.VK) for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
+    if (stop) return;
     sm[ty][tx] = acc;
     __syncthreads();
     if (ty < 8) {
@@ -374,11 +375,16 @@ __global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
 // ll_{t-1}, the stopping rule and the pass counter.
 __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
 {
-    if (r.ctl->stop) return;
+    const int stop = r.ctl->stop;
     const int k = blockIdx.x, lane = threadIdx.x, c = r.t % 3;
+    if (k == (int)gridDim.x - 1) {      // the extra block: pass tail, concurrent with the topic blocks (its loads are a dependent chain)
+        if (!stop && lane == 0) lda_pass_tail(r);
+        return;
+    }
     const double* sums = r.stats + (size_t)k * V;
     double part = 0.0;
     for (int v = lane; v < V; v += 64) part += eta + sums[v];
+    if (stop) return;
     const double cs = wave_sum(part);
     const double psi = dev_digamma_pos(cs);
     for (int v = lane; v < V; v += 64) {
@@ -387,7 +393,6 @@ __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double et
         const size_t e = (size_t)k * V + v;
         lambda.s[c][e] = l; Elnbeta.s[c][e] = el; expElnbeta.s[c][e] = exp(el); beta.s[c][e] = l / cs;
     }
-    if (k == 0 && lane == 0) lda_pass_tail(r);
 }
 
 // ---- ILDA (src/ILDA.jl): LDA whose topic-term distribution factorises over I features of the term, beta_kv = prod_i
@@ -1023,7 +1028,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
                                m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0);
             hipLaunchKernelGGL(k_lda_tail_only, dim3(1), dim3(1), 0, ctx->stream, r);
         } else
-            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
                                m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
