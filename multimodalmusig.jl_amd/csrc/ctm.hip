@@ -215,16 +215,21 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
     constexpr int G = MMM_WAVE / L;
     const CtmDims& dm = a.c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
-    {   // replica r = blockIdx.y of a batched launch works on the r-th copy of every per-model array
-        const size_t r = blockIdx.y;
-        if (a.active && !a.active[r]) return;
-        a.invSigma += r * MK * MK; a.mu += r * MK; a.lam_in += r * D * MK; a.nu += r * D * MK; a.zeta += r * D * M; a.sumth += r * D * MK;
-        if (a.expE) a.expE += r * GT;
-        if (a.lam_out) a.lam_out += r * D * MK;
-        if (a.partial) a.partial += r * gridDim.x * GT;
-        if (a.nev_nu) a.nev_nu += r * D;
-        if (a.nev_lam) a.nev_lam += r * D;
-    }
+    // replica r = blockIdx.y of a batched launch works on the r-th copy of every per-model array.  The kernel arguments are
+    // NOT modified in place: that would force the whole struct into scratch and turn its scalar loads into private-memory loads.
+    const size_t rep = blockIdx.y;
+    if (a.active && !a.active[rep]) return;
+    const double* __restrict__ p_invSigma = a.invSigma + rep * MK * MK;
+    const double* __restrict__ p_mu = a.mu + rep * MK;
+    const double* p_lam_in = a.lam_in + rep * D * MK;
+    double* p_lam_out = a.lam_out ? a.lam_out + rep * D * MK : nullptr;
+    double* p_nu = a.nu + rep * D * MK;
+    double* p_zeta = a.zeta + rep * D * M;
+    double* p_sumth = a.sumth + rep * D * MK;
+    const double* __restrict__ p_expE = a.expE ? a.expE + rep * GT : nullptr;
+    double* p_partial = a.partial ? a.partial + rep * gridDim.x * GT : nullptr;
+    int* p_nev_nu = a.nev_nu ? a.nev_nu + rep * D : nullptr;
+    int* p_nev_lam = a.nev_lam ? a.nev_lam + rep * D : nullptr;
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / L, l = lane % L;
@@ -236,10 +241,10 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
     double* sB = sScr + (size_t)NW * G * 2 * L;        // [GT]      (PH 0)
     double* sSlab = sB + GT;                           // [NW][GT]  (PH 0, F_SLAB)
     if (PH == 1) {
-        for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = a.invSigma[i];
-        for (int i = tid; i < MK; i += blockDim.x) sMu[i] = a.mu[i];
+        for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = p_invSigma[i];
+        for (int i = tid; i < MK; i += blockDim.x) sMu[i] = p_mu[i];
     } else {
-        if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = a.expE[i];
+        if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = p_expE[i];
         if (flags & F_SLAB) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
     }
     __syncthreads();
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
         const int d = base + g;
         const bool valid = d < D;
         const bool act = valid && l < MK;
-        double lam = act ? a.lam_in[(size_t)d * MK + l] : 0.0;
-        double nu = act ? a.nu[(size_t)d * MK + l] : 1.0;
+        double lam = act ? p_lam_in[(size_t)d * MK + l] : 0.0;
+        double nu = act ? p_nu[(size_t)d * MK + l] : 1.0;
         const double Nl = act ? a.c.Ndm[(size_t)d * M + mod_l] : 0.0;
         // ---- update_ζ! (MMCTM.jl:172-181) -------------------------------------------------------------------------
         double zl = 1.0;
@@ -263,13 +268,13 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
             for (int m = 0; m < M; ++m) {
                 const double zm = group_sum<L>((act && mod_l == m) ? E : 0.0);
                 if (mod_l == m) zl = zm;
-                if (valid && l == m) a.zeta[(size_t)d * M + m] = zm;
+                if (valid && l == m) p_zeta[(size_t)d * M + m] = zm;
             }
-        } else if (act) zl = a.zeta[(size_t)d * M + mod_l];
+        } else if (act) zl = p_zeta[(size_t)d * M + mod_l];
         const double cl = Nl / zl;                                   // Ndivζ (MMCTM.jl:119-125)
         // ---- update_θ! (MMCTM.jl:183-198) and sumθ (MMCTM.jl:110-117) ------------------------------------------------
         double sumth = 0.0;
-        if (PH == 1) sumth = act ? a.sumth[(size_t)d * MK + l] : 0.0;
+        if (PH == 1) sumth = act ? p_sumth[(size_t)d * MK + l] : 0.0;
         if (PH == 0 && (flags & (F_THETA_COMPUTE | F_THETA_STORED))) {
             double mx = 0.0;
             for (int m = 0; m < M; ++m) {
@@ -323,26 +328,26 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
                 }
             }
         }
-        if (PH == 0) { if (act) a.sumth[(size_t)d * MK + l] = sumth; continue; }
+        if (PH == 0) { if (act) p_sumth[(size_t)d * MK + l] = sumth; continue; }
         SolveOpts o = a.opt;
         // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ ----------------
         if (flags & F_NU) {
             NuObj obj{lam, cl, act ? sS[l * MK + l] : 1.0, act};
             const int nev = mma_group<L>(obj, act, g, nu, true, o.nu_lower, o);
-            if (act) a.nu[(size_t)d * MK + l] = nu;
-            if (a.nev_nu && valid && l == 0) a.nev_nu[d] = nev;
+            if (act) p_nu[(size_t)d * MK + l] = nu;
+            if (p_nev_nu && valid && l == 0) p_nev_nu[d] = nev;
         }
         // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν ---------------------------------------------
         if (flags & F_LAMBDA) {
             LamObj obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
             const int nev = mma_group<L>(obj, act, g, lam, false, 0.0, o);
-            if (act) a.lam_out[(size_t)d * MK + l] = lam;
-            if (a.nev_lam && valid && l == 0) a.nev_lam[d] = nev;
+            if (act) p_lam_out[(size_t)d * MK + l] = lam;
+            if (p_nev_lam && valid && l == 0) p_nev_lam[d] = nev;
         }
     }
     if (PH == 0 && (flags & F_SLAB)) {
         __syncthreads();
-        double* out = a.partial + (size_t)blockIdx.x * GT;
+        double* out = p_partial + (size_t)blockIdx.x * GT;
         for (int i = tid; i < GT; i += blockDim.x) {
             double s = 0.0;
             for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * GT + i];
@@ -478,15 +483,22 @@ struct MstepArgs {
     int nalpha;
 };
 
-__device__ __forceinline__ bool mstep_replica(MstepArgs& a)
+// the per-replica pointers of a batched M-step launch.  They are formed in locals (registers); the argument struct itself
+// stays untouched in the kernarg segment, so that its dimension arrays keep being read with scalar loads.
+struct MstepPtrs {
+    const double* stats; double* mu; double* Sigma; double* invSigma; double* gamma; double* Elnphi; double* phi;
+    double* Eeff; double* expEeff; double* phieff; int* status; const double* alpha;
+};
+
+__device__ __forceinline__ bool mstep_replica(const MstepArgs& a, MstepPtrs& q)
 {
     const size_t r = blockIdx.y;
     if (a.active && !a.active[r]) return false;
     const size_t MK = a.dm.MK, GT = a.dm.GT, GM = a.GM;
-    a.stats += r * a.stats_stride; a.mu += r * MK; a.Sigma += r * MK * MK; a.invSigma += r * MK * MK;
-    a.gamma += r * GM; a.Elnphi += r * GM; if (a.phi) a.phi += r * GM;
-    a.Eeff += r * GT; a.expEeff += r * GT; a.phieff += r * GT; a.status += r;
-    a.tp.alpha += r * a.nalpha;
+    q.stats = a.stats + r * a.stats_stride; q.mu = a.mu + r * MK; q.Sigma = a.Sigma + r * MK * MK; q.invSigma = a.invSigma + r * MK * MK;
+    q.gamma = a.gamma + r * GM; q.Elnphi = a.Elnphi + r * GM; q.phi = a.phi ? a.phi + r * GM : nullptr;
+    q.Eeff = a.Eeff + r * GT; q.expEeff = a.expEeff + r * GT; q.phieff = a.phieff + r * GT; q.status = a.status + r;
+    q.alpha = a.tp.alpha + r * a.nalpha;
     return true;
 }
 
@@ -536,12 +548,13 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv;
-    if (!mstep_replica(a)) return;
+    MstepPtrs q;
+    if (!mstep_replica(a, q)) return;
     const CtmDims& dm = a.dm;
     const int MK = dm.MK, tid = threadIdx.x, nt = blockDim.x;
-    const double* sLam = a.stats; const double* sNu = a.stats + MK; const double* sLL = a.stats + 2 * MK;
+    const double* sLam = q.stats; const double* sNu = q.stats + MK; const double* sLL = q.stats + 2 * MK;
     // update_μ! (MMCTM.jl:200-202)
-    if (a.do_mu) { for (int i = tid; i < MK; i += nt) a.mu[i] = sLam[i] / a.Dglobal; }
+    if (a.do_mu) { for (int i = tid; i < MK; i += nt) q.mu[i] = sLam[i] / a.Dglobal; }
     __syncthreads();
     // update_Σ! (MMCTM.jl:204-212) from raw moments: (diag Σν + Σ (λ-μ)(λ-μ)') / D with the NEW μ
     if (a.do_sigma) {
@@ -549,16 +562,16 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
         for (int e = tid; e < MK * MK; e += nt) {
             const int i = e % MK, j = e / MK;
             // Σ_d (λ_i-μ_i)(λ_j-μ_j) = Σλλ' - μ_i Σλ_j - μ_j Σλ_i + D μ_i μ_j
-            const double mi = a.mu[i], mj = a.mu[j];
+            const double mi = q.mu[i], mj = q.mu[j];
             double v = sLL[e] - mi * sLam[j] - mj * sLam[i] + a.Dglobal * mi * mj;
             if (i == j) v += sNu[i];
             v /= a.Dglobal;
-            a.Sigma[e] = v; A[i * MK + j] = v;
+            q.Sigma[e] = v; A[i * MK + j] = v;
         }
         __syncthreads();
         block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
-        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; a.invSigma[e] = Ai[i * MK + j]; }
-        if (tid == 0 && s_sing) *a.status = 1;
+        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; q.invSigma[e] = Ai[i * MK + j]; }
+        if (tid == 0 && s_sing) *q.status = 1;
         __syncthreads();
     }
 }
@@ -568,11 +581,12 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
 __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
 {
     __shared__ double sh[4];
-    if (!mstep_replica(a)) return;
+    MstepPtrs q;
+    if (!mstep_replica(a, q)) return;
     const CtmDims& dm = a.dm;
     const CtmTopics& tp = a.tp;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const double* sG = a.stats + 2 * dm.MK + dm.MK * dm.MK;
+    const double* sG = q.stats + 2 * dm.MK + dm.MK * dm.MK;
     int m = 0;
     while (m + 1 < dm.M && (int)blockIdx.x >= dm.koff[m + 1]) ++m;
     const int k = blockIdx.x - dm.koff[m];
@@ -580,8 +594,8 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
     if (!tp.immctm) {
         double part = 0.0;
         for (int v = tid; v < Vm; v += nt) {
-            const double gm = a.gamma_from_stats ? tp.alpha[m] + sG[go + k * Vm + v] : a.gamma[go + k * Vm + v];
-            if (a.gamma_from_stats) a.gamma[go + k * Vm + v] = gm;
+            const double gm = a.gamma_from_stats ? q.alpha[m] + sG[go + k * Vm + v] : q.gamma[go + k * Vm + v];
+            if (a.gamma_from_stats) q.gamma[go + k * Vm + v] = gm;
             part += gm;
         }
         part = wave_sum(part);
@@ -590,12 +604,12 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
         const double cs = sh[0] + sh[1] + sh[2] + sh[3];
         const double pcs = dev_digamma(cs);
         for (int v = tid; v < Vm; v += nt) {
-            const double gm = a.gamma[go + k * Vm + v];
+            const double gm = q.gamma[go + k * Vm + v];
             const double el = dev_digamma(gm) - pcs;
-            a.Elnphi[go + k * Vm + v] = el; a.Eeff[go + k * Vm + v] = el; a.expEeff[go + k * Vm + v] = exp(el);
+            q.Elnphi[go + k * Vm + v] = el; q.Eeff[go + k * Vm + v] = el; q.expEeff[go + k * Vm + v] = exp(el);
             const double ph = gm / cs;
-            if (a.phi) a.phi[go + k * Vm + v] = ph;
-            a.phieff[go + k * Vm + v] = ph;
+            if (q.phi) q.phi[go + k * Vm + v] = ph;
+            q.phieff[go + k * Vm + v] = ph;
         }
     } else {
         const int mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
@@ -604,9 +618,9 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
         if (a.gamma_from_stats) for (int e = tid; e < SJ; e += nt) {
             int jj = e, i = 0;
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
-            double s = tp.alpha[ao + i];
+            double s = q.alpha[ao + i];
             for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
-            a.gamma[mg + k * SJ + e] = s;
+            q.gamma[mg + k * SJ + e] = s;
         }
         __syncthreads();
         // Elnphi[m][k][i][j] = psi(gamma) - psi(sum_j gamma)   (IMMCTM.jl:188-197)
@@ -614,8 +628,8 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             int jj = e, i = 0, jo = 0;
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
             double cs = 0.0;
-            for (int j = 0; j < tp.J[ao + i]; ++j) cs += a.gamma[mg + k * SJ + jo + j];
-            a.Elnphi[mg + k * SJ + e] = dev_digamma(a.gamma[mg + k * SJ + e]) - dev_digamma(cs);
+            for (int j = 0; j < tp.J[ao + i]; ++j) cs += q.gamma[mg + k * SJ + jo + j];
+            q.Elnphi[mg + k * SJ + e] = dev_digamma(q.gamma[mg + k * SJ + e]) - dev_digamma(cs);
         }
         __syncthreads();
         // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
@@ -624,12 +638,12 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             for (int i = 0; i < nf; ++i) {
                 const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
                 double cs = 0.0;
-                for (int j = 0; j < Ji; ++j) cs += a.gamma[mg + k * SJ + jo + j];
-                se += a.Elnphi[mg + k * SJ + jo + f];
-                pp *= a.gamma[mg + k * SJ + jo + f] / cs;
+                for (int j = 0; j < Ji; ++j) cs += q.gamma[mg + k * SJ + jo + j];
+                se += q.Elnphi[mg + k * SJ + jo + f];
+                pp *= q.gamma[mg + k * SJ + jo + f] / cs;
                 jo += Ji;
             }
-            a.Eeff[go + k * Vm + v] = se; a.expEeff[go + k * Vm + v] = exp(se); a.phieff[go + k * Vm + v] = pp;
+            q.Eeff[go + k * Vm + v] = se; q.expEeff[go + k * Vm + v] = exp(se); q.phieff[go + k * Vm + v] = pp;
         }
     }
 }
@@ -1059,7 +1073,7 @@ int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int g
     MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
                 m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
                 m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha};
-    a.tp.alpha += r0 * m->nalpha;
+    a.tp.alpha += r0 * m->nalpha;      // host-side copy of the argument struct: fine
     const size_t lds = sizeof(double) * 2 * MK * MK;
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
