@@ -85,13 +85,14 @@ struct NuObj {
     __device__ __forceinline__ double eval(double x, double& g) const
     {
         const double E = exp(lam + 0.5 * x);
-        g = act ? 0.5 * Sll + 0.5 * c * E - 1.0 / (2.0 * x) : 0.0;
-        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * log(x) : 0.0;
+        g = act ? 0.5 * Sll + 0.5 * c * E - dev_div(1.0, 2.0 * x) : 0.0;
+        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * dev_log_pos(x) : 0.0;
         return group_sum<L>(t);
     }
 };
 
 // lambda: f = 1/2 (x-mu)' S (x-mu) - x . sumtheta + sum c_i exp(x_i + nu_i/2)
+template <int MKT>      // MKT = sum K when known at compile time (the matrix-vector product unrolls fully), 0 = runtime
 struct LamObj {
     double nu, c, sumth, mu; bool act; int l, MK;
     const double* sS;     // [j*MK + i], symmetric
@@ -106,12 +107,23 @@ struct LamObj {
         double Sd = 0.0;
         if (act) {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // four independent chains, combined pairwise
-            int j = 0;
-            for (; j + 3 < MK; j += 4) {
-                s0 = fma(sS[j * MK + l], scr[j], s0); s1 = fma(sS[(j + 1) * MK + l], scr[j + 1], s1);
-                s2 = fma(sS[(j + 2) * MK + l], scr[j + 2], s2); s3 = fma(sS[(j + 3) * MK + l], scr[j + 3], s3);
+            if (MKT) {
+                const double* col = sS + l;                     // immediate LDS offsets: j * MKT * 8 bytes
+#pragma unroll
+                for (int j = 0; j + 3 < MKT; j += 4) {
+                    s0 = fma(col[j * MKT], scr[j], s0); s1 = fma(col[(j + 1) * MKT], scr[j + 1], s1);
+                    s2 = fma(col[(j + 2) * MKT], scr[j + 2], s2); s3 = fma(col[(j + 3) * MKT], scr[j + 3], s3);
+                }
+#pragma unroll
+                for (int j = MKT & ~3; j < MKT; ++j) s0 = fma(col[j * MKT], scr[j], s0);
+            } else {
+                int j = 0;
+                for (; j + 3 < MK; j += 4) {
+                    s0 = fma(sS[j * MK + l], scr[j], s0); s1 = fma(sS[(j + 1) * MK + l], scr[j + 1], s1);
+                    s2 = fma(sS[(j + 2) * MK + l], scr[j + 2], s2); s3 = fma(sS[(j + 3) * MK + l], scr[j + 3], s3);
+                }
+                for (; j < MK; ++j) s0 = fma(sS[j * MK + l], scr[j], s0);
             }
-            for (; j < MK; ++j) s0 = fma(sS[j * MK + l], scr[j], s0);
             Sd = (s0 + s1) + (s2 + s3);
         }
         const double E = exp(x + 0.5 * nu);
@@ -139,15 +151,15 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         const double sigma2 = sigma * sigma;
         const double u = grad * sigma2;
         const double v = fabs(grad) * sigma + 0.5 * rho;
-        const double q = u / (v * sigma);
-        double dx = (u / v) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+        const double q = dev_div(u, v * sigma);
+        double dx = dev_div(dev_div(u, v), -1.0 - dev_sqrt(fabs(1.0 - q * q)));
         double xc = x + dx;
         if (has_lb && xc < lb) xc = lb;
         if (xc > x + 0.9 * sigma) xc = x + 0.9 * sigma; else if (xc < x - 0.9 * sigma) xc = x - 0.9 * sigma;
         if (!act) xc = x;
         dx = xc - x;
         const double dx2 = dx * dx;
-        const double denominv = 1.0 / (sigma2 - dx2);
+        const double denominv = dev_div(1.0, sigma2 - dx2);
         const double gl = act ? (grad * (sigma2 * dx) + (fabs(grad) * sigma + 0.5 * rho) * dx2) * denominv : 0.0;
         const double wl = act ? 0.5 * dx2 * denominv : 0.0;
         const double gval = fbest + group_sum<L>(gl);
@@ -160,7 +172,7 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
             inner_done = gval >= fcur;
             if (fcur < fbest) { fbest = fcur; x = xc; grad = gcur; }
             if (nev >= cap) { done = true; capped = true; inner_done = false; }
-            else if (!inner_done && fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + (fcur - gval) / wval));
+            else if (!inner_done && fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval)));
         }
         // outer iteration finished in at least one group of this wave: NLopt's x-tolerance test on (xcur, xprev)
         if (__any(inner_done)) {
@@ -208,13 +220,13 @@ struct CtmEArgs {
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
 // PH = 1: the two LD_MMA solves (few registers, high occupancy: the solves are latency-bound dependent chains)
-template <int L, int PH>
+template <int L, int PH, int MKT = 0>
 __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;
     const CtmDims& dm = a.c.dm;
-    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    const int MK = MKT ? MKT : dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
     // replica r = blockIdx.y of a batched launch works on the r-th copy of every per-model array.  The kernel arguments are
     // NOT modified in place: that would force the whole struct into scratch and turn its scalar loads into private-memory loads.
     const size_t rep = blockIdx.y;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
         }
         // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν ---------------------------------------------
         if (flags & F_LAMBDA) {
-            LamObj obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
+            LamObj<MKT> obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
             const int nev = mma_group<L>(obj, act, g, lam, false, 0.0, o);
             if (act) p_lam_out[(size_t)d * MK + l] = lam;
             if (p_nev_lam && valid && l == 0) p_nev_lam[d] = nev;
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
         for (int64_t e = dp[d]; e < dp[d + 1]; ++e) sumth += theta[dm.toff[m] + (size_t)(e - dm.estart[m]) * Km + k] * (double)c.tc[e].y;
     }
     double g1, g2;
-    LamObj lo{v, cl, sumth, act ? mu[l] : 0.0, act, l, MK, sS, scr};
+    LamObj<0> lo{v, cl, sumth, act ? mu[l] : 0.0, act, l, MK, sS, scr};
     const double f1 = lo.eval<64>(x, g1);
     NuObj no{x, cl, act ? sS[l * MK + l] : 1.0, act};
     const double f2 = no.eval<64>(v, g2);
@@ -1003,11 +1015,11 @@ struct Scope { int rep0, nrep; const int* active; };
 inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
 inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
 
-template <int L, int PH>
+template <int L, int PH, int MKT = 0>
 int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L, PH>;
+    auto k = k_ctm_estep<L, PH, MKT>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
@@ -1031,6 +1043,11 @@ size_t solve_lds(const mmm_ctm* m)
 template <int PH>
 int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
+    if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
+        if (m->L == 16 && m->dm.MK == 10) return launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
+        if (m->L == 16 && m->dm.MK == 14) return launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
+        if (m->L == 32 && m->dm.MK == 28) return launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
+    }
     if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves, nrep);
     if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves, nrep);
     return launch_estep_L<64, PH>(m, a, lds, grid, waves, nrep);

@@ -61,6 +61,30 @@ __device__ __forceinline__ double dev_rcp(double x)
     return r;
 }
 
+// a / b, bit-identical to the compiler's IEEE division whenever no operand or intermediate leaves the normal range: the
+// same rcp + 2 Newton + residual-correction sequence, without the v_div_scale / v_div_fmas / v_div_fixup range handling
+// (8 instead of ~25 instructions).  For the MMA step algebra: all operands there are O(1e-7 .. 1e7).
+__device__ __forceinline__ double dev_div(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    y = fma(fma(-b, y, 1.0), y, y);
+    y = fma(fma(-b, y, 1.0), y, y);
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+// sqrt(x) for x = 0 or x in the normal range, the compiler's rsq-based sequence without its subnormal scaling
+__device__ __forceinline__ double dev_sqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = 0.5 * y;
+    const double r0 = fma(-h0, g0, 0.5);
+    const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+    const double g2 = fma(fma(-g1, g1, x), h1, g1);
+    const double g3 = fma(fma(-g2, g2, x), h1, g2);
+    return x == 0.0 ? 0.0 : g3;
+}
+
 // natural log for finite x > 0 (normal or subnormal-free inputs: probabilities and Dirichlet parameters), fdlibm-style:
 // x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))).
 // ~35 instructions (ocml's log is ~90); error < 2 ulp.
