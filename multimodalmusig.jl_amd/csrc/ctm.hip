@@ -515,53 +515,67 @@ __device__ __forceinline__ bool mstep_replica(const MstepArgs& a, MstepPtrs& q)
 }
 
 // in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; returns
-// log|det A| in *logdet (thread 0).  One block.
+// log|det A| in *logdet (thread 0).  One block of >= 64 threads, n <= 64.  Per column: wave 0 finds the pivot (lane = row,
+// butterfly arg-max, first maximum wins like a serial scan), one sweep swaps + scales the pivot row, one sweep eliminates;
+// threads keep a fixed (row-phase, column) assignment, so there is no integer division inside the loops.
 __device__ void block_inverse(int n, double* A, double* Ainv, double* logdet, int* singular, int* s_piv)
 {
+    __shared__ double s_col[64];
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < n * n; i += nt) Ainv[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    for (int i = tid; i < n * n; i += nt) Ainv[i] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) Ainv[i * n + i] = 1.0;
     if (tid == 0) { *logdet = 0.0; *singular = 0; }
+    const int j0 = tid % n, r0 = tid / n, rstep = nt / n;      // thread -> column j0, rows r0, r0 + rstep, ...
     __syncthreads();
     for (int c = 0; c < n; ++c) {
-        if (tid == 0) {
-            int p = c; double best = fabs(A[c * n + c]);
-            for (int r = c + 1; r < n; ++r) { const double v = fabs(A[r * n + c]); if (v > best) { best = v; p = r; } }
-            *s_piv = p;
-            if (!(best > 0.0)) *singular = 1;
-            *logdet += log(best);
-        }
-        __syncthreads();
-        const int p = *s_piv;
-        if (p != c) for (int j = tid; j < n; j += nt) {
-            double t = A[c * n + j]; A[c * n + j] = A[p * n + j]; A[p * n + j] = t;
-            t = Ainv[c * n + j]; Ainv[c * n + j] = Ainv[p * n + j]; Ainv[p * n + j] = t;
-        }
-        __syncthreads();
-        const double piv = A[c * n + c];
-        __syncthreads();
-        for (int j = tid; j < n; j += nt) { A[c * n + j] /= piv; Ainv[c * n + j] /= piv; }
-        __syncthreads();
-        for (int i = tid; i < n * n; i += nt) {
-            const int r = i / n, j = i % n;
-            if (r != c) {
-                const double f = A[r * n + c];
-                // column c of A is needed unchanged by every thread of this sweep: update it last
-                if (j != c) A[r * n + j] -= f * A[c * n + j];
-                Ainv[r * n + j] -= f * Ainv[c * n + j];
+        if (tid < 64) {
+            double best = (tid >= c && tid < n) ? fabs(A[tid * n + c]) : -1.0;
+            int p = tid;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int op = __shfl_xor(p, off, 64);
+                if (ob > best || (ob == best && op < p)) { best = ob; p = op; }
+            }
+            if (tid == 0) {
+                *s_piv = p;
+                if (!(best > 0.0)) *singular = 1;
+                *logdet += log(best);
             }
         }
         __syncthreads();
-        for (int r = tid; r < n; r += nt) if (r != c) A[r * n + c] = 0.0;
+        const int p = *s_piv;
+        const double piv = A[p * n + c];
+        __syncthreads();
+        // row c <- row p / piv, row p <- old row c  (A and Ainv); threads 0..n-1 and n..2n-1
+        if (tid < 2 * n) {
+            double* Mx = tid < n ? A : Ainv;
+            const int j = tid < n ? tid : tid - n;
+            const double top = Mx[c * n + j], low = Mx[p * n + j];
+            Mx[c * n + j] = low / piv;
+            if (p != c) Mx[p * n + j] = top;
+        }
+        __syncthreads();
+        if (tid < n) s_col[tid] = A[tid * n + c];       // column c of the swapped matrix, frozen for the sweep
+        __syncthreads();
+        if (r0 < rstep) {
+            const double ac = A[c * n + j0], ic = Ainv[c * n + j0];
+            for (int r = r0; r < n; r += rstep) {
+                if (r == c) continue;
+                const double f = s_col[r];
+                A[r * n + j0] = (j0 == c) ? 0.0 : A[r * n + j0] - f * ac;
+                Ainv[r * n + j0] -= f * ic;
+            }
+        }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
+// update_μ! / update_Σ! of one replica by the calling block (>= 128 threads); smem: 2 MK^2 doubles
+__device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv;
-    MstepPtrs q;
-    if (!mstep_replica(a, q)) return;
     const CtmDims& dm = a.dm;
     const int MK = dm.MK, tid = threadIdx.x, nt = blockDim.x;
     const double* sLam = q.stats; const double* sNu = q.stats + MK; const double* sLL = q.stats + 2 * MK;
@@ -586,6 +600,14 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
         if (tid == 0 && s_sing) *q.status = 1;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    MstepPtrs q;
+    if (!mstep_replica(a, q)) return;
+    ctm_gauss_mstep(a, q, smem);
 }
 
 // update_γ! / update_Elnϕ! / update_ϕ! (MMCTM.jl:214-250; IMMCTM.jl:188-223): one block per topic (m,k) -- topics are
@@ -765,15 +787,24 @@ __global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmT
 
 // props = softmax(lambda block) (MMCTM.jl:145-154) and per-modality ll numerators (MMCTM.jl:384-418); wave per document.
 // llpart[block][M]
+// gauss != 0: the launch carries one extra block (the last) that runs update_μ!/update_Σ! of the same pass -- the ll needs
+// only lambda and phi, the next E-step needs mu / Sigma^-1, so the 50 us single-block inversion hides behind the document sweep
 __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
-                                                        int compute_ll, const int* active)
+                                                        int compute_ll, const int* active, MstepArgs ga, int gauss)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double shw[kWavesS][kMaxM];
     const CtmDims& dm = c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
     if (active && !active[blockIdx.y]) return;
-    lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * gridDim.x * M;
+    const int ndoc_blocks = gauss ? gridDim.x - 1 : gridDim.x;
+    if (gauss && blockIdx.x == 0) {      // block 0: dispatched first, so the serial inversion starts with the sweep, not after it
+        MstepPtrs q;
+        if (mstep_replica(ga, q)) ctm_gauss_mstep(ga, q, smem);
+        return;
+    }
+    const int bx = (int)blockIdx.x - gauss;
+    lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * ndoc_blocks * M;
     if (props) props += (size_t)blockIdx.y * D * MK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double* sP = smem;                       // [GT]
@@ -784,7 +815,7 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
     double acc[kMaxM];
     for (int m = 0; m < kMaxM; ++m) acc[m] = 0.0;
-    for (int d = blockIdx.x * kWavesS + wid; d < D; d += gridDim.x * kWavesS) {
+    for (int d = bx * kWavesS + wid; d < D; d += ndoc_blocks * kWavesS) {
         const bool act = lane < MK;
         const double x = act ? lam[(size_t)d * MK + lane] : 0.0;
         double pr = 0.0;
@@ -819,7 +850,7 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     if (compute_ll) {
         if (lane == 0) for (int m = 0; m < M; ++m) shw[wid][m] = acc[m];
         __syncthreads();
-        if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)blockIdx.x * M + tid] = s; }
+        if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)bx * M + tid] = s; }
     }
 }
 
@@ -1083,14 +1114,21 @@ int reduce_partials(mmm_ctm* m, Scope sc, const double* part, int nslab, int n, 
     return MMM_OK;
 }
 
-int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
+MstepArgs mstep_args(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
 {
-    mmm_ctx* ctx = m->ctx;
     const size_t r0 = sc.rep0, MK = m->dm.MK, GT = m->dm.GT, GM = m->GM;
     MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
                 m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
                 m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha};
     a.tp.alpha += r0 * m->nalpha;      // host-side copy of the argument struct: fine
+    return a;
+}
+
+int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int gamma_from_stats)
+{
+    mmm_ctx* ctx = m->ctx;
+    const size_t MK = m->dm.MK;
+    const MstepArgs a = mstep_args(m, sc, do_mu, do_sigma, do_gamma, gamma_from_stats);
     const size_t lds = sizeof(double) * 2 * MK * MK;
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1153,15 +1191,18 @@ int materialise_theta(mmm_ctm* m)
 }
 
 // props (+ ll written to dst + r*dst_stride for every replica of the scope)
-int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool compute_ll)
+// gauss_mu / gauss_sigma: also run update_μ! / update_Σ! of the pass in an extra block of the same launch (see k_ctm_loglik)
+int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool compute_ll, int gauss_mu = 0, int gauss_sigma = 0)
 {
     mmm_ctx* ctx = m->ctx;
     const int M = m->dm.M;
     const size_t r0 = sc.rep0;
-    const size_t lds = sizeof(double) * ((size_t)m->dm.GT + kWavesS * 64);
+    const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
+    const size_t lds = sizeof(double) * std::max((size_t)m->dm.GT + kWavesS * 64, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(), m->phieff.p + r0 * m->dm.GT,
-                       m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active);
+    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
+                       m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
+                       mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
     MMM_LAUNCH_CHECK(ctx);
     if (!compute_ll) return MMM_OK;
     hipLaunchKernelGGL(k_sum_columns, dim3(M, sc.nrep), dim3(64), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->llnum.p + r0 * m->s_llnum,
@@ -1233,7 +1274,11 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     if ((rc = reduce_partials(m, sc, m->partial.p, m->grid_e, dm.GT, m->stats.p + m->nmom, m->s_stats))) return rc;
     if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
     // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!
-    if ((rc = run_mstep(m, sc, 1, (update_sigma || m->immctm) ? 1 : 0, 1, 1))) return rc;
+    // (the Gaussian part runs as an extra block of the log-likelihood launch below, beside the document sweep)
+    static const int fuse_env = getenv("MMM_CTM_FUSE_GAUSS") ? atoi(getenv("MMM_CTM_FUSE_GAUSS")) : -1;
+    const bool fuse = fuse_env >= 0 ? fuse_env != 0 : true;
+    const int do_sig = (update_sigma || m->immctm) ? 1 : 0;
+    if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, 1, 1))) return rc;
     if ((fit_flags & MMM_FIT_AUTO_ALPHA) && (rc = run_update_alpha(m, sc))) return rc;      // MMCTM.jl:472-474
     // update_props! and the log-likelihoods
     if ((rc = ensure_hist(m, 1))) return rc;
@@ -1241,7 +1286,8 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     int nh = 0;       // the replicas still running share one history length (fit_scope checks it)
     for (int i = 0; i < sc.nrep; ++i)
         if (!sc.active || m->h_active[sc.rep0 + i]) nh = std::max(nh, m->n_hist[sc.rep0 + i]);
-    if ((rc = run_loglik(m, sc, m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + nh) * M, (size_t)m->cap_hist * M, true))) return rc;
+    if ((rc = run_loglik(m, sc, m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + nh) * M, (size_t)m->cap_hist * M, true, fuse ? 1 : 0,
+                         fuse ? do_sig : 0))) return rc;
     for (int i = 0; i < sc.nrep; ++i) {
         const int r = sc.rep0 + i;
         if (sc.active && !m->h_active[r]) continue;
@@ -1823,12 +1869,11 @@ static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_s
         const int chunk = (pass == 0) ? std::min(maxiter, 11) : 1;
         for (int i = 0; i < chunk; ++i)
             if ((rc = infer_flags < 0 ? fused_pass(m, sc, update_sigma) : frozen_pass(m, sc, infer_flags))) return rc;
-        for (int i = 0; i < nrep; ++i) {
-            const int r = sc.rep0 + i;
-            if (batch && !m->h_active[r]) continue;
-            MMM_HIP(ctx, hipMemcpyAsync(ll.data() + ((size_t)i * maxiter + pass) * M, m->ll_hist.p + ((size_t)r * m->cap_hist + base[i] + pass) * M,
-                                        sizeof(double) * chunk * M, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        // the new rows of every replica of the scope in ONE strided copy (base is common to the scope; rows of replicas that
+        // have already stopped are stale and never read: done[i] bounds what is returned)
+        MMM_HIP(ctx, hipMemcpy2DAsync(ll.data() + (size_t)pass * M, sizeof(double) * maxiter * M,
+                                      m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + base[0] + pass) * M, sizeof(double) * m->cap_hist * M,
+                                      sizeof(double) * chunk * M, (size_t)nrep, hipMemcpyDeviceToHost, ctx->stream));
         if ((rc = check_status(m, sc))) return rc;
         pass += chunk;
         bool changed = false;
