@@ -10,7 +10,7 @@
 // between stores (the "LL" idea of collective libraries).  seq is a per-context call counter (identical on all ranks, which
 // issue the same calls in the same order); slot = seq & 1 suffices because a rank cannot start call s+2 before every rank
 // has finished reading call s (it needs their s+1 contributions, which they send after their call-s kernel has ended).
-// Every poll loop has a wall-clock exit (default 2 s): on expiry the kernel records the failure and ends, and the next
+// Every poll loop has a wall-clock exit (default 20 s): on expiry the kernel records the failure and ends, and the next
 // host synchronisation point reports it -- a lost peer cannot hang the GPU.
 //
 // Set-up is transport-agnostic: mmm_p2p_local_handle / mmm_p2p_attach exchange 64-byte IPC handles by whatever the host has.
@@ -99,7 +99,7 @@ static int p2p_alloc(mmm_ctx* ctx, int nranks)
     MMM_HIP(ctx, hipMemset(p->err, 0, sizeof(int)));
     MMM_HIP(ctx, hipDeviceSynchronize());
     p->args.nranks = nranks; p->args.cap = kP2PCap; p->args.err = p->err;
-    double secs = 2.0;
+    double secs = 20.0;      // generous: a peer may be loading code objects or be descheduled at start-up
     if (const char* s = getenv("MMM_P2P_TIMEOUT_S")) secs = std::max(0.001, atof(s));
     p->args.timeout_ticks = (unsigned long long)(secs * 1e8);
     ctx->p2p = p;
