@@ -443,23 +443,41 @@ __global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double
     // up to 4 output entries per thread (n <= 2*64 + 64*64 needs more: loop)
     for (int e0 = 0; e0 < n; e0 += 4 * blockDim.x) {
         double acc[4] = {0, 0, 0, 0};
+        // what each of this thread's entries reads: two LDS columns (a, b); kind 0: sum a (lambda or nu tile), 1: sum a*b
+        const double* pa[4]; const double* pb[4]; int kind[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * blockDim.x + threadIdx.x;
+            kind[q] = -1; pa[q] = sL; pb[q] = sL;
+            if (e < MK) { kind[q] = 0; pa[q] = sL + e; }
+            else if (e < 2 * MK) { kind[q] = 0; pa[q] = sN + (e - MK); }
+            else if (e < n) { kind[q] = 1; pa[q] = sL + (e - 2 * MK) % MK; pb[q] = sL + (e - 2 * MK) / MK; }
+        }
         for (int t0 = d0; t0 < d1; t0 += T) {
             const int nt = min(T, d1 - t0);
             __syncthreads();
-            for (int i = threadIdx.x; i < nt * MK; i += blockDim.x) { sL[i] = lam[(size_t)t0 * MK + i]; sN[i] = nu[(size_t)t0 * MK + i]; }
+            // a short last tile is zero-padded, so the sums below always run over T documents (compile-time trip count)
+            for (int i = threadIdx.x; i < T * MK; i += blockDim.x) {
+                const bool in = i < nt * MK;
+                sL[i] = in ? lam[(size_t)t0 * MK + i] : 0.0; sN[i] = in ? nu[(size_t)t0 * MK + i] : 0.0;
+            }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = e0 + q * blockDim.x + threadIdx.x;
-                if (e >= n) continue;
-                double s = 0.0;
-                if (e < MK) for (int d = 0; d < nt; ++d) s += sL[d * MK + e];
-                else if (e < 2 * MK) for (int d = 0; d < nt; ++d) s += sN[d * MK + (e - MK)];
-                else {
-                    const int i = (e - 2 * MK) % MK, j = (e - 2 * MK) / MK;
-                    for (int d = 0; d < nt; ++d) s = fma(sL[d * MK + i], sL[d * MK + j], s);
+                if (kind[q] < 0) continue;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // independent chains: the LDS reads pipeline
+                const double* A = pa[q]; const double* B = pb[q];
+                if (kind[q] == 0) {
+#pragma unroll 2
+                    for (int d = 0; d < T; d += 4) { s0 += A[d * MK]; s1 += A[(d + 1) * MK]; s2 += A[(d + 2) * MK]; s3 += A[(d + 3) * MK]; }
+                } else {
+#pragma unroll 2
+                    for (int d = 0; d < T; d += 4) {
+                        s0 = fma(A[d * MK], B[d * MK], s0); s1 = fma(A[(d + 1) * MK], B[(d + 1) * MK], s1);
+                        s2 = fma(A[(d + 2) * MK], B[(d + 2) * MK], s2); s3 = fma(A[(d + 3) * MK], B[(d + 3) * MK], s3);
+                    }
                 }
-                acc[q] += s;
+                acc[q] += (s0 + s1) + (s2 + s3);
             }
         }
 #pragma unroll
@@ -514,11 +532,19 @@ __device__ __forceinline__ bool mstep_replica(const MstepArgs& a, MstepPtrs& q)
     return true;
 }
 
-// in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; returns
-// log|det A| in *logdet (thread 0).  One block of >= 64 threads, n <= 64.  Per column: wave 0 finds the pivot (lane = row,
-// butterfly arg-max, first maximum wins like a serial scan), one sweep swaps + scales the pivot row, one sweep eliminates;
-// threads keep a fixed (row-phase, column) assignment, so there is no integer division inside the loops.
+// in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; log|det A| in
+// *logdet.  One block of >= 2n threads, n <= 64.  (A single-wave variant -- lanes own columns, multipliers by readlane, no
+// block barriers -- was measured slower: 113 vs 59 us for the launch at n = 28; its row updates are LDS-latency bound.)
+__device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logdet, int* singular, int* s_piv);
+
 __device__ void block_inverse(int n, double* A, double* Ainv, double* logdet, int* singular, int* s_piv)
+{
+    block_inverse_wide(n, A, Ainv, logdet, singular, s_piv);
+}
+
+// Per column: wave 0 finds the pivot (lane = row, butterfly arg-max), one sweep swaps
+// + scales the pivot row, one sweep eliminates; threads keep a fixed (row-phase, column) assignment.
+__device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logdet, int* singular, int* s_piv)
 {
     __shared__ double s_col[64];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -548,7 +574,6 @@ __device__ void block_inverse(int n, double* A, double* Ainv, double* logdet, in
         const int p = *s_piv;
         const double piv = A[p * n + c];
         __syncthreads();
-        // row c <- row p / piv, row p <- old row c  (A and Ainv); threads 0..n-1 and n..2n-1
         if (tid < 2 * n) {
             double* Mx = tid < n ? A : Ainv;
             const int j = tid < n ? tid : tid - n;
@@ -557,7 +582,7 @@ __device__ void block_inverse(int n, double* A, double* Ainv, double* logdet, in
             if (p != c) Mx[p * n + j] = top;
         }
         __syncthreads();
-        if (tid < n) s_col[tid] = A[tid * n + c];       // column c of the swapped matrix, frozen for the sweep
+        if (tid < n) s_col[tid] = A[tid * n + c];
         __syncthreads();
         if (r0 < rstep) {
             const double ac = A[c * n + j0], ic = Ainv[c * n + j0];
@@ -842,7 +867,7 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
                 const int2 t = c.tc[start + w];
                 double p = 0.0;
                 for (int k = 0; k < Km; ++k) p = fma(sPr[off + k], tb[k * Vm + t.x], p);
-                a += (double)t.y * log(p);
+                a += (double)t.y * dev_log_pos(p);
             }
             acc[m] += wave_sum(a);
         }
@@ -1436,7 +1461,8 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     m->waves_s = 4;
     m->grid_v = std::max(1, std::min((D + m->waves_s * G - 1) / (m->waves_s * G), ctx->num_cu * 8));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
-    m->grid_m = std::max(1, std::min((D + 127) / 128, 512));
+    m->grid_m = std::max(1, std::min((D + 31) / 32, 1024));      // one 32-document tile per block while the reduce stays small
+    if (const char* gm = getenv("MMM_CTM_GRID_M")) m->grid_m = std::max(1, atoi(gm));
     const size_t MK = dm.MK, DMK = (size_t)D * MK, Rz = (size_t)R;
     m->nmom = 2 * dm.MK + dm.MK * dm.MK; m->nalpha = nalpha;
     m->s_stats = (size_t)m->nmom + dm.GT + 16;
