@@ -67,6 +67,9 @@ int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n);
  * begin and end every launch of it is bracketed by an event pair; end synchronises and returns the number of
  * launches and the sum of their durations in milliseconds. */
 int mmm_ctx_profile_begin(mmm_ctx* ctx);
+/* repeat = 2: every profiled span holds the (idempotent) LDA E-step kernel twice; the difference of the spans measured with
+ * repeat 2 and repeat 1 is the kernel's duration without the ~4 us that an event pair adds around a single launch. */
+int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat);
 int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 
 /* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------

@@ -48,6 +48,7 @@ _SIGS = {
     "mmm_ctx_stream": (vp, [vp]),
     "mmm_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "mmm_ctx_profile_begin": (C.c_int, [vp]),
+    "mmm_ctx_profile_repeat": (C.c_int, [vp, C.c_int]),
     "mmm_ctx_profile_end": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
@@ -160,7 +161,8 @@ class Context:
         check(lib().mmm_ctx_device_name(self.h, b, 64), self.h)
         return b.value.decode()
 
-    def profile_begin(self):
+    def profile_begin(self, repeat=1):
+        check(lib().mmm_ctx_profile_repeat(self.h, int(repeat)), self.h, "mmm_ctx_profile_repeat")
         check(lib().mmm_ctx_profile_begin(self.h), self.h, "mmm_ctx_profile_begin")
 
     def profile_end(self):

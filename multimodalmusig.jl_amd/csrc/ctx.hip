@@ -80,6 +80,14 @@ int mmm_ctx_profile_begin(mmm_ctx* ctx)
     return MMM_OK;
 }
 
+int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, repeat >= 1 && repeat <= 4, "mmm_ctx_profile_repeat: repeat must be 1..4");
+    ctx->prof_repeat = repeat;
+    return MMM_OK;
+}
+
 int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms)
 {
     if (!ctx || !n_launches || !total_ms) return MMM_ERR_ARG;

@@ -29,6 +29,7 @@ struct mmm_ctx {
     char arch[64] = {0};
     // HIP-event spans around the dominant kernel (mmm_ctx_profile_begin/end)
     bool profiling = false;
+    int prof_repeat = 1;          // launches of the dominant kernel inside each profiled span (differential timing)
     std::vector<hipEvent_t> ev;   // pairs: ev[2i] start, ev[2i+1] stop
     size_t ev_used = 0;
 };
