@@ -367,3 +367,47 @@ def test_fit_autoalpha_matches_oracle(mmm, oracle, case):
         a0 = b.select(0).α.copy(); a1 = b.select(1).α.copy()
         s0 = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], X, γ0=g0[0]); mmm.fit(s0, maxiter=6, tol=0.0, verbose=False, autoα=True)
         assert np.array_equal(a0, s0.α) and not np.array_equal(a0, a1)
+
+
+# ------------------------------------------------------------------------------------------ degenerate shapes
+@pytest.mark.parametrize("case", ["one_doc", "k1", "empty_modality", "wide_vocab", "heavy_counts"])
+def test_degenerate_shapes_against_oracle(mmm, oracle, case):
+    """Shapes at the edges of what the kernels are built for: a single document, one-topic modalities (theta = 1), a modality that
+    is empty in every document (its ll is 0/0 = NaN in the reference, MMCTM.jl:415, and stays NaN here), a vocabulary much wider
+    than a wave, counts in the tens of thousands."""
+    rng = np.random.default_rng(3)
+    if case == "one_doc":
+        K, V = [3, 2], [12, 9]
+        X = [[np.array([[1, 4], [5, 2], [12, 7]]), np.array([[2, 1], [9, 3]])]]
+    elif case == "k1":
+        K, V = [1, 1, 4], [10, 6, 8]
+        X, _ = np_ref.synth_mm(20, V, K, seed=5, means=[80, 40, 60])
+    elif case == "empty_modality":
+        K, V = [3, 2], [15, 7]
+        X, _ = np_ref.synth_mm(18, V, K, seed=6, means=[120, 30])
+        X = [[d[0], np.zeros((0, 2), dtype=np.int64)] for d in X]
+    elif case == "wide_vocab":
+        K, V = [4, 3], [700, 260]
+        X, _ = np_ref.synth_mm(25, V, K, seed=7, means=[4000, 900])
+    else:
+        K, V = [5, 3], [40, 24]
+        X, _ = np_ref.synth_mm(16, V, K, seed=8, means=[60000, 25000])
+    D, M, MK = len(X), len(K), sum(K)
+    g0 = [rng.integers(1, 101, size=(K[m], V[m])).astype(np.float64) for m in range(M)]
+    g = mmm.MMCTM(K, [0.1] * M, V, X, γ0=g0)
+    o = oracle.CtmOracle(K, [0.1] * M, X, V=V, gamma0=np.concatenate([x.ravel() for x in g0]))
+    for it in range(2):
+        mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        o.estep_range(0, D); o.update_mu(); assert o.update_Sigma() == 0; o.update_gamma(); o.update_props(); o.update_phi()
+        _robust_close(g.lam_matrix(), o.lam.reshape(D, MK), frac=0.9 if D > 4 else 1.0, loose=2e-2)
+        np.testing.assert_allclose(g._get("zeta").reshape(D, M), o.zeta.reshape(D, M), rtol=1e-4)
+        np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=1e-3)
+    np.testing.assert_allclose(g._get("theta"), o.theta, rtol=1e-4, atol=1e-12)
+    ll_g, ll_o = mmm.calculate_loglikelihoods(g), o.loglik()
+    if case == "empty_modality":
+        assert np.isnan(ll_g[1]) and np.isnan(ll_o[1])
+        np.testing.assert_allclose(ll_g[0], ll_o[0], rtol=1e-5)
+    else:
+        np.testing.assert_allclose(ll_g, ll_o, rtol=1e-5)
+        assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
+    assert g.solver_stats()["n_capped"] == 0
