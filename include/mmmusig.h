@@ -1,6 +1,7 @@
 /*
  * mmmusig.h -- C ABI of libmmmusig_hip.so: the MI355X (gfx950) variational-EM backend that sits under the
- * MultiModalMuSig.jl API (LDA / MMCTM / IMMCTM, fit!).
+ * MultiModalMuSig.jl API (LDA / ILDA / MMCTM / IMMCTM: fit!, the update_*! functions, transform, fit_heldout,
+ * predict_modality_η, and the restart sweep of scripts/run_mmctm.jl as batched fits).
  *
  * The reference has no FFI: its hot path is reached by ordinary Julia dispatch.  Each entry point below
  * therefore names the Julia function (file:line under the reference's src/) whose work it replaces; the Julia
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MMM_VERSION 100
+#define MMM_VERSION 110
 
 enum {
     MMM_OK = 0,
