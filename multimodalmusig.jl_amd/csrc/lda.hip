@@ -317,6 +317,9 @@ struct ReduceArgs {
     double Nglobal, tol;
     double* ll_hist;
     int do_ll, conv_base, run_tail;
+    // several GPUs with the mailboxes up: k_lda_reduce sends its entries to the peers as it produces them and k_lda_mstep sums
+    // the contributions in rank order as it consumes them -- the all-reduce costs no launch of its own
+    int p2p; unsigned int p2p_seq; P2PArgs px;
 };
 
 // ll_{t-1}, the convergence test of common.jl:53-56 after > 10 values (LDA.jl:215) and t += 1 (one thread)
@@ -361,12 +364,13 @@ __global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
         r.stats[e] = v;
+        if (r.p2p) p2p_send(r.px, r.p2p_seq, e, v);
     }
     if (blockIdx.x == 0 && ty == 1) {       // wave 1 of block 0: ll numerator of pass t-1
         double v = 0.0;
         for (int i = tx + 16 * 0; i < r.nslab; i += 16) v += r.llpart[i];
         v = group_sum<16>(v);
-        if (tx == 0) r.stats[r.VK] = v;
+        if (tx == 0) { r.stats[r.VK] = v; if (r.p2p) p2p_send(r.px, r.p2p_seq, r.VK, v); }
     }
 }
 
@@ -378,10 +382,15 @@ __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double et
     const int stop = r.ctl->stop;
     const int k = blockIdx.x, lane = threadIdx.x, c = r.t % 3;
     if (k == (int)gridDim.x - 1) {      // the extra block: pass tail, concurrent with the topic blocks (its loads are a dependent chain)
-        if (!stop && lane == 0) lda_pass_tail(r);
+        if (!stop && lane == 0) {
+            if (r.p2p) r.stats[r.VK] = p2p_recv_sum(r.px, r.p2p_seq, r.VK, r.stats[r.VK]);
+            lda_pass_tail(r);
+        }
         return;
     }
-    const double* sums = r.stats + (size_t)k * V;
+    double* sums = r.stats + (size_t)k * V;
+    if (r.p2p && !stop)      // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
+        for (int v = lane; v < V; v += 64) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
     double part = 0.0;
     for (int v = lane; v < V; v += 64) part += eta + sums[v];
     if (stop) return;
@@ -1024,9 +1033,12 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         if (rc) return rc;
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
+        r.p2p = 0; r.p2p_seq = 0;
+        static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
+        if (fold && !m->ilda && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;
         hipLaunchKernelGGL(k_lda_reduce, dim3((VK + 15) / 16), dim3(16, 64), 0, ctx->stream, r);
         MMM_LAUNCH_CHECK(ctx);
-        if ((rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
+        if (!r.p2p && (rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
         if (m->ilda) {
             const int c = t % 3;
             hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,

@@ -93,6 +93,64 @@ struct DevBuf {
     void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
 
+// ---- xGMI mailbox all-reduce (p2p.hip): argument block and the two device-side halves, shared with kernels that fold the
+// exchange into their own epilogue / prologue (lda.hip) --------------------------------------------------------------
+constexpr int kP2PMaxRanks = 16;
+constexpr size_t kP2PCap = 8192;            // doubles per call (LDA: 961; CTM cfg 4: 2,450)
+
+struct P2PArgs {
+    unsigned long long* peer[kP2PMaxRanks];   // mailbox base of every rank (peer[rank] = the local one)
+    int nranks, rank;
+    size_t cap;
+    int* err;                                 // device word: sequence number of a call that timed out (0 = none)
+    unsigned long long timeout_ticks;         // s_memrealtime ticks (100 MHz)
+};
+
+#ifdef __HIPCC__
+// store `mine` as element e of call `seq` into every peer's mailbox (two 8-byte words, each tagged with seq)
+__device__ __forceinline__ void p2p_send(const P2PArgs& a, unsigned int seq, int e, double mine)
+{
+    const size_t slot = seq & 1u;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    const unsigned long long w0 = (bits & 0xffffffffull) | tag, w1 = (bits >> 32) | tag;
+    for (int p = 0; p < a.nranks; ++p) {
+        if (p == a.rank) continue;
+        unsigned long long* dst = a.peer[p] + ((slot * a.nranks + a.rank) * a.cap + e) * 2;
+        __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// element e of call `seq`: own value + the peers' contributions from the local mailbox, summed in rank order
+__device__ __forceinline__ double p2p_recv_sum(const P2PArgs& a, unsigned int seq, int e, double mine)
+{
+    const size_t slot = seq & 1u;
+    const int n = a.nranks, me = a.rank;
+    double sum = 0.0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool failed = false;
+    for (int r = 0; r < n; ++r) {
+        double v = mine;
+        if (r != me) {
+            const unsigned long long* src = a.peer[me] + ((slot * n + r) * a.cap + e) * 2;
+            unsigned long long x0, x1;
+            for (;;) {
+                x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned int)(x0 >> 32) == seq && (unsigned int)(x1 >> 32) == seq) break;
+                if (failed || __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            v = __longlong_as_double((long long)((x0 & 0xffffffffull) | (x1 << 32)));
+        }
+        sum += v;
+    }
+    if (failed) atomicExch(a.err, (int)seq);
+    return sum;
+}
+#endif
+
 // true when mmm_allreduce_sum really communicates.  A one-rank communicator is only exercised on request
 // (MMM_FORCE_RCCL=1: lets a single-GPU box run the RCCL path)
 inline bool mmm_comm_active(const mmm_ctx* ctx)
@@ -108,4 +166,6 @@ inline bool mmm_comm_active(const mmm_ctx* ctx)
 int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count);
 int mmm_p2p_setup_over_rccl(mmm_ctx* ctx);
 int mmm_p2p_check(mmm_ctx* ctx);
+// for kernels that fold the exchange in: the argument block and a fresh sequence number (false: p2p not in use / too large)
+bool mmm_p2p_begin(mmm_ctx* ctx, size_t count, P2PArgs* args, unsigned int* seq);
 void mmm_p2p_release(mmm_ctx* ctx);

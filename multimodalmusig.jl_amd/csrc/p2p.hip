@@ -20,54 +20,13 @@
 
 namespace {
 
-constexpr int kP2PMaxRanks = 16;
-constexpr size_t kP2PCap = 8192;            // doubles per call (LDA: 961; CTM cfg 4: 2,450)
-
-struct P2PArgs {
-    unsigned long long* peer[kP2PMaxRanks];   // mailbox base of every rank (peer[rank] = the local one)
-    int nranks, rank;
-    size_t cap;
-    int* err;                                 // device word: sequence number of a call that timed out (0 = none)
-    unsigned long long timeout_ticks;         // s_memrealtime ticks (100 MHz)
-};
-
 __global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, double* buf, int count, unsigned int seq)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
-    const int n = a.nranks, me = a.rank;
-    const size_t slot = seq & 1u;
     const double mine = buf[e];
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
-    const unsigned long long tag = (unsigned long long)seq << 32;
-    const unsigned long long w0 = (bits & 0xffffffffull) | tag, w1 = (bits >> 32) | tag;
-    for (int p = 0; p < n; ++p) {
-        if (p == me) continue;
-        unsigned long long* dst = a.peer[p] + ((slot * n + me) * a.cap + e) * 2;
-        __hip_atomic_store(dst, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    double sum = 0.0;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    bool failed = false;
-    for (int r = 0; r < n; ++r) {
-        double v = mine;
-        if (r != me) {
-            const unsigned long long* src = a.peer[me] + ((slot * n + r) * a.cap + e) * 2;
-            unsigned long long x0, x1;
-            for (;;) {
-                x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned int)(x0 >> 32) == seq && (unsigned int)(x1 >> 32) == seq) break;
-                if (failed || __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { failed = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            v = __longlong_as_double((long long)((x0 & 0xffffffffull) | (x1 << 32)));
-        }
-        sum += v;
-    }
-    if (failed) atomicExch(a.err, (int)seq);
-    buf[e] = sum;
+    p2p_send(a, seq, e, mine);
+    buf[e] = p2p_recv_sum(a, seq, e, mine);
 }
 
 } // namespace
@@ -136,6 +95,14 @@ static int p2p_launch(mmm_ctx* ctx, double* dev, size_t count)
     hipLaunchKernelGGL(k_p2p_allreduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, p->args, dev, (int)count, seq);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
+}
+
+bool mmm_p2p_begin(mmm_ctx* ctx, size_t count, P2PArgs* args, unsigned int* seq)
+{
+    if (!ctx->p2p || !ctx->p2p_on || ctx->nranks < 2 || count > kP2PCap) return false;
+    *args = ctx->p2p->args;
+    *seq = ++ctx->p2p->seq;
+    return true;
 }
 
 int mmm_allreduce_sum(mmm_ctx* ctx, double* dev, size_t count)
