@@ -89,3 +89,29 @@ def test_restart_driver_on_brca(mmm):
     assert np.all(np.isfinite(model.ll)) and np.isfinite(model.elbo)
     assert np.all(model.ll > all_ll.mean(axis=0) - 0.05)
     print("restart driver: stage-1 ll per restart\n%s\nbest per modality %s, stage-2 ll %s" % (all_ll, opt_ll, model.ll))
+
+
+def test_against_committed_golden_trajectories(mmm):
+    """The same two configurations against tests/golden/oracle_trajectories.json: a committed target that needs no oracle
+    build on the GPU box (generated by tests/golden/make_trajectories.py from the CPU oracle)."""
+    import json
+    traj = json.load(open(os.path.join(GOLD, "oracle_trajectories.json")))
+    samples, snv, sv = _tables(mmm)
+    t = traj["config1_lda_k7"]
+    lam0 = np.random.default_rng(t["lambda0_seed"]).integers(1, 101, size=(96, 7)).astype(np.float64)
+    g = mmm.LDA(7, 0.1, 0.1, mmm.format_counts_lda(snv, samples), λ0=lam0)
+    ll = mmm.fit(g, maxiter=t["maxiter"], tol=t["tol"], verbose=False)
+    assert len(ll) == len(t["ll"]) and g.converged == t["converged"]
+    np.testing.assert_allclose(ll, t["ll"], rtol=1e-9)
+    assert g.elbo == pytest.approx(t["elbo"], rel=1e-5)                     # the north-star tolerance
+    assert g.λ.sum() == pytest.approx(t["lambda_sum"], rel=1e-12)           # = eta V K + N: every count accounted for
+    np.testing.assert_allclose(g.θ[:, 0], t["theta_first_doc"], rtol=1e-5)
+    t = traj["config3_mmctm_77"]
+    rng = np.random.default_rng(t["gamma0_seed"])
+    g0 = [rng.integers(1, 101, size=(7, 96)).astype(np.float64), rng.integers(1, 101, size=(7, 48)).astype(np.float64)]
+    c = mmm.MMCTM([7, 7], [0.1, 0.1], [96, 48], mmm.format_counts_mmctm([snv, sv], samples), γ0=g0)
+    llc = mmm.fit(c, maxiter=t["maxiter"], tol=0.0, verbose=False)
+    np.testing.assert_allclose(llc[:3], np.asarray(t["ll"])[:3], rtol=1e-9)
+    np.testing.assert_allclose(llc, t["ll"], rtol=1e-4)                      # MMA stopping flips accumulate (DESIGN §2)
+    assert c.elbo == pytest.approx(t["elbo"], rel=1e-4)
+    assert c._get("gamma").sum() == pytest.approx(t["gamma_sum"], rel=1e-9)
