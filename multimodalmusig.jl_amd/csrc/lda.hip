@@ -418,11 +418,16 @@ struct IldaDesc {
 // mode 0: lambda = eta + folded sums (update_λ!, ILDA.jl:107-126); 1: from the stored lambda (update_Elnβ!/update_β!,
 // :97-104,128-130); 2: effective tables only, from the stored Elnbeta / beta (after an upload).  One wave per topic.
 __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const double* sums, double* ilam, double* iEln, double* ibeta,
-                                                   double* Eeff, double* expEeff, double* beff, const int* stop, int write_beta_only)
+                                                   double* Eeff, double* expEeff, double* beff, const int* stop, int write_beta_only,
+                                                   ReduceArgs tail, int with_tail)
 {
     __shared__ double sE[kIldaMaxSJ], sB[kIldaMaxSJ];
     if (stop && *stop) return;
     const int k = blockIdx.x, lane = threadIdx.x, V = ds.V, K = ds.K;
+    if (with_tail && k == K) {           // extra block of the fused pass: ll_{t-1}, stopping rule, pass counter (as k_lda_mstep)
+        if (lane == 0) lda_pass_tail(tail);
+        return;
+    }
     for (int i = 0; i < ds.I; ++i) {
         const int Ji = ds.J[i];
         const size_t base = (size_t)K * ds.joff[i] + (size_t)Ji * k;
@@ -431,13 +436,17 @@ __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const 
         for (int j0 = 0; j0 < Ji; j0 += 64) {
             const int j = j0 + lane;
             double l = 0.0;
-            if (j < Ji) {
-                if (mode == 0) {
-                    l = ds.eta[i];
-                    for (int v = 0; v < V; ++v) if (f[v] == j) l += sums[(size_t)k * V + v];
-                    ilam[base + j] = l;
-                } else l = ilam[base + j];
-            }
+            if (mode == 0) {
+                // fold the topic's V statistics onto this feature's values: all 64 lanes walk the terms, one butterfly sum per
+                // value (a lane-per-value loop over V global loads is a 60 us dependent chain)
+                for (int jj = j0; jj < min(Ji, j0 + 64); ++jj) {
+                    double t = 0.0;
+                    for (int v = lane; v < V; v += 64) t += (f[v] == jj) ? sums[(size_t)k * V + v] : 0.0;
+                    t = wave_sum(t);
+                    if (lane == jj - j0) l = ds.eta[i] + t;
+                }
+                if (j < Ji) ilam[base + j] = l;
+            } else if (j < Ji) l = ilam[base + j];
             part += l;
         }
         const double cs = wave_sum(part);
@@ -996,7 +1005,7 @@ int run_topic_update(mmm_lda* m, bool from_sums)
     if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->scratch.p, (size_t)m->V * m->K); if (rc) return rc; }
     if (m->ilda) {
         hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, from_sums ? 0 : 1, m->scratch.p, m->ilam[c].p, m->iEln[c].p,
-                           m->ibeta[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 0);
+                           m->ibeta[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 0, ReduceArgs{}, 0);
         MMM_LAUNCH_CHECK(ctx);
         return MMM_OK;
     }
@@ -1041,9 +1050,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (!r.p2p && (rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
         if (m->ilda) {
             const int c = t % 3;
-            hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
-                               m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0);
-            hipLaunchKernelGGL(k_lda_tail_only, dim3(1), dim3(1), 0, ctx->stream, r);
+            hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+                               m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0, r, 1);
         } else
             hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
                                m->ring(m->expElnbeta), m->ring(m->beta));
@@ -1234,7 +1242,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
     if (!ilda) hipLaunchKernelGGL(k_lda_topic, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda[0].p, m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, 0);
     else hipLaunchKernelGGL(k_ilda_mstep, dim3(K), dim3(64), 0, st, m->ids, 1, (const double*)nullptr, m->ilam[0].p, m->iEln[0].p, m->ibeta[0].p,
-                            m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, (const int*)nullptr, 0);      // ILDA.jl:36-40 (+ tables)
+                            m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, (const int*)nullptr, 0, ReduceArgs{}, 0);      // ILDA.jl:36-40 (+ tables)
     if (KD) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma[0].p, KD, 1.0);
         hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
@@ -1346,7 +1354,7 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     if (field == MMM_ILDA_ELNBETA || field == MMM_ILDA_BETA) {      // effective tables follow the uploaded factors
         const int c = m->cur();
         hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 2, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
-                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, field == MMM_ILDA_BETA ? 1 : 0);
+                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, field == MMM_ILDA_BETA ? 1 : 0, ReduceArgs{}, 0);
         MMM_LAUNCH_CHECK(ctx);
     }
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1397,7 +1405,7 @@ int mmm_lda_update_beta(mmm_lda* m)
     const int c = m->cur();
     if (m->ilda)
         hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, m->ctx->stream, m->ids, 1, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
-                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 1);
+                           m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 1, ReduceArgs{}, 0);
     else
     hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, m->ctx->stream, m->V, m->eta, (const double*)nullptr, m->lambda[c].p,
                        (double*)nullptr, (double*)nullptr, m->beta[c].p, 1);
