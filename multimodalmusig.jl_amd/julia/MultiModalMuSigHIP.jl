@@ -41,17 +41,16 @@ function check(rc::Cint, ctx::Context, what::String)
     nothing
 end
 
-# ---- count formatting (identical to src/utils.jl:1-36) --------------------------------------------------------------
+# ---- count formatting: same results as src/utils.jl:1-36 (a document = W x 2 matrix [1-based term id, count > 0]) ----------
+# sparse view of one count column: rows (term, count) for the terms that occur
 function make_count_matrix(counts)
-    idx = findall(counts .> 0)
-    countmat = Array{Int}(undef, length(idx), 2)
-    countmat[:, 1] = idx
-    countmat[:, 2] = counts[idx]
-    return countmat
+    terms = [t for t in eachindex(counts) if counts[t] > 0]
+    return Int[terms counts[terms]]
 end
-format_counts_lda(df::DataFrame, cols::Vector{Symbol}) = Matrix{Int}[make_count_matrix(convert(Array, df[!, c])) for c in cols]
+column(df::DataFrame, c::Symbol) = collect(df[!, c])
+format_counts_lda(df::DataFrame, cols::Vector{Symbol}) = Matrix{Int}[make_count_matrix(column(df, c)) for c in cols]
 format_counts_mmctm(dfs::Vector{DataFrame}, cols::Vector{Symbol}) =
-    Vector{Matrix{Int}}[Matrix{Int}[make_count_matrix(convert(Array, df[!, c])) for df in dfs] for c in cols]
+    Vector{Matrix{Int}}[Matrix{Int}[make_count_matrix(column(df, c)) for df in dfs] for c in cols]
 format_counts_ctm(df::DataFrame, cols::Vector{Symbol}) = format_counts_mmctm([df], cols)
 
 # CSR packing expected by the ABI: 0-based Int32 terms, Int32 counts, Int64 offsets
