@@ -148,10 +148,11 @@ def main():
 
     if rank == 0:
         docs_total = D * world * args.steps
-        # dominant kernel: k_lda_estep (fused E-step + lagged ll).  Algorithmic bytes per launch: 8 B per nonzero
-        # (term,count) + gamma_t and gamma_{t-1} reads + Elntheta and gamma_{t+1} writes (4 x 8 B x K per document);
-        # phi stays in registers, the topic tables (15 KB) are L2-resident and excluded.
-        algo_bytes = 8.0 * nnz + 32.0 * K * D
+        # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch: 8 B per nonzero
+        # (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in registers, the
+        # topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
+        # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
+        algo_bytes = 8.0 * nnz + 24.0 * K * D
         span1 = (k_ms / max(n_launch, 1)) * 1e-3
         span2 = (k_ms2 / max(n_launch2, 1)) * 1e-3
         avg_s = span2 - span1 if span2 > span1 > 0 else span1
@@ -166,7 +167,7 @@ def main():
                        "allreduce": ctx.transport},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_lda_estep<10,16,true,96>", "launches": n_launch, "avg_us": avg_s * 1e6,
+                         "kernel": "k_lda_estep<10,16,false,96,true>", "launches": n_launch, "avg_us": avg_s * 1e6,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "event_span_1_launch_us": span1 * 1e6, "event_span_2_launches_us": span2 * 1e6,
                          "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "

@@ -320,6 +320,9 @@ struct ReduceArgs {
     // several GPUs with the mailboxes up: k_lda_reduce sends its entries to the peers as it produces them and k_lda_mstep sums
     // the contributions in rank order as it consumes them -- the all-reduce costs no launch of its own
     int p2p; unsigned int p2p_seq; P2PArgs px;
+    // the log-likelihood of pass t-1 evaluated by extra blocks of the reduce launch (k_lda_reduce_ll) instead of inside the
+    // E-step kernel: per-block numerators in llpart2[n_ll], summed (and exchanged) by the pass-tail block
+    const double* llpart2; int n_ll, ll_in_k2;
 };
 
 // ll_{t-1}, the convergence test of common.jl:53-56 after > 10 values (LDA.jl:215) and t += 1 (one thread)
@@ -340,8 +343,86 @@ __device__ void lda_pass_tail(const ReduceArgs& r)
     r.ctl->ticket = 0;
 }
 
+// the pass-tail block (one wave) of the M-step launches: finishes the ll numerator of pass t-1 -- sum of the k_lda_reduce_ll
+// partials and/or the peers' share -- and runs lda_pass_tail
+__device__ __forceinline__ void lda_tail_block(const ReduceArgs& r, int lane)
+{
+    double v = 0.0;
+    if (r.ll_in_k2 && r.do_ll) {
+        for (int i = lane; i < r.n_ll; i += 64) v += r.llpart2[i];
+        v = wave_sum(v);
+    }
+    if (lane != 0) return;
+    if (r.ll_in_k2) {
+        if (r.do_ll) {
+            if (r.p2p) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
+            r.stats[r.VK] = v;
+        }
+    } else if (r.p2p) r.stats[r.VK] = p2p_recv_sum(r.px, r.p2p_seq, r.VK, r.stats[r.VK]);
+    lda_pass_tail(r);
+}
+
+// log-likelihood numerator of pass t-1 (LDA.jl:174-188 with theta_{t-1} = gamma_{t-1} / sum, beta_{t-1}) for the documents of
+// "ll block" lb of nlb, by a block of 16 waves laid out like k_lda_reduce's (16 x 64 threads): L lanes per document (as in the
+// E-step), 64/L documents per wave step, beta staged in LDS -- the ll half of the E-step's chunk loop, moved out of it.
+template <int KP, int L>
+__device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, const double* __restrict__ bprev, double* llpart2, int lb, int nlb,
+                             double* smem)
+{
+    __shared__ double s_w[16];
+    const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int G = MMM_WAVE / L;
+    const int g = lane / L, l = lane % L;
+    const int K = c.K, V = c.V, D = c.D;
+    double* sBeta = smem;
+    double* myT = smem + (size_t)KP * V + ((size_t)wid * G + g) * KP;
+    for (int i = tid; i < KP * V; i += 1024) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    for (int base = (lb * 16 + wid) * G; base < D; base += nlb * 16 * G) {
+        const int d = base + g;
+        const bool valid = d < D;
+        const double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+        const int64_t start = valid ? c.doc_ptr[d] : 0;
+        const int W = valid ? (int)(c.doc_ptr[d + 1] - start) : 0;
+        const int2* __restrict__ tcd = c.tc + start;
+        const double Sp = group_sum<L>(gp);
+        lds_wave_sync();
+        if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+        lds_wave_sync();
+        double tv[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) tv[k] = myT[k];
+        int nchmax = (W + L - 1) / L;
+        if (G >= 2) nchmax = max(nchmax, __shfl_xor(nchmax, 32, MMM_WAVE));
+        if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
+        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+        for (int j = 0; j < nchmax; ++j) {
+            const int w = j * L + l;
+            const bool act = w < W;
+            const int2 t = act ? tcd[w] : make_int2(0, 0);
+            const double* bc = sBeta + t.x;
+            double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
+            if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
+            const double p = act ? p0 + p1 : 1.0;
+            acc = fma((double)t.y, dev_log_pos(p), acc);
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s_w[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += s_w[w];
+        llpart2[lb] = v;
+    }
+}
+
 // grid = ceil(V*K/16) blocks of (16 entries, 64 slab lanes): fixed-order (deterministic) sum of the per-block partials
-__global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
+__device__ void lda_reduce_block(const ReduceArgs& r)
 {
     __shared__ double sm[64][17];
     const int stop = r.ctl->stop;        // only the stores depend on it: the partial loads below are issued alongside this load
@@ -366,12 +447,26 @@ __global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r)
         r.stats[e] = v;
         if (r.p2p) p2p_send(r.px, r.p2p_seq, e, v);
     }
-    if (blockIdx.x == 0 && ty == 1) {       // wave 1 of block 0: ll numerator of pass t-1
+    if (blockIdx.x == 0 && ty == 1 && !r.ll_in_k2) {       // wave 1 of block 0: ll numerator of pass t-1 (from the E-step's partials)
         double v = 0.0;
         for (int i = tx + 16 * 0; i < r.nslab; i += 16) v += r.llpart[i];
         v = group_sum<16>(v);
         if (tx == 0) { r.stats[r.VK] = v; if (r.p2p) p2p_send(r.px, r.p2p_seq, r.VK, v); }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_lda_reduce(ReduceArgs r) { lda_reduce_block(r); }
+
+// the same launch with the ll of pass t-1 riding along: blocks [0, nred) are k_lda_reduce's, blocks [nred, gridDim) evaluate the
+// log-likelihood numerators while the reduction -- 60 blocks -- leaves most of the chip idle
+template <int KP>
+__global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, double* llpart2, int nred)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x < nred) { lda_reduce_block(r); return; }
+    if (r.ctl->stop) return;
+    constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);       // K <= KP: the E-step's lane-group width (K = 16 -> KP = 16 -> 32 lanes)
+    lda_ll_block<KP, L>(c, gprev, bprev, llpart2, (int)blockIdx.x - nred, (int)gridDim.x - nred, smem);
 }
 
 // M-step of pass t from the (all-reduced) statistics, one wave per topic (no inter-block dependency: Elnbeta_k needs
@@ -382,10 +477,7 @@ __global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double et
     const int stop = r.ctl->stop;
     const int k = blockIdx.x, lane = threadIdx.x, c = r.t % 3;
     if (k == (int)gridDim.x - 1) {      // the extra block: pass tail, concurrent with the topic blocks (its loads are a dependent chain)
-        if (!stop && lane == 0) {
-            if (r.p2p) r.stats[r.VK] = p2p_recv_sum(r.px, r.p2p_seq, r.VK, r.stats[r.VK]);
-            lda_pass_tail(r);
-        }
+        if (!stop) lda_tail_block(r, lane);
         return;
     }
     double* sums = r.stats + (size_t)k * V;
@@ -425,7 +517,7 @@ __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const 
     if (stop && *stop) return;
     const int k = blockIdx.x, lane = threadIdx.x, V = ds.V, K = ds.K;
     if (with_tail && k == K) {           // extra block of the fused pass: ll_{t-1}, stopping rule, pass counter (as k_lda_mstep)
-        if (lane == 0) lda_pass_tail(tail);
+        lda_tail_block(tail, lane);
         return;
     }
     for (int i = 0; i < ds.I; ++i) {
@@ -804,7 +896,8 @@ struct mmm_lda {
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc;
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
-    DevBuf<double> partial, stats[2], scratch, llpart, elbopart, ll_hist;
+    DevBuf<double> partial, stats[2], scratch, llpart, llpart2, elbopart, ll_hist;
+    int n_ll = 0;               // ll blocks of the reduce launch
     DevBuf<LdaCtl> ctl;
     // host mirror of the device control block (exact after sync_ctl)
     int t = 0, n_hist = 0, cap_hist = 0;
@@ -1032,8 +1125,21 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         const int t = m->t + 1;
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
         const int from_stats = 0;
+        // Where the ll of pass t-1 is evaluated: in extra blocks of the reduce launch (the reduction occupies 60 CUs for ~6 us,
+        // the ll sweep fits beside it and the E-step kernel sheds 43 % of its chunk-loop instructions and half its table
+        // reads), unless the statistics go through ncclAllReduce -- then the numerator has to exist before that call and the
+        // E-step kernel keeps producing it.  MMM_LDA_LL_IN_ESTEP=1 forces the older placement (A/B).
+        static const bool ll_estep_env = getenv("MMM_LDA_LL_IN_ESTEP") != nullptr;
+        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
+        r.p2p = 0; r.p2p_seq = 0;
+        static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
+        if (fold && !m->ilda && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
+        const bool ll_in_k2 = !ll_estep_env && (r.p2p || !mmm_comm_active(ctx));
+        r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
+        const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
+        r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, do_ll, t, from_stats, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
+                    m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, from_stats, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
             ProfSpan span(ctx);
@@ -1041,11 +1147,16 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             for (int q = 0; q < reps && !rc; ++q) rc = launch_estep(m, a);
         }
         if (rc) return rc;
-        ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
-        r.p2p = 0; r.p2p_seq = 0;
-        static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
-        if (fold && !m->ilda && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;
-        hipLaunchKernelGGL(k_lda_reduce, dim3((VK + 15) / 16), dim3(16, 64), 0, ctx->stream, r);
+        const int nred = (VK + 15) / 16;
+        if (r.n_ll > 0) {
+            const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+            MMM_KP_SWITCH(m, {
+                auto k = k_lda_reduce_ll<KPV>;
+                if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_m = true; }
+                hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p,
+                                   m->llpart2.p, nred);
+            })
+        } else hipLaunchKernelGGL(k_lda_reduce, dim3(nred), dim3(16, 64), 0, ctx->stream, r);
         MMM_LAUNCH_CHECK(ctx);
         if (!r.p2p && (rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
         if (m->ilda) {
@@ -1215,7 +1326,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
-    A(partial, (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(elbopart, (size_t)m->grid_s * 5 + 8);
+    A(partial, (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1);
     if (ilda) {
         A(features, (size_t)I * V);

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -42,5 +43,8 @@ def _run(force):
 
 def test_one_rank_rccl_path_equals_plain_path():
     a, b = _run(False), _run(True)
-    assert a["ll"] == b["ll"] and a["elbo"] == b["elbo"] and a["lam"] == b["lam"]
+    # LDA: the statistics path is bitwise the same; the log-likelihood numerator is summed in a different order (with RCCL it
+    # has to exist before the ncclAllReduce call, so the E-step kernel produces it; otherwise extra blocks of the reduce launch do)
+    np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
+    assert a["elbo"] == b["elbo"] and a["lam"] == b["lam"]
     assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
