@@ -376,15 +376,23 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     const int K = c.K, V = c.V, D = c.D;
     double* sBeta = smem;
     double* myT = smem + (size_t)KP * V + ((size_t)wid * G + g) * KP;
+    // the first step's document loads go out before the table is staged (as in the E-step kernel)
+    int base = (lb * 16 + wid) * G;
+    int d = base + g;
+    bool valid = d < D;
+    double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+    int64_t start = valid ? c.doc_ptr[d] : 0;
+    int W = valid ? (int)(c.doc_ptr[d + 1] - start) : 0;
     for (int i = tid; i < KP * V; i += 1024) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
     __syncthreads();
     double acc = 0.0;
-    for (int base = (lb * 16 + wid) * G; base < D; base += nlb * 16 * G) {
-        const int d = base + g;
-        const bool valid = d < D;
-        const double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-        const int64_t start = valid ? c.doc_ptr[d] : 0;
-        const int W = valid ? (int)(c.doc_ptr[d + 1] - start) : 0;
+    for (; base < D; base += nlb * 16 * G) {
+        if (base != (lb * 16 + wid) * G) {
+            d = base + g; valid = d < D;
+            gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+            start = valid ? c.doc_ptr[d] : 0;
+            W = valid ? (int)(c.doc_ptr[d + 1] - start) : 0;
+        }
         const int2* __restrict__ tcd = c.tc + start;
         const double Sp = group_sum<L>(gp);
         lds_wave_sync();
