@@ -8,9 +8,9 @@
 //   phi        [nnz][K] (= per-doc K x W_d blocks, k fastest); materialised only when asked for
 //   ctl        device control block: ticket, stop flag, iteration counter t, ll-history length
 //
-// One outer iteration t (the body of fit!, LDA.jl:201-209) = TWO kernels on one GPU:
+// One outer iteration t (the body of fit!, LDA.jl:201-209) = THREE launches:
 //
-// k_lda_estep<KP, L> (dominant): a wave handles 64/L documents at a time, L lanes per document (L = 16 for
+// k_lda_estep<KP, L, LL, VT, SINGLE> (dominant): a wave handles 64/L documents at a time, L lanes per document (L = 16 for
 //   K <= 15), lanes over the document's nonzero terms.
 //   * Elntheta_k = psi(gamma_k) - psi(sum gamma) on the first K+1 lanes of the group (LDA.jl:78-80)
 //   * phi_kw = a_k B_vk / sum_k a_k B_vk with a_k = exp(Elntheta_k) (K exps per document) and B = exp(Elnbeta)
@@ -21,13 +21,15 @@
 //   * gamma of iteration t+1 (LDA.jl:85-87 uses the previous phi) = alpha + sum_w phi_kw n_w is formed in the
 //     same pass with DPP row reductions, so phi never round-trips through HBM inside the loop; phi is
 //     materialised on demand from (Elntheta_t, Elnbeta_{t-1}), which reproduces the stored phi
-//   * the log-likelihood of iteration t-1 (LDA.jl:174-188: needs beta_{t-1}, only known after M-step t-1) is
-//     evaluated in the same sweep from gamma_{t-1} and beta_{t-1} ("lagged ll"): one pass over X per
-//     iteration instead of two, and on several GPUs its numerator rides in the same all-reduce as lambda
-// k_lda_reduce_mstep: sums the per-block partials in fixed order (deterministic); the last block to arrive
-//   (agent-scope release/acquire + ticket) runs the M-step tail: lambda = eta + sums, Elnbeta, exp table, beta
-//   (LDA.jl:96-112), ll_{t-1}, the convergence test of common.jl:53-56 (device-side stop flag) and t += 1.
-//   With an RCCL communicator the tail is a third, one-block kernel after the all-reduce.
+//   * LL = true: also the log-likelihood numerator of iteration t-1 (LDA.jl:174-188: needs beta_{t-1}, only known after
+//     M-step t-1; "lagged ll") -- used when the statistics go through ncclAllReduce and by the frozen-topic passes
+// k_lda_reduce_ll / k_lda_reduce: blocks of (16 entries x 64 slab lanes) sum the per-block partials in fixed order
+//   (deterministic); with the mailbox transport they send each statistic to the peer GPUs as it is produced.  The "_ll"
+//   launch carries extra blocks that evaluate the lagged log-likelihood beside the reduction (default on one GPU and
+//   with the mailboxes).
+// k_lda_mstep: one wave per topic (receives the peers' statistics in rank order when folded): lambda = eta + sums,
+//   Elnbeta, exp table, beta (LDA.jl:96-112); an extra block finishes ll_{t-1}, applies the convergence test of
+//   common.jl:53-56 (device-side stop flag: later launches exit at once) and advances t.  ILDA: k_ilda_mstep instead.
 #include "dev_math.h"
 #include "mmm_internal.h"
 
@@ -64,43 +66,7 @@ struct EstepArgs {
     double* llpart;    // [gridDim]
     int do_ll;
     int t;             // this pass (1-based); the host's count, valid unless ctl->stop is set
-    // M-step of pass t-1 folded into this kernel's prologue (from_stats): every block rebuilds the exp(Elnbeta) and
-    // beta tables in LDS from the reduced statistics; block 0 also stores the topic state of pass t-1
-    int from_stats;
-    const double* stats_prev;
-    Ring lambda, Elnbeta;
 };
-
-// lambda = eta + sums, Elnbeta, exp(Elnbeta), beta for all topics (LDA.jl:96-112) by one block.  sLam/sExp: [KP*V] LDS
-// (sLam is overwritten with exp(Elnbeta)), sBet: [KP*V] LDS, sCol/sPsi: [K] LDS.  Optional global outputs.
-template <int KP>
-__device__ __forceinline__ void lda_topics_from_stats(int K, int V, double eta, const double* __restrict__ sums, double* sLam,
-                                                      double* sBet, double* sCol, double* sPsi, double* gl, double* gE,
-                                                      double* gX, double* gB)
-{
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
-    for (int e = tid; e < KP * V; e += nthr) sLam[e] = (e < K * V) ? eta + sums[e] : 1.0;
-    __syncthreads();
-    for (int k = wid; k < K; k += nw) {
-        double part = 0.0;
-        for (int v = lane; v < V; v += 64) part += sLam[k * V + v];
-        part = wave_sum(part);
-        if (lane == 0) { sCol[k] = part; sPsi[k] = dev_digamma_pos(part); }
-    }
-    __syncthreads();
-    for (int e = tid; e < KP * V; e += nthr) {
-        if (e < K * V) {
-            const int k = e / V;
-            const double l = sLam[e];
-            const double el = dev_digamma_pos(l) - sPsi[k];
-            const double eb = exp(el), bt = l / sCol[k];
-            sLam[e] = eb; sBet[e] = bt;
-            if (gl) { gl[e] = l; gE[e] = el; gX[e] = eb; gB[e] = bt; }
-        } else { sLam[e] = 0.0; sBet[e] = 0.0; }
-    }
-    __syncthreads();
-}
-
 
 #ifdef MMM_DIAG_STAMPS
 // diagnostic build only (make diag): s_memtime stamps of block 0 / wave 0 through the fused E-step kernel.
@@ -604,16 +570,6 @@ __global__ __launch_bounds__(64) void k_lda_infer_tail(ReduceArgs r, int phase)
 
 __global__ void k_lda_tail_only(ReduceArgs r) { if (!r.ctl->stop) lda_pass_tail(r); }
 
-// topic state of the current pass from its reduced statistics (same arithmetic as the E-step prologue)
-template <int KP>
-__global__ __launch_bounds__(kMaxWavesE* MMM_WAVE) void k_lda_finalize(int K, int V, double eta, const double* sums, double* gl,
-                                                                        double* gE, double* gX, double* gB)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* sLam = smem; double* sBet = smem + (size_t)KP * V; double* sCol = sBet + (size_t)KP * V; double* sPsi = sCol + KP;
-    lda_topics_from_stats<KP>(K, V, eta, sums, sLam, sBet, sCol, sPsi, gl, gE, gX, gB);
-}
-
 // ---- on-demand / stage kernels (reference-granularity entry points; not on the fused path) -----------------------
 // phi = softmax_k(Elntheta + Elnbeta[v]) written to HBM (update_ϕ!, LDA.jl:69-76); one wave per document
 template <int KP>
@@ -915,8 +871,6 @@ struct mmm_lda {
     bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
-    bool topics_pending = false; // the topic state of pass t still has to be formed from stats[t&1]
-    bool stats_valid = false;    // stats[t&1] are the M-step statistics of the current state
     bool attr_e[2] = {false, false}, attr_m = false;
     bool stop_seen = false;     // the device stop flag may be set
     bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
@@ -1047,8 +1001,6 @@ int sync_ctl(mmm_lda* m)
 }
 
 // phi of the current state: after fused passes it is softmax_k(Elntheta_t + Elnbeta_{t-1}) (LDA.jl:69-76)
-int finalize_topics(mmm_lda* m);
-
 int materialise_phi(mmm_lda* m)
 {
     int rc = sync_ctl(m);
@@ -1080,7 +1032,7 @@ int ensure_hist(mmm_lda* m, int extra)
 int flush_ll(mmm_lda* m, double* also_dev)
 {
     int rc = sync_ctl(m);
-    if (rc || (rc = finalize_topics(m))) return rc;
+    if (rc) return rc;
     if (!m->ll_pending && !also_dev) return MMM_OK;
     mmm_ctx* ctx = m->ctx;
     const int c = m->cur();
@@ -1132,7 +1084,6 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
     for (int it = 0; it < n_iter; ++it) {
         const int t = m->t + 1;
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
-        const int from_stats = 0;
         // Where the ll of pass t-1 is evaluated: in extra blocks of the reduce launch (the reduction occupies 60 CUs for ~6 us,
         // the ll sweep fits beside it and the E-step kernel sheds 43 % of its chunk-loop instructions and half its table
         // reads), unless the statistics go through ncclAllReduce -- then the numerator has to exist before that call and the
@@ -1147,7 +1098,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
         r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, from_stats, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
+                    m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
             ProfSpan span(ctx);
@@ -1183,7 +1134,6 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
     if (n_iter > 0) {
         m->inflight = true; m->lag_ll = true; m->phi_table_beta = false;
         m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
-        m->topics_pending = false; m->stats_valid = true;
     }
     return MMM_OK;
 }
@@ -1209,7 +1159,7 @@ int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_b
         Ring g = m->ring(m->gamma);
         g.s[(t + 2) % 3] = g.s[t % 3];
         EstepArgs a{m->dev(), m->ctl.p, g, m->ring(m->Elntheta), unsmoothed ? m->ring(m->beta) : m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, 1, t, 0, m->stats[(t + 1) & 1].p, m->ring(m->lambda), m->ring(m->Elnbeta)};
+                    m->partial.p, m->llpart.p, 1, t};
         { ProfSpan span(ctx); rc = launch_estep(m, a); }
         if (rc) return rc;
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, 1, conv_base, 1};
@@ -1227,36 +1177,14 @@ int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_b
     if (n_iter > 0) {
         m->inflight = true; m->lag_ll = false; m->ll_pending = false; m->phi_table_beta = unsmoothed != 0;
         m->phi_valid = false; m->phi_from_prev = true; m->gnext_valid = true; m->theta_valid = false;
-        m->topics_pending = false; m->stats_valid = false;
     }
-    return MMM_OK;
-}
-
-// form lambda/Elnbeta/exp(Elnbeta)/beta of the current pass from its statistics (they are otherwise produced by
-// the next pass's E-step prologue)
-int finalize_topics(mmm_lda* m)
-{
-    if (!m->topics_pending) return MMM_OK;
-    mmm_ctx* ctx = m->ctx;
-    const int c = m->cur();
-    const size_t lds = sizeof(double) * (2 * (size_t)m->KP * m->V + 2 * m->KP);
-    MMM_KP_SWITCH(m, {
-        auto k = k_lda_finalize<KPV>; int rc;
-        if ((rc = set_lds(ctx, k, lds))) return rc;
-        hipLaunchKernelGGL(k, dim3(1), dim3(m->waves_e * MMM_WAVE), lds, ctx->stream, m->K, m->V, m->eta, m->stats[m->t & 1].p,
-                           m->lambda[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p);
-    })
-    MMM_LAUNCH_CHECK(ctx);
-    m->topics_pending = false;
     return MMM_OK;
 }
 
 int prepare_call(mmm_lda* m)
 {
     MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
-    int rc = sync_ctl(m);
-    if (rc) return rc;
-    return finalize_topics(m);
+    return sync_ctl(m);
 }
 
 } // namespace
@@ -1462,7 +1390,7 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     MMM_CHECK(ctx, host && n == cnt, "mmm_lda_set(field %d): expected %zu doubles, got %zu", field, cnt, n);
     if ((rc = materialise_phi(m))) return rc;     // make the implicit phi explicit before state is overwritten
     if ((rc = flush_ll(m, nullptr))) return rc;
-    m->gnext_valid = false; m->phi_from_prev = false; m->stats_valid = false;
+    m->gnext_valid = false; m->phi_from_prev = false;
     if (field == MMM_LDA_THETA) m->theta_valid = true;
     if (field == MMM_LDA_GAMMA) m->theta_valid = false;
     if (n) MMM_HIP(ctx, hipMemcpyAsync(p, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1488,7 +1416,7 @@ int mmm_lda_update_gamma(mmm_lda* m)
     const int c = m->cur();
     hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p);
     MMM_LAUNCH_CHECK(m->ctx);
-    m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false; m->stats_valid = false;
+    m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false;
     return MMM_OK;
 }
 
@@ -1499,7 +1427,7 @@ int mmm_lda_update_phi(mmm_lda* m)
     if (rc || (rc = flush_ll(m, nullptr))) return rc;
     const int c = m->cur();
     if ((rc = launch_phi(m, m->Elntheta[c].p, m->expElnbeta[c].p))) return rc;
-    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false; m->stats_valid = false;
+    m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false;
     return MMM_OK;
 }
 
@@ -1512,7 +1440,7 @@ int mmm_lda_update_lambda(mmm_lda* m)
     MMM_HIP(ctx, hipMemsetAsync(m->scratch.p, 0, sizeof(double) * (size_t)m->V * m->K, ctx->stream));
     if (m->nnz) hipLaunchKernelGGL(k_lda_lambda_from_phi, dim3((unsigned)((m->nnz + 255) / 256)), dim3(256), 0, ctx->stream, m->dev(), m->nnz, m->phi.p, m->scratch.p);
     MMM_LAUNCH_CHECK(ctx);
-    m->gnext_valid = false; m->phi_from_prev = false; m->stats_valid = false;
+    m->gnext_valid = false; m->phi_from_prev = false;
     return run_topic_update(m, true);
 }
 
