@@ -44,6 +44,8 @@ struct LdaDev {
     const int64_t* doc_ptr;
     const int2* tc;
     double alpha, eta;
+    const int2* ell;      // [D][V] rows padded with (-1, 0), or NULL: lets the ll blocks fetch a document's terms without first
+                          // waiting for doc_ptr (built when V <= 128 and no document lists a term twice)
 };
 
 struct LdaCtl {
@@ -342,18 +344,61 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     const int K = c.K, V = c.V, D = c.D;
     double* sBeta = smem;
     double* myT = smem + (size_t)KP * V + ((size_t)wid * G + g) * KP;
-    // the first step's document loads go out before the table is staged (as in the E-step kernel)
-    int base = (lb * 16 + wid) * G;
+    // the first step's document loads go out before the table is staged (as in the E-step kernel).  (Splitting a document
+    // group's chunks over 2 or 4 waves -- more, lighter blocks on the CUs the reduction leaves idle -- was slower: 29.7 / 33.6
+    // vs 26.6 us per iteration; the launch is bound by block dispatch and table staging, not by the sweep's arithmetic.)
+    const int wslot = lb * 16 + wid, nslots = nlb * 16;
+    int base = wslot * G;
     int d = base + g;
     bool valid = d < D;
     double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-    int64_t start = valid ? c.doc_ptr[d] : 0;
-    int W = valid ? (int)(c.doc_ptr[d + 1] - start) : 0;
+    constexpr int PRE = 128 / L;          // padded rows: every chunk of the document is requested up front, no doc_ptr needed
+    const bool ell = c.ell != nullptr;
+    int2 pre[PRE];
+    if (ell) {
+        const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? row[j * L + l] : make_int2(-1, 0);
+    }
+    int64_t start = (!ell && valid) ? c.doc_ptr[d] : 0;
+    int W = (!ell && valid) ? (int)(c.doc_ptr[d + 1] - start) : 0;
     for (int i = tid; i < KP * V; i += 1024) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
     __syncthreads();
     double acc = 0.0;
-    for (; base < D; base += nlb * 16 * G) {
-        if (base != (lb * 16 + wid) * G) {
+    if (ell) {
+        const int nch = (V + L - 1) / L;
+        for (; base < D; base += nslots * G) {
+            if (base != wslot * G) {
+                d = base + g; valid = d < D;
+                gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+                const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
+#pragma unroll
+                for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? row[j * L + l] : make_int2(-1, 0);
+            }
+            const double Sp = group_sum<L>(gp);
+            lds_wave_sync();
+            if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+            lds_wave_sync();
+            double tv[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) tv[k] = myT[k];
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                if (j >= nch) break;
+                const int2 t = pre[j];
+                const bool act = t.x >= 0;
+                const double* bc = sBeta + (act ? t.x : 0);
+                double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
+                if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
+                const double p = act ? p0 + p1 : 1.0;
+                acc = fma((double)t.y, dev_log_pos(p), acc);
+            }
+        }
+    } else
+    for (; base < D; base += nslots * G) {
+        if (base != wslot * G) {
             d = base + g; valid = d < D;
             gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
             start = valid ? c.doc_ptr[d] : 0;
@@ -857,7 +902,7 @@ struct mmm_lda {
     int64_t nnz = 0;
     double alpha = 0, eta = 0;
     double Nglobal = 0, Dglobal = 0;
-    DevBuf<int64_t> doc_ptr; DevBuf<int2> tc;
+    DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
     DevBuf<double> partial, stats[2], scratch, llpart, llpart2, elbopart, ll_hist;
@@ -883,7 +928,7 @@ struct mmm_lda {
     IldaDesc ids{};
     DevBuf<int> features;
     DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
-    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta}; }
+    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
@@ -1272,6 +1317,19 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * (D + 1), hipMemcpyHostToDevice, st));
     if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
+    std::vector<int2> ell;
+    {   // padded rows for the ll blocks (V <= 128 slots, no duplicate terms: then a document always fits its row)
+        int64_t maxW = 0;
+        for (int d = 0; d < D; ++d) maxW = std::max<int64_t>(maxW, doc_ptr[d + 1] - doc_ptr[d]);
+        if (V <= 128 && maxW <= V && D > 0) {
+            ell.assign((size_t)D * V, make_int2(-1, 0));
+            for (int d = 0; d < D; ++d)
+                for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
+            hipError_t e_ = m->tc_ell.alloc(ell.size());
+            if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(tc_ell): %s", hipGetErrorString(e_)); delete m; return rc; }
+            MMM_HIP(ctx, hipMemcpyAsync(m->tc_ell.p, ell.data(), sizeof(int2) * ell.size(), hipMemcpyHostToDevice, st));
+        }
+    }
     if (!ilda) MMM_HIP(ctx, hipMemcpyAsync(m->lambda[0].p, lambda0, sizeof(double) * VK, hipMemcpyHostToDevice, st));
     else {
         m->ilda = true;
