@@ -219,7 +219,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             double av[KP], acc[KP];
 #pragma unroll
             for (int k = 0; k < KP; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
-#pragma unroll 1
+#pragma unroll 2
             for (int j = 0; j < nchmax; ++j) {
                 int2 tcv = tcp[0];
 #pragma unroll
