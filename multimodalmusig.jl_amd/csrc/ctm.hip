@@ -400,14 +400,19 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
 }
 
 // partial[nslab][n] -> out[n], fixed summation order; grid = ceil(n/16) blocks of (16, 64)
+// an optional second job (part2 ... out2) rides in the same launch: blocks [nb1, gridDim.x)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double* __restrict__ part, int nslab, int n, double* __restrict__ out,
-                                                          size_t out_stride, const int* active)
+                                                          size_t out_stride, const int* active, int nb1 = 0x7fffffff,
+                                                          const double* __restrict__ part2 = nullptr, int nslab2 = 0, int n2 = 0,
+                                                          double* __restrict__ out2 = nullptr)
 {
     __shared__ double sm[64][17];
     if (active && !active[blockIdx.y]) return;
+    int bx = blockIdx.x;
+    if (bx >= nb1) { bx -= nb1; part = part2; nslab = nslab2; n = n2; out = out2; }
     part += (size_t)blockIdx.y * nslab * n; out += (size_t)blockIdx.y * out_stride;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int e = blockIdx.x * 16 + tx;
+    const int e = bx * 16 + tx;
     double acc = 0.0;
     if (e < n) for (int sl = ty; sl < nslab; sl += 64) acc += part[(size_t)sl * n + e];
     sm[ty][tx] = acc;
@@ -890,6 +895,19 @@ __global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, i
     if (threadIdx.x == 0) out[j] = acc;
 }
 
+// k_sum_columns + k_ll_store in one launch (single GPU: no exchange between them)
+__global__ __launch_bounds__(64) void k_ll_finish(const double* part, int n, int M, const double* Nm, double* num, size_t num_stride, double* dst,
+                                                  size_t dst_stride, const int* active)
+{
+    const int j = blockIdx.x;
+    if (active && !active[blockIdx.y]) return;
+    part += (size_t)blockIdx.y * n * M;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) acc += part[(size_t)i * M + j];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) { num[blockIdx.y * num_stride + j] = acc; dst[blockIdx.y * dst_stride + j] = acc / Nm[j]; }
+}
+
 __global__ void k_ll_store(int M, const double* num, size_t num_stride, const double* Nm, double* dst, size_t dst_stride, const int* active)
 {
     if (active && !active[blockIdx.y]) return;
@@ -1230,6 +1248,12 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
                        mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
     MMM_LAUNCH_CHECK(ctx);
     if (!compute_ll) return MMM_OK;
+    if (!mmm_comm_active(ctx)) {        // nothing to exchange: column sums and the division by N_m in one launch
+        hipLaunchKernelGGL(k_ll_finish, dim3(M, sc.nrep), dim3(64), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->Nm.p,
+                           m->llnum.p + r0 * m->s_llnum, m->s_llnum, dst_dev, dst_stride, sc.active);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     hipLaunchKernelGGL(k_sum_columns, dim3(M, sc.nrep), dim3(64), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->llnum.p + r0 * m->s_llnum,
                        m->s_llnum, sc.active);
     MMM_LAUNCH_CHECK(ctx);
@@ -1259,6 +1283,26 @@ int ensure_hist(mmm_ctm* m, int extra)
     return MMM_OK;
 }
 
+// two per-replica copies in one launch (blocks [0, nb1) take the first array)
+__global__ void k_copy2_rep(double* dst1, const double* src1, size_t n1, int nb1, double* dst2, const double* src2, size_t n2, const int* active)
+{
+    if (active && !active[blockIdx.y]) return;
+    const bool first = (int)blockIdx.x < nb1;
+    const size_t n = first ? n1 : n2;
+    const size_t i = (size_t)(first ? blockIdx.x : blockIdx.x - nb1) * blockDim.x + threadIdx.x;
+    if (i < n) (first ? dst1 : dst2)[blockIdx.y * n + i] = (first ? src1 : src2)[blockIdx.y * n + i];
+}
+
+int copy2_rep(mmm_ctm* m, Scope sc, double* dst1, const double* src1, size_t n1, double* dst2, const double* src2, size_t n2)
+{
+    const int nb1 = (int)((n1 + 255) / 256), nb2 = (int)((n2 + 255) / 256);
+    if (nb1 + nb2 == 0) return MMM_OK;
+    hipLaunchKernelGGL(k_copy2_rep, dim3(nb1 + nb2, sc.nrep), dim3(256), 0, m->ctx->stream, dst1 + sc.rep0 * n1, src1 + sc.rep0 * n1, n1, nb1,
+                       dst2 + sc.rep0 * n2, src2 + sc.rep0 * n2, n2, sc.active);
+    MMM_LAUNCH_CHECK(m->ctx);
+    return MMM_OK;
+}
+
 int copy_rep(mmm_ctm* m, Scope sc, double* dst, const double* src, size_t n)
 {
     if (!n) return MMM_OK;
@@ -1285,8 +1329,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     const CtmDims& dm = m->dm;
     int rc;
     // keep lambda_{t-1} and the exp table of this pass: theta_t is rebuilt from them on demand
-    if ((rc = copy_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK()))) return rc;
-    if ((rc = copy_rep(m, sc, m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
+    if ((rc = copy2_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK(), m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
     // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
     { ProfSpan span(ctx); rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p); }
     if (rc) return rc;
@@ -1295,8 +1338,13 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                        m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
     MMM_LAUNCH_CHECK(ctx);
-    if ((rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats))) return rc;
-    if ((rc = reduce_partials(m, sc, m->partial.p, m->grid_e, dm.GT, m->stats.p + m->nmom, m->s_stats))) return rc;
+    {   // moments and gamma sums reduced by one launch
+        const int nb1 = (m->nmom + 15) / 16, nb2 = (dm.GT + 15) / 16;
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nb1 + nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + r0 * m->grid_m * m->nmom, m->grid_m,
+                           m->nmom, m->stats.p + r0 * m->s_stats, m->s_stats, sc.active, nb1, m->partial.p + r0 * m->grid_e * dm.GT, m->grid_e, dm.GT,
+                           m->stats.p + r0 * m->s_stats + m->nmom);
+        MMM_LAUNCH_CHECK(ctx);
+    }
     if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
     // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!
     // (the Gaussian part runs as an extra block of the log-likelihood launch below, beside the document sweep)
