@@ -194,3 +194,14 @@ def test_degenerate_shapes(mmm, oracle):
         _cmp_state(g, o, 1e-9)
         assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
         g.close()
+
+
+def test_large_corpus_grid_stride_paths(mmm, oracle):
+    """40,000 documents: the grid-stride E-step build (several steps per wave) and the ll blocks' loop (more document groups than
+    ll blocks) against the oracle."""
+    X, g, o = _pair(mmm, oracle, 40000, 96, 10, seed=77, mean_n=150, empty=(0, 39999))
+    ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=4, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(96, 10, order="F"), rtol=1e-9)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
