@@ -21,8 +21,9 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "build", "libmmm_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("mmm_oracle.c", "mmm_oracle.h")]
-    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    so_omp = os.path.join(_HERE, "build", "libmmm_oracle_omp.so")
+    src = [os.path.join(_HERE, f) for f in ("mmm_oracle.c", "mmm_oracle.h", "mmm_oracle_omp.c")]
+    stale = (not os.path.exists(so)) or (not os.path.exists(so_omp)) or any(os.path.getmtime(s) > min(os.path.getmtime(so), os.path.getmtime(so_omp)) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return so
@@ -113,6 +114,22 @@ def lib():
     L.orc_ctm_infer.argtypes = [P, C.c_int, C.c_int, C.c_double, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _LIB = L
     return L
+
+
+_LIB_OMP = None
+
+
+def lib_omp():
+    """The OpenMP variant of the LDA pass (oracle/mmm_oracle_omp.c): bench.py's all-cores CPU baseline only."""
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "build", "libmmm_oracle_omp.so"))
+        L.orc_omp_threads.restype = C.c_int
+        L.orc_lda_pass_omp.restype = C.c_double
+        L.orc_lda_pass_omp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, i32p, i32p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
+        _LIB_OMP = L
+    return _LIB_OMP
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -249,6 +266,11 @@ class LdaOracle:
 
     def loglik(self):
         return lib().orc_lda_loglik(self.K, self.D, self.V, self.doc_ptr, self.term, self.count, self.theta, self.beta)
+
+    def pass_omp(self):
+        """One body of fit! with the document loops on all host cores (timing baseline); returns the ll."""
+        return lib_omp().orc_lda_pass_omp(self.D, self.V, self.K, self.alpha, self.eta, self.doc_ptr, self.term, self.count, self.lam,
+                                          self.Elnbeta, self.beta, self.gamma, self.Elntheta, self.theta, self.phi)
 
     def elbo(self):
         t = np.empty(7)

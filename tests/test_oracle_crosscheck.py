@@ -207,3 +207,18 @@ def test_mmctm_unsmoothed_theta_and_transform_flags(oracle):
     b = oracle.CtmOracle(K, m.alpha, X, V=[int(v) for v in m.V], seed=9); b.phi[:] = m.phi
     ll = b.infer(3, 12, 1e4)
     assert ll.shape == (11, new.M) and b.converged and not np.allclose(b.Sigma, m.Sigma)
+
+
+def test_openmp_lda_pass_equals_the_sequential_oracle(oracle):
+    """oracle/mmm_oracle_omp.c (bench.py's all-cores CPU baseline) against the literal sequential restatement."""
+    X, lam0 = np_ref.synth_lda(300, 96, 10, seed=21, mean_n=500)
+    a = oracle.LdaOracle(10, 0.1, 0.1, X, V=96, lambda0=lam0)
+    b = oracle.LdaOracle(10, 0.1, 0.1, X, V=96, lambda0=lam0)
+    for _ in range(5):
+        a.update_gamma(); a.update_phi(); a.update_lambda(); a.update_beta(); a.update_theta()
+        lla = a.loglik()
+        llb = b.pass_omp()
+        assert llb == pytest.approx(lla, rel=1e-12)
+    np.testing.assert_allclose(b.lam, a.lam, rtol=1e-12)
+    np.testing.assert_allclose(b.phi, a.phi, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(b.theta, a.theta, rtol=1e-12)
