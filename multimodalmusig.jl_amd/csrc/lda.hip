@@ -254,9 +254,9 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     }
     MMM_STAMP(6);
     // ---- block epilogue: slabs -> one partial; ll partial ------------------------------------------------------
-    ll_acc = wave_sum(ll_acc);
+    if (LL) ll_acc = wave_sum(ll_acc);
     __syncthreads();
-    if (lane == 0) sA[wid] = ll_acc;      // sA is free now
+    if (LL && lane == 0) sA[wid] = ll_acc;      // sA is free now
     double* out = a.partial + (size_t)blockIdx.x * K * V;
     for (int i = tid; i < K * V; i += blockDim.x) {
         double v8[kMaxWavesE];
@@ -267,11 +267,13 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         for (int w = 0; w < kMaxWavesE; ++w) s += v8[w];
         out[i] = s;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += sA[w];
-        a.llpart[blockIdx.x] = s;
+    if (LL) {
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += sA[w];
+            a.llpart[blockIdx.x] = s;
+        }
     }
     MMM_STAMP(7);
 }

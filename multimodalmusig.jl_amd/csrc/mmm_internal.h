@@ -122,30 +122,37 @@ __device__ __forceinline__ void p2p_send(const P2PArgs& a, unsigned int seq, int
     }
 }
 
-// element e of call `seq`: own value + the peers' contributions from the local mailbox, summed in rank order
+// element e of call `seq`: own value + the peers' contributions from the local mailbox, summed in rank order.  All pending
+// cells are requested together in each polling round (a round costs one memory latency, not one per peer).
 __device__ __forceinline__ double p2p_recv_sum(const P2PArgs& a, unsigned int seq, int e, double mine)
 {
     const size_t slot = seq & 1u;
     const int n = a.nranks, me = a.rank;
-    double sum = 0.0;
+    const unsigned long long* base = a.peer[me] + (slot * n * a.cap + e) * 2;      // rank r's cell: base + r * cap * 2
+    const size_t rstride = a.cap * 2;
+    unsigned long long w0[kP2PMaxRanks], w1[kP2PMaxRanks];
+    unsigned int pending = ((n >= 32 ? 0xffffffffu : ((1u << n) - 1u))) & ~(1u << me);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     bool failed = false;
-    for (int r = 0; r < n; ++r) {
-        double v = mine;
-        if (r != me) {
-            const unsigned long long* src = a.peer[me] + ((slot * n + r) * a.cap + e) * 2;
-            unsigned long long x0, x1;
-            for (;;) {
-                x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned int)(x0 >> 32) == seq && (unsigned int)(x1 >> 32) == seq) break;
-                if (failed || __builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { failed = true; break; }
-                __builtin_amdgcn_s_sleep(8);
+    while (pending) {
+#pragma unroll
+        for (int r = 0; r < kP2PMaxRanks; ++r)
+            if ((pending >> r) & 1u) {
+                w0[r] = __hip_atomic_load(base + r * rstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w1[r] = __hip_atomic_load(base + r * rstride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            v = __longlong_as_double((long long)((x0 & 0xffffffffull) | (x1 << 32)));
+#pragma unroll
+        for (int r = 0; r < kP2PMaxRanks; ++r)
+            if (((pending >> r) & 1u) && (unsigned int)(w0[r] >> 32) == seq && (unsigned int)(w1[r] >> 32) == seq) pending &= ~(1u << r);
+        if (pending) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(4);
         }
-        sum += v;
     }
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < kP2PMaxRanks; ++r)
+        if (r < n) sum += (r == me) ? mine : __longlong_as_double((long long)((w0[r] & 0xffffffffull) | (w1[r] << 32)));
     if (failed) atomicExch(a.err, (int)seq);
     return sum;
 }
