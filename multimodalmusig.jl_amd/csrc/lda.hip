@@ -493,17 +493,22 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
 // M-step of pass t from the (all-reduced) statistics, one wave per topic (no inter-block dependency: Elnbeta_k needs
 // only the column sum of topic k): lambda = eta + sums, Elnbeta, exp table, beta (LDA.jl:96-112); block 0 then finalises
 // ll_{t-1}, the stopping rule and the pass counter.
-__global__ __launch_bounds__(64) void k_lda_mstep(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
+// Blocks of two waves: with the mailbox exchange folded in, both waves receive (V <= 128 entries in ONE polling round);
+// wave 0 alone then runs the topic's M-step.
+__global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
 {
     const int stop = r.ctl->stop;
-    const int k = blockIdx.x, lane = threadIdx.x, c = r.t % 3;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, c = r.t % 3;
     if (k == (int)gridDim.x - 1) {      // the extra block: pass tail, concurrent with the topic blocks (its loads are a dependent chain)
-        if (!stop) lda_tail_block(r, lane);
+        if (!stop && tid < 64) lda_tail_block(r, lane);
         return;
     }
     double* sums = r.stats + (size_t)k * V;
-    if (r.p2p && !stop)      // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
-        for (int v = lane; v < V; v += 64) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
+    if (r.p2p) {             // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
+        if (!stop) for (int v = tid; v < V; v += 128) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
+        __syncthreads();
+    }
+    if (tid >= 64) return;
     double part = 0.0;
     for (int v = lane; v < V; v += 64) part += eta + sums[v];
     if (stop) return;
@@ -1170,7 +1175,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                                m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0, r, 1);
         } else
-            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(128), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
                                m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
