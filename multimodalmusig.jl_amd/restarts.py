@@ -31,10 +31,31 @@ def pick_optimal_model(ll):
     return int(np.argmin(ranks.mean(axis=1)))
 
 
-def fit_seed_models(counts, K, α, V, seeds, batch_size=None, ctx=None, maxiter=1000, tol=1e-4, **kw):
+def fit_seed_models(counts, K, α, V, seeds, batch_size=None, ctx=None, maxiter=1000, tol=1e-4, rank=0, nranks=1, allgather=None, **kw):
     """Stage 1 (run_mmctm.jl:97-109): one restart per seed.  Returns (γ of the best restart per modality -- a list over m of
-    [K_m, V_m] arrays --, their final log-likelihoods, the [len(seeds), M] matrix of all final log-likelihoods)."""
+    [K_m, V_m] arrays --, their final log-likelihoods, the [len(seeds), M] matrix of all final log-likelihoods).
+
+    Several GPUs: restarts are independent, so they are simply dealt out -- rank r of nranks fits seeds[r::nranks] on its own
+    context (one WITHOUT a communicator: every rank holds the whole corpus) and the per-modality winners are merged with the
+    host's `allgather(obj) -> list of every rank's obj` (torch.distributed.all_gather_object, MPI, ...).  No device collective."""
     seeds = [int(s) for s in seeds]
+    if nranks > 1:
+        if allgather is None:
+            raise ValueError("nranks > 1 needs an allgather callable")
+        mine = seeds[rank::nranks]
+        g, ll, all_ll = fit_seed_models(counts, K, α, V, mine, batch_size=batch_size, ctx=ctx, maxiter=maxiter, tol=tol, **kw) if mine else (
+            [None] * len(K), np.full(len(K), -np.inf), np.zeros((0, len(K))))
+        parts = allgather((g, ll, all_ll))
+        M = len(K)
+        best_gamma, best_ll = [None] * M, np.full(M, -np.inf)
+        for pg, pl, _ in parts:                      # rank order: ties go to the lowest rank on every rank alike
+            for m in range(M):
+                if pg[m] is not None and pl[m] > best_ll[m]:
+                    best_ll[m], best_gamma[m] = pl[m], pg[m]
+        merged = np.zeros((len(seeds), M))
+        for r, (_, _, pa) in enumerate(parts):
+            merged[r::nranks][:len(pa)] = pa
+        return best_gamma, best_ll, merged
     R = len(seeds)
     bs = R if not batch_size else int(batch_size)
     M = len(K)
@@ -68,10 +89,12 @@ def seed_and_fit_restart(counts, K, α, V, opt_gamma, ctx=None, maxiter=1000, to
     return model
 
 
-def fit_model(counts, K, α, V, restarts, seed=0, verbose=False, batch_size=None, ctx=None, **kw):
-    """`fit_model` of run_mmctm.jl:163-182.  Returns the fitted stage-2 model (fields as MMCTM: ϕ, props, Σ, ll, elbo...)."""
+def fit_model(counts, K, α, V, restarts, seed=0, verbose=False, batch_size=None, ctx=None, rank=0, nranks=1, allgather=None, **kw):
+    """`fit_model` of run_mmctm.jl:163-182.  Returns the fitted stage-2 model (fields as MMCTM: ϕ, props, Σ, ll, elbo...).
+    With nranks > 1 stage 1 is dealt over the ranks (see fit_seed_models); every rank then fits the same seeded stage 2."""
     seeds = np.random.default_rng(seed).integers(1, 2 ** 62, size=int(restarts))
-    opt_gamma, opt_ll, all_ll = fit_seed_models(counts, K, α, V, seeds, batch_size=batch_size, ctx=ctx, **kw)
+    opt_gamma, opt_ll, all_ll = fit_seed_models(counts, K, α, V, seeds, batch_size=batch_size, ctx=ctx, rank=rank, nranks=nranks,
+                                                allgather=allgather, **kw)
     if verbose:
         print("Modality optimal model log-likelihoods:")
         for m in range(len(K)):
