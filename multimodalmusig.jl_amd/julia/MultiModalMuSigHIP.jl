@@ -115,7 +115,7 @@ function LDA(k::Int, α::Float64, η::Float64, X::Vector{Matrix{Int}}; kw...)   
     return LDA(k, α, η, V, X; kw...)
 end
 
-function lda_get(model::LDA, field::Int, n::Int)
+function lda_get(model, field::Int, n::Int)
     buf = Vector{Float64}(undef, n)
     check(ccall((:mmm_lda_get, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, buf, n), model.ctx, "mmm_lda_get")
     return buf
@@ -144,6 +144,124 @@ function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true)
     model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = ll[end]
     download!(model)
     return ll
+end
+
+# ---- LDA frozen-topic inference (LDA.jl:226-295) ------------------------------------------------------------------------
+function lda_set(model, field::Int, v::Vector{Float64})
+    check(ccall((:mmm_lda_set, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, v, length(v)), model.ctx, "mmm_lda_set")
+end
+
+function lda_infer!(model, unsmoothed::Bool, maxiter::Int, tol::Float64, verbose::Bool)
+    ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0)
+    check(ccall((:mmm_lda_infer, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}),
+                model.h, unsmoothed ? 1 : 0, maxiter, tol, ll, n, cv), model.ctx, "mmm_lda_infer")
+    resize!(ll, n[])
+    if verbose
+        for (iter, v) in enumerate(ll) println("$iter\tLog-likelihood: ", v) end
+    end
+    model.converged = cv[] != 0
+    return ll
+end
+
+function lda_elbo(model)
+    e = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_lda_elbo, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ptr{Cdouble}), model.h, e, C_NULL), model.ctx, "mmm_lda_elbo")
+    return e[]
+end
+
+# transform(model, X) -- LDA.jl:233-263: θ (K x D) of new documents under the trained β
+function transform(model::LDA, X::Vector{Matrix{Int}}; maxiter=1000, tol=1e-4, verbose=false)
+    newmodel = LDA(model.K, model.α, model.η, model.V, X; ctx=model.ctx)
+    lda_set(newmodel, 2, vec(model.β))                                    # :237
+    lda_infer!(newmodel, true, maxiter, Float64(tol), verbose)
+    newmodel.converged || @warn "transform did not converge"              # :258-260 (`warn` upstream)
+    download!(newmodel)
+    return newmodel.θ
+end
+
+# fit_heldout(Xheldout, model) -- LDA.jl:265-295
+function fit_heldout(Xheldout::Vector{Matrix{Int}}, model::LDA; maxiter=100, verbose=false)
+    heldout_model = LDA(model.K, model.α, model.η, model.V, Xheldout; ctx=model.ctx)
+    lda_set(heldout_model, 0, vec(model.λ)); lda_set(heldout_model, 2, vec(model.β)); lda_set(heldout_model, 1, vec(model.Elnβ))   # :269-271
+    ll = lda_infer!(heldout_model, false, maxiter, 1e-4, verbose)
+    heldout_model.elbo = lda_elbo(heldout_model)                          # :291
+    heldout_model.ll = ll[end]
+    download!(heldout_model)
+    return heldout_model
+end
+
+# ---- ILDA (struct fields as ILDA.jl:1-23; same C handle type as LDA) ---------------------------------------------------------
+mutable struct ILDA
+    K::Int; D::Int; I::Int; J::Vector{Int}
+    η::Vector{Float64}; λ::Vector{Matrix{Float64}}; β::Vector{Matrix{Float64}}; Elnβ::Vector{Matrix{Float64}}
+    α::Float64; γ::Matrix{Float64}; θ::Matrix{Float64}; Elnθ::Matrix{Float64}
+    ϕ::Vector{Matrix{Float64}}
+    features::Matrix{Int}; X::Vector{Matrix{Int}}
+    converged::Bool; elbo::Float64; ll::Float64
+    ctx::Context; h::Ptr{Cvoid}; doc_ptr::Vector{Int64}
+
+    function ILDA(k::Int, α::Float64, η::Vector{Float64}, features::Matrix{Int}, X::Vector{Matrix{Int}}; ctx::Context=default_context())
+        model = new()
+        model.K = k; model.α = α; model.η = copy(η); model.X = X; model.D = length(X)
+        model.I = size(features, 2); model.J = vec(maximum(features, dims=1)); model.features = features
+        V = size(features, 1)
+        model.λ = [Float64.(rand(1:100, model.J[i], k)) for i in 1:model.I]               # ILDA.jl:36
+        lambda0 = vcat([vec(model.λ[i]) for i in 1:model.I]...)                           # J_i x K column-major, feature after feature
+        featflat = Int32.(vec(features .- 1))                                             # [i*V + v], 0-based values
+        doc_ptr, term, count = pack_lda(X)
+        model.doc_ptr = doc_ptr; model.ctx = ctx
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:mmm_ilda_create, LIB), Cint,
+                    (Ptr{Cvoid}, Cint, Cint, Cint, Cdouble, Cint, Ptr{Cint}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32},
+                     Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
+                    ctx.h, model.D, V, k, α, model.I, Cint.(model.J), model.η, featflat, doc_ptr, term, count, lambda0, out), ctx, "mmm_ilda_create")
+        model.h = out[]
+        finalizer(m -> ccall((:mmm_lda_destroy, LIB), Cint, (Ptr{Cvoid},), m.h), model)
+        model.converged = false
+        download!(model)
+        return model
+    end
+end
+
+ILDA(k::Int, α::Float64, η::Float64, features::Matrix{Int}, X::Vector{Matrix{Int}}; kw...) =      # ILDA.jl:58-63
+    ILDA(k, α, fill(η, size(features, 2)), features, X; kw...)
+
+function download!(model::ILDA)
+    K, D = model.K, model.D
+    off = cumsum([0; model.J .* K])
+    factors(field) = (f = lda_get(model, field, off[end]); [reshape(f[off[i] + 1:off[i + 1]], model.J[i], K) for i in 1:model.I])
+    model.λ = factors(7); model.Elnβ = factors(8); model.β = factors(9)
+    model.γ = reshape(lda_get(model, 3, K * D), K, D); model.Elnθ = reshape(lda_get(model, 4, K * D), K, D)
+    model.θ = reshape(lda_get(model, 5, K * D), K, D)
+    flat = lda_get(model, 6, K * model.doc_ptr[end])
+    model.ϕ = [reshape(flat[K * model.doc_ptr[d] + 1:K * model.doc_ptr[d + 1]], K, :) for d in 1:D]
+    return model
+end
+
+# fit!(model; maxiter, tol, verbose) -- ILDA.jl:246-272
+function fit!(model::ILDA; maxiter=1000, tol=1e-4, verbose=true)
+    ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_lda_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
+                model.h, maxiter, tol, ll, n, cv, elbo), model.ctx, "mmm_lda_fit")
+    resize!(ll, n[])
+    if verbose
+        for (iter, v) in enumerate(ll) println("$iter\tLog-likelihood: ", v) end
+    end
+    model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = ll[end]
+    download!(model)
+    return ll
+end
+
+# fit_heldout(Xheldout, model) -- ILDA.jl:320-353.  (`transform(::ILDA)` is a MethodError upstream, ILDA.jl:293: not provided.)
+function fit_heldout(Xheldout::Vector{Matrix{Int}}, model::ILDA; maxiter=100, verbose=false)
+    heldout_model = ILDA(model.K, model.α, model.η, model.features, Xheldout; ctx=model.ctx)
+    packed(fs) = vcat([vec(f) for f in fs]...)
+    lda_set(heldout_model, 7, packed(model.λ)); lda_set(heldout_model, 9, packed(model.β)); lda_set(heldout_model, 8, packed(model.Elnβ))
+    ll = lda_infer!(heldout_model, false, maxiter, 1e-4, verbose)
+    heldout_model.elbo = lda_elbo(heldout_model)
+    heldout_model.ll = ll[end]
+    download!(heldout_model)
+    return heldout_model
 end
 
 # ---- MMCTM / IMMCTM (struct fields as MMCTM.jl:1-27 / IMMCTM.jl:1-27) -----------------------------------------------------
@@ -199,17 +317,14 @@ function ctm_get(model, field::Int, n::Int)
     return buf
 end
 
-function download!(model::MMCTM)
-    M, D, K, V = model.M, model.D, model.K, model.V
-    MK = sum(K); koff = cumsum([0; K]); goff = cumsum([0; K .* V])
+# μ, Σ, invΣ and the per-document λ, ν, ζ, θ: same flat layouts for MMCTM and IMMCTM handles
+function download_docs!(model)
+    M, D, K = model.M, model.D, model.K
+    MK = sum(K)
     model.μ = ctm_get(model, 0, MK); model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK); model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
-    nest(flat) = [[flat[goff[m] + (kk - 1) * V[m] + 1:goff[m] + kk * V[m]] for kk in 1:K[m]] for m in 1:M]
-    model.γ = nest(ctm_get(model, 3, goff[end])); model.Elnϕ = nest(ctm_get(model, 4, goff[end])); model.ϕ = nest(ctm_get(model, 5, goff[end]))
     lam = reshape(ctm_get(model, 6, D * MK), MK, D); nu = reshape(ctm_get(model, 7, D * MK), MK, D)
     model.λ = [lam[:, d] for d in 1:D]; model.ν = [nu[:, d] for d in 1:D]
     z = reshape(ctm_get(model, 8, D * M), M, D); model.ζ = [z[:, d] for d in 1:D]
-    pr = reshape(ctm_get(model, 9, D * MK), MK, D)
-    model.props = [[pr[koff[m] + 1:koff[m + 1], d] for m in 1:M] for d in 1:D]
     dp = model.doc_ptr
     estart = [dp[(m - 1) * (D + 1) + 1] for m in 1:M]
     nnz = [dp[m * (D + 1)] - estart[m] for m in 1:M]
@@ -217,6 +332,17 @@ function download!(model::MMCTM)
     th = ctm_get(model, 10, toff[end])
     model.θ = [[reshape(th[toff[m] + (dp[(m - 1) * (D + 1) + d] - estart[m]) * K[m] + 1:toff[m] + (dp[(m - 1) * (D + 1) + d + 1] - estart[m]) * K[m]], K[m], :)
                 for m in 1:M] for d in 1:D]
+    return model
+end
+
+function download!(model::MMCTM)
+    M, D, K, V = model.M, model.D, model.K, model.V
+    MK = sum(K); koff = cumsum([0; K]); goff = cumsum([0; K .* V])
+    download_docs!(model)
+    nest(flat) = [[flat[goff[m] + (kk - 1) * V[m] + 1:goff[m] + kk * V[m]] for kk in 1:K[m]] for m in 1:M]
+    model.γ = nest(ctm_get(model, 3, goff[end])); model.Elnϕ = nest(ctm_get(model, 4, goff[end])); model.ϕ = nest(ctm_get(model, 5, goff[end]))
+    pr = reshape(ctm_get(model, 9, D * MK), MK, D)
+    model.props = [[pr[koff[m] + 1:koff[m + 1], d] for m in 1:M] for d in 1:D]
     return model
 end
 
@@ -360,16 +486,53 @@ function fit!(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false) 
         a = ctm_get(model, 11, sum(model.I)); off = cumsum([0; model.I])
         model.α = [a[off[m] + 1:off[m + 1]] for m in 1:M]
     end
-    MK = sum(model.K); D = model.D
-    model.μ = ctm_get(model, 0, MK); model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK); model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
-    lam = reshape(ctm_get(model, 6, D * MK), MK, D); nu = reshape(ctm_get(model, 7, D * MK), MK, D)
-    model.λ = [lam[:, d] for d in 1:D]; model.ν = [nu[:, d] for d in 1:D]
+    download!(model)
+    return hist
+end
+
+function download!(model::IMMCTM)
+    M = model.M
+    download_docs!(model)
     SJ = [sum(model.J[m]) for m in 1:M]; mgoff = cumsum([0; model.K .* SJ])
     gflat = ctm_get(model, 3, mgoff[end]); eflat = ctm_get(model, 4, mgoff[end])
     nest(flat) = [[[flat[mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i - 1]) + 1:mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i])]
                     for i in 1:model.I[m]] for kk in 1:model.K[m]] for m in 1:M]
     model.γ = nest(gflat); model.Elnϕ = nest(eflat)
-    return hist
+    return model
+end
+
+flat3(nested) = vcat((flat(x) for x in nested)...)         # [m][k][i][j] -> flat, the library's layout
+
+# fit_heldout(Xheldout, model) -- IMMCTM.jl:468-497
+function fit_heldout(Xheldout::Vector{Vector{Matrix{Int}}}, model::IMMCTM; maxiter=100, verbose=false)
+    heldout_model = IMMCTM(model.K, model.α, model.features, Xheldout; ctx=model.ctx)
+    ctm_set(heldout_model, 0, model.μ); ctm_set(heldout_model, 1, vec(model.Σ)); ctm_set(heldout_model, 2, vec(model.invΣ))
+    ctm_set(heldout_model, 3, flat3(model.γ)); ctm_set(heldout_model, 4, flat3(model.Elnϕ))
+    hist = ctm_infer!(heldout_model, 0, maxiter, 1e-4)
+    isempty(hist) || (heldout_model.ll = hist[end])
+    download!(heldout_model)
+    return heldout_model
+end
+
+# predict_modality_η(Xobs, m, model) -- MMCTM.jl:588-634 / IMMCTM.jl:499-545: E[η of the unobserved modality m | the other
+# modalities' counts].  The frozen-topic passes run on the GPU; the Gaussian conditioning is MK x MK host algebra.
+function predict_modality_η(Xobs::Vector{Vector{Matrix{Int}}}, m::Int, model::Union{MMCTM,IMMCTM}; maxiter=100, verbose=false)
+    obsM = setdiff(1:model.M, m)
+    koff = cumsum([0; model.K])
+    unobs = collect(koff[m] + 1:koff[m + 1]); obs = setdiff(1:koff[end], unobs)
+    if model isa IMMCTM
+        obsmodel = IMMCTM(model.K[obsM], model.α[obsM], model.features[obsM], Xobs; ctx=model.ctx)
+        ctm_set(obsmodel, 3, flat3(model.γ[obsM])); ctm_set(obsmodel, 4, flat3(model.Elnϕ[obsM]))
+    else
+        obsmodel = MMCTM(model.K[obsM], model.α[obsM], model.V[obsM], Xobs; ctx=model.ctx)
+        ctm_set(obsmodel, 3, flat(model.γ[obsM])); ctm_set(obsmodel, 4, flat(model.Elnϕ[obsM])); ctm_set(obsmodel, 5, flat(model.ϕ[obsM]))
+    end
+    ctm_set(obsmodel, 0, model.μ[obs]); ctm_set(obsmodel, 1, vec(model.Σ[obs, obs])); ctm_set(obsmodel, 2, vec(model.invΣ[obs, obs]))   # :597-599
+    ctm_infer!(obsmodel, 0, maxiter, 1e-4)
+    obsmodel.converged || @warn "model not converged."                    # :623-625 (`warn` upstream)
+    download_docs!(obsmodel)
+    A = model.Σ[unobs, obs] * model.invΣ[obs, obs]                         # :627-633
+    return [model.μ[unobs] .+ A * (obsmodel.λ[d] .- model.μ[obs]) for d in 1:obsmodel.D]
 end
 
 end # module
