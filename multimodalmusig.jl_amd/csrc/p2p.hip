@@ -46,7 +46,7 @@ static size_t p2p_bytes(int nranks) { return sizeof(unsigned long long) * 2 * 2 
 static int p2p_alloc(mmm_ctx* ctx, int nranks)
 {
     if (ctx->p2p) return MMM_OK;
-    MMM_CHECK(ctx, nranks >= 2 && nranks <= kP2PMaxRanks, "p2p: nranks %d not in 2..%d", nranks, kP2PMaxRanks);
+    MMM_CHECK(ctx, nranks >= 1 && nranks <= kP2PMaxRanks, "p2p: nranks %d not in 1..%d", nranks, kP2PMaxRanks);
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_p2p* p = new mmm_p2p();
     p->bytes = p2p_bytes(nranks);
@@ -99,7 +99,7 @@ static int p2p_launch(mmm_ctx* ctx, double* dev, size_t count)
 
 bool mmm_p2p_begin(mmm_ctx* ctx, size_t count, P2PArgs* args, unsigned int* seq)
 {
-    if (!ctx->p2p || !ctx->p2p_on || ctx->nranks < 2 || count > kP2PCap) return false;
+    if (!ctx->p2p || !ctx->p2p_on || count > kP2PCap) return false;
     *args = ctx->p2p->args;
     *seq = ++ctx->p2p->seq;
     return true;
@@ -208,7 +208,7 @@ int mmm_p2p_enable(mmm_ctx* ctx, int on)
 const char* mmm_comm_transport(const mmm_ctx* ctx)
 {
     if (!ctx) return "none";
-    if (ctx->p2p_on && ctx->nranks > 1) return "p2p";
+    if (ctx->p2p_on) return "p2p";
     return mmm_comm_active(ctx) ? "rccl" : "none";
 }
 
@@ -217,7 +217,9 @@ const char* mmm_comm_transport(const mmm_ctx* ctx)
 // RCCL-bootstrapped set-up used by mmm_comm_init_rank: all-gather the handles, attach, rehearse, agree
 int mmm_p2p_setup_over_rccl(mmm_ctx* ctx)
 {
-    if (ctx->nranks < 2 || ctx->nranks > kP2PMaxRanks) return MMM_OK;
+    // a one-rank communicator has nothing to exchange; MMM_P2P_ONE_RANK=1 sets the mailboxes up anyway, so that a single-GPU
+    // box can run this function and the folded exchange end to end (tests/test_multirank_gpu.py)
+    if (ctx->nranks > kP2PMaxRanks || (ctx->nranks < 2 && !getenv("MMM_P2P_ONE_RANK"))) return MMM_OK;
     if (const char* s = getenv("MMM_P2P")) if (atoi(s) == 0) return MMM_OK;
     const int n = ctx->nranks;
     char mine[MMM_P2P_HANDLE_BYTES];

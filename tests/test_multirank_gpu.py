@@ -26,15 +26,17 @@ ll = pkg.fit(g, maxiter=14, tol=0.0, verbose=False)
 Xm, g0 = np_ref.synth_mm(120, [40, 24], [5, 4], seed=4, means=[600, 80], empty_frac=0.1)
 c = pkg.MMCTM([5, 4], [0.1, 0.1], [40, 24], Xm, γ0=g0, ctx=ctx)
 llc = pkg.fit(c, maxiter=5, tol=0.0, verbose=False)
-print("RESULT " + json.dumps({"ll": ll.tolist(), "elbo": g.elbo, "lam": g.λ.sum(), "llc": llc.tolist(), "elboc": c.elbo, "mu": c.μ.tolist()}))
+print("RESULT " + json.dumps({"transport": ctx.transport, "ll": ll.tolist(), "elbo": g.elbo, "lam": g.λ.sum(), "llc": llc.tolist(), "elboc": c.elbo, "mu": c.μ.tolist()}))
 """
 
 
-def _run(force):
+def _run(force, mailboxes=False):
     env = dict(os.environ)
-    env.pop("MMM_FORCE_RCCL", None)
+    env.pop("MMM_FORCE_RCCL", None); env.pop("MMM_P2P_ONE_RANK", None)
     if force:
         env["MMM_FORCE_RCCL"] = "1"
+    if mailboxes:
+        env["MMM_P2P_ONE_RANK"] = "1"
     p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -47,6 +49,18 @@ def test_one_rank_rccl_path_equals_plain_path():
     # has to exist before the ncclAllReduce call, so the E-step kernel produces it; otherwise extra blocks of the reduce launch do)
     # ... and the two E-step instantiations (with / without the ll in the chunk loop) are scheduled differently by the compiler:
     # last-bit differences, nothing more
+    np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
+    np.testing.assert_allclose([a["elbo"], a["lam"]], [b["elbo"], b["lam"]], rtol=1e-13)
+    assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
+
+
+def test_one_rank_mailbox_setup_over_rccl_and_folded_exchange():
+    """What `bench.py --gpus N` runs on a multi-GPU node, with N = 1: mmm_comm_init_rank sets the xGMI mailboxes up over the
+    RCCL communicator (handle all-gather, attach, rehearsal, unanimous agreement) and the LDA iteration then sends its
+    statistics from the reduce launch and receives them in the M-step launch.  With one rank there is no peer to hear from,
+    so the results must be the plain path's."""
+    a, b = _run(False), _run(True, mailboxes=True)
+    assert a["transport"] == "none" and b["transport"] == "p2p"
     np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
     np.testing.assert_allclose([a["elbo"], a["lam"]], [b["elbo"], b["lam"]], rtol=1e-13)
     assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
