@@ -75,7 +75,11 @@ int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 
 /* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------
  * (no counterpart in the reference, which is single-threaded; replaces the doc loops' cross-document sums
- *  LDA.jl:103-105, MMCTM.jl:201,205-210,230-240 and the log-likelihood sums) */
+ *  LDA.jl:103-105, MMCTM.jl:201,205-210,230-240 and the log-likelihood sums).
+ * With a communicator on ctx, every model call that produces or consumes a cross-document sum is COLLECTIVE: all ranks make
+ * the same calls on their handles in the same order -- *_create, *_iterate, *_fit, *_infer, the update_* stages, *_loglik,
+ * *_elbo, and *_ll_history / *_set (they complete the last pass's pending log-likelihood first).  *_get and *_destroy are
+ * local. */
 #define MMM_UNIQUE_ID_BYTES 128
 int mmm_comm_unique_id(char out[MMM_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId   */
 int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id[MMM_UNIQUE_ID_BYTES]);
