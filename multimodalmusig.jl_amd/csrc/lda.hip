@@ -624,14 +624,18 @@ __global__ void k_lda_tail_only(ReduceArgs r) { if (!r.ctl->stop) lda_pass_tail(
 
 // ---- on-demand / stage kernels (reference-granularity entry points; not on the fused path) -----------------------
 // phi = softmax_k(Elntheta + Elnbeta[v]) written to HBM (update_ϕ!, LDA.jl:69-76); one wave per document
-template <int KP>
+// (TAB_LDS = false: vocabularies whose table does not fit LDS read it through L2; topics k >= K are then skipped, not padded)
+template <int KP, bool TAB_LDS>
 __global__ __launch_bounds__(kBlock) void k_lda_phi(LdaDev c, const double* Elntheta, const double* expElnbeta, double* phi)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int K = c.K, V = c.V;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < KP * V; i += kBlock) smem[i] = (i < K * V) ? expElnbeta[i] : 0.0;
-    __syncthreads();
+    const double* tab = TAB_LDS ? smem : expElnbeta;
+    if (TAB_LDS) {
+        for (int i = tid; i < KP * V; i += kBlock) smem[i] = (i < K * V) ? expElnbeta[i] : 0.0;
+        __syncthreads();
+    }
     for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
         const double ak = (lane < K) ? exp(Elntheta[(size_t)d * K + lane]) : 0.0;
         double av[KP];
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_phi(LdaDev c, const double* Elnt
             const int v = c.tc[start + w].x;
             double e[KP], s = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) { e[k] = av[k] * smem[k * V + v]; s += e[k]; }
+            for (int k = 0; k < KP; ++k) { e[k] = (TAB_LDS || k < K) ? av[k] * tab[(size_t)k * V + v] : 0.0; s += e[k]; }
             double* ph = phi + (size_t)(start + w) * K;
 #pragma unroll
             for (int k = 0; k < KP; ++k) if (k < K) ph[k] = e[k] / s;
@@ -694,7 +698,7 @@ __global__ void k_exp_table(int n, const double* in, double* out)
 }
 
 // theta = gamma / sum gamma (LDA.jl:92-94) and the log-likelihood numerator (LDA.jl:174-188), wave per document
-template <int KP>
+template <int KP, bool TAB_LDS>
 __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* gamma, const double* beta, double* theta,
                                                        double* llpart, int compute_ll)
 {
@@ -702,7 +706,8 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
     __shared__ double shw[kWavesPerBlock];
     const int K = c.K, V = c.V;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (compute_ll) {
+    const double* tab = TAB_LDS ? smem : beta;
+    if (TAB_LDS && compute_ll) {
         for (int i = tid; i < KP * V; i += kBlock) smem[i] = (i < K * V) ? beta[i] : 0.0;
         __syncthreads();
     }
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
             const int2 t = c.tc[start + w];
             double p = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) p = fma(tv[k], smem[k * V + t.x], p);
+            for (int k = 0; k < KP; ++k) if (TAB_LDS || k < K) p = fma(tv[k], tab[(size_t)k * V + t.x], p);
             acc += (double)t.y * log(p);
         }
         wave_ll += wave_sum(acc);
@@ -732,6 +737,123 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
         if (lane == 0) shw[wid] = wave_ll;
         __syncthreads();
         if (tid == 0) llpart[blockIdx.x] = shw[0] + shw[1] + shw[2] + shw[3];
+    }
+}
+
+// ---- wide vocabularies: K*V tables that do not fit LDS next to a slab (e.g. 1536 pentanucleotide contexts, or any V in the
+// thousands).  Same pass structure and rings as the fused path, different data flow: the per-block statistics partials
+// (grid x K*V doubles) are out of the question here, and so is streaming phi (K*nnz doubles) out and back in a different
+// order.  Instead every phi_kw is evaluated TWICE, in two sweeps that each read 8 B per nonzero:
+//   * document-major (k_lda_estep_wide, one wave per document, table columns gathered through L2): Elntheta_t,
+//     a_d = exp(Elntheta_t) -> `aexp`, gamma_{t+1} = alpha + sum_w phi_t n, and (do_ll) the ll numerator of pass t-1;
+//   * term-major (k_lda_stats_terms, one block per term over a posting list (doc, count) built at create): with the term's
+//     table column in scalar registers and a_d gathered from the L2-resident D x K array, stats[k][v] = sum_postings
+//     n a_dk eB_kv / (sum_k' a_dk' eB_k'v) in posting order -- a fixed summation order, no atomics.
+template <int KP>
+__global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* __restrict__ aexp)
+{
+    __shared__ double shw[kWavesPerBlock];
+    if (a.ctl->stop) return;
+    const int t = a.t;
+    const double* __restrict__ gam = a.gamma.s[t % 3];
+    const double* __restrict__ gprev = a.gamma.s[(t + 2) % 3];
+    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
+    double* __restrict__ Eln = a.Elntheta.s[t % 3];
+    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
+    const double* __restrict__ bprev = a.beta.s[(t + 2) % 3];
+    const int K = a.c.K, V = a.c.V, D = a.c.D;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double wave_ll = 0.0;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < D; d += gridDim.x * kWavesPerBlock) {
+        const double gk = (lane < K) ? gam[(size_t)d * K + lane] : 0.0;
+        const double S = wave_sum(gk);
+        const double ps = dev_digamma_pos(lane < K ? gk : S);          // lanes >= K hold psi(S)
+        const double el = ps - wave_bcast(ps, K);
+        const double ak = (lane < K) ? exp(el) : 0.0;
+        if (lane < K) { Eln[(size_t)d * K + lane] = el; aexp[(size_t)d * K + lane] = ak; }
+        double th = 0.0;
+        if (a.do_ll) {
+            const double gp = (lane < K) ? gprev[(size_t)d * K + lane] : 0.0;
+            th = gp / wave_sum(gp);
+        }
+        double av[KP], tv[KP], acc[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { av[k] = wave_bcast(ak, k); tv[k] = wave_bcast(th, k); acc[k] = 0.0; }
+        const int64_t start = a.c.doc_ptr[d];
+        const int W = (int)(a.c.doc_ptr[d + 1] - start);
+        double ll = 0.0;
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int2 tc = a.c.tc[start + w];
+            const double n = (double)tc.y;
+            double e[KP], s = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { e[k] = (k < K) ? av[k] * eB[(size_t)k * V + tc.x] : 0.0; s += e[k]; }
+            const double rn = n / s;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc[k] = fma(e[k], rn, acc[k]);
+            if (a.do_ll) {
+                double p = 0.0;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) if (k < K) p = fma(tv[k], bprev[(size_t)k * V + tc.x], p);
+                ll = fma(n, log(p), ll);
+            }
+        }
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { const double tot = wave_sum(acc[k]); if (lane == k) mine = tot; }
+        if (lane < K) gnext[(size_t)d * K + lane] = a.c.alpha + mine;
+        if (a.do_ll) wave_ll += wave_sum(ll);
+    }
+    if (a.do_ll) {
+        if (lane == 0) shw[wid] = wave_ll;
+        __syncthreads();
+        if (threadIdx.x == 0) a.llpart[blockIdx.x] = shw[0] + shw[1] + shw[2] + shw[3];
+    }
+}
+
+// block v < V: the statistics of term v (LDA.jl:103-105), its postings split into blockDim.x / 64 contiguous segments, one per
+// wave, lanes over a segment's postings in order, segment sums added in segment order.  Block V: the E-step's ll partials
+// summed into stats[V*K] (what lda_reduce_block's wave 1 does).
+template <int KP>
+__global__ __launch_bounds__(512) void k_lda_stats_terms(int V, int K, const int64_t* __restrict__ term_ptr, const int2* __restrict__ tpost,
+                                                          const double* __restrict__ aexp, const double* __restrict__ eB, ReduceArgs r)
+{
+    __shared__ double sh[8][KP];
+    if (r.ctl->stop) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int v = blockIdx.x;
+    if (v == V) {
+        if (wid == 0) {
+            double s = 0.0;
+            for (int i = lane; i < r.nslab; i += MMM_WAVE) s += r.llpart[i];
+            s = wave_sum(s);
+            if (lane == 0) r.stats[r.VK] = s;
+        }
+        return;
+    }
+    double eb[KP], acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { eb[k] = (k < K) ? eB[(size_t)k * V + v] : 0.0; acc[k] = 0.0; }
+    const int64_t p0 = term_ptr[v], p1 = term_ptr[v + 1];
+    const int64_t seg = (p1 - p0 + nw - 1) / nw;
+    const int64_t q0 = p0 + wid * seg, q1 = (q0 + seg < p1) ? q0 + seg : p1;
+    for (int64_t j = q0 + lane; j < q1; j += MMM_WAVE) {
+        const int2 dn = tpost[j];
+        const double* __restrict__ ad = aexp + (size_t)dn.x * K;
+        double e[KP], s = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { e[k] = (k < K) ? ad[k] * eb[k] : 0.0; s += e[k]; }
+        const double rn = (double)dn.y / s;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] = fma(e[k], rn, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { const double tot = wave_sum(acc[k]); if (lane == 0) sh[wid][k] = tot; }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        double tot = 0.0;
+        for (int w = 0; w < nw; ++w) tot += sh[w][threadIdx.x];
+        r.stats[(size_t)threadIdx.x * V + v] = tot;
     }
 }
 
@@ -928,6 +1050,11 @@ struct mmm_lda {
     bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
     bool phi_table_beta = false; // phi of the current state is exp(Elntheta) .* beta normalised (unsmoothed_update_ϕ!, LDA.jl:226)
     bool single_step = false;   // one step per wave: the grid covers every document
+    bool wide = false;          // K*V tables larger than LDS: k_lda_estep_wide + k_lda_stats_terms, tables through L2
+    DevBuf<int64_t> term_ptr;           // wide: the postings of term v are tpost[term_ptr[v] .. term_ptr[v+1])
+    DevBuf<int2> tpost;                 // (document, count), documents ascending within a term
+    DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x K, written by the document sweep for the term sweep
+    int stats_waves = 1;                // waves per term block of k_lda_stats_terms
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
     // ILDA (src/ILDA.jl): feature-factorised topics; the V x K rings then hold the effective tables
@@ -1000,6 +1127,11 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
     int rc = MMM_OK;
+    if (m->wide) {
+        MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_estep_wide<KPV>, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, a, m->aexp.p); })
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     MMM_KP_SWITCH(m, {
         if (m->L == 16) { if constexpr (KPV <= 16) rc = a.do_ll ? go_estep<KPV, 16, true>(m, a) : go_estep<KPV, 16, false>(m, a); }
         else if (m->L == 32) { if constexpr (KPV >= 16) rc = a.do_ll ? go_estep<KPV, 32, true>(m, a) : go_estep<KPV, 32, false>(m, a); }
@@ -1014,9 +1146,12 @@ int launch_phi(mmm_lda* m, const double* Elntheta, const double* expElnbeta)
 {
     mmm_ctx* ctx = m->ctx;
     MMM_KP_SWITCH(m, {
-        auto k = k_lda_phi<KPV>; int rc;
-        if ((rc = set_lds(ctx, k, m->lds_tab))) return rc;
-        hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), m->lds_tab, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+        if (m->wide) hipLaunchKernelGGL((k_lda_phi<KPV, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+        else {
+            auto k = k_lda_phi<KPV, true>; int rc;
+            if ((rc = set_lds(ctx, k, m->lds_tab))) return rc;
+            hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), m->lds_tab, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+        }
     })
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
@@ -1027,9 +1162,12 @@ int launch_loglik(mmm_lda* m, const double* gamma, const double* beta, double* t
     mmm_ctx* ctx = m->ctx;
     const size_t lds = compute_ll ? m->lds_tab : 0;
     MMM_KP_SWITCH(m, {
-        auto k = k_lda_loglik<KPV>; int rc;
-        if ((rc = set_lds(ctx, k, lds))) return rc;
-        hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), lds, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+        if (m->wide) hipLaunchKernelGGL((k_lda_loglik<KPV, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+        else {
+            auto k = k_lda_loglik<KPV, true>; int rc;
+            if ((rc = set_lds(ctx, k, lds))) return rc;
+            hipLaunchKernelGGL(k, dim3(m->grid_s), dim3(kBlock), lds, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+        }
     })
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
@@ -1144,8 +1282,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
         r.p2p = 0; r.p2p_seq = 0;
         static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
-        if (fold && !m->ilda && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
-        const bool ll_in_k2 = !ll_estep_env && (r.p2p || !mmm_comm_active(ctx));
+        if (fold && !m->ilda && !m->wide && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
+        const bool ll_in_k2 = !ll_estep_env && !m->wide && (r.p2p || !mmm_comm_active(ctx));
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
         r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
@@ -1159,7 +1297,10 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         if (rc) return rc;
         const int nred = (VK + 15) / 16;
-        if (r.n_ll > 0) {
+        if (m->wide) {
+            MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_stats_terms<KPV>, dim3(m->V + 1), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, m->V, m->K,
+                                                  m->term_ptr.p, m->tpost.p, m->aexp.p, m->expElnbeta[(t + 2) % 3].p, r); })
+        } else if (r.n_ll > 0) {
             const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
             MMM_KP_SWITCH(m, {
                 auto k = k_lda_reduce_ll<KPV>;
@@ -1293,19 +1434,20 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     int waves = small ? swaves : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
-    if (lds_for(waves) > 160 * 1024)
-        return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K*V = %d*%d needs %zu B of LDS (> 160 KiB)", K, V, lds_for(waves));
+    // tables + one slab beyond LDS: the wide path (k_lda_estep_wide); MMM_LDA_WIDE=1 forces it for any shape (tests, A/B)
+    const bool wide = lds_for(waves) > 160 * 1024 || getenv("MMM_LDA_WIDE") != nullptr;
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_lda* m = new mmm_lda();
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
-    m->waves_e = waves; m->lds_e = lds_for(waves); m->lds_tab = tabB;
-    if (const char* s = getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
+    m->waves_e = waves; m->lds_e = wide ? 0 : lds_for(waves); m->lds_tab = tabB; m->wide = wide;
+    if (const char* s = wide ? nullptr : getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
-    const int blocks_per_cu = std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
-    m->single_step = small && (int64_t)m->waves_e * G * ctx->num_cu >= D;
+    const int blocks_per_cu = wide ? 8 : std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
+    m->single_step = !wide && small && (int64_t)m->waves_e * G * ctx->num_cu >= D;
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
+    if (wide) m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * blocks_per_cu));     // wave per document
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
@@ -1314,7 +1456,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
-    A(partial, (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
+    A(partial, wide ? 1 : (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1);
     if (ilda) {
         A(features, (size_t)I * V);
@@ -1324,11 +1466,30 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * (D + 1), hipMemcpyHostToDevice, st));
     if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tc.p, tc.data(), sizeof(int2) * nnz, hipMemcpyHostToDevice, st));
+    std::vector<int64_t> tptr;
+    std::vector<int2> tpost;
+    if (wide) {     // postings by term, documents ascending within a term (counting sort): the summation order of k_lda_stats_terms
+        tptr.assign((size_t)V + 1, 0);
+        for (int64_t e = 0; e < nnz; ++e) tptr[(size_t)term[e] + 1]++;
+        for (int v = 0; v < V; ++v) tptr[(size_t)v + 1] += tptr[(size_t)v];
+        tpost.resize((size_t)nnz);
+        std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+        for (int d = 0; d < D; ++d)
+            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) tpost[(size_t)fill[(size_t)term[e]]++] = make_int2(d, count[e]);
+        hipError_t e1 = m->term_ptr.alloc((size_t)V + 1), e2 = m->tpost.alloc((size_t)nnz), e3 = m->aexp.alloc(KD);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); delete m; return rc; }
+        MMM_HIP(ctx, hipMemcpyAsync(m->term_ptr.p, tptr.data(), sizeof(int64_t) * ((size_t)V + 1), hipMemcpyHostToDevice, st));
+        if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tpost.p, tpost.data(), sizeof(int2) * (size_t)nnz, hipMemcpyHostToDevice, st));
+        // waves per term block: segments of >= 128 postings on average, at most 8
+        const int64_t avg = nnz / std::max(1, V);
+        m->stats_waves = 1;
+        while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
+    }
     std::vector<int2> ell;
     {   // padded rows for the ll blocks (V <= 128 slots, no duplicate terms: then a document always fits its row)
         int64_t maxW = 0;
         for (int d = 0; d < D; ++d) maxW = std::max<int64_t>(maxW, doc_ptr[d + 1] - doc_ptr[d]);
-        if (V <= 128 && maxW <= V && D > 0) {
+        if (V <= 128 && maxW <= V && D > 0 && !wide) {
             ell.assign((size_t)D * V, make_int2(-1, 0));
             for (int d = 0; d < D; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
