@@ -129,6 +129,12 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 __device__ __forceinline__ double wave_bcast(double v, int lane) { return __shfl(v, lane, MMM_WAVE); }
+// the same for a lane known at compile time, through v_readlane: the result lives in scalar registers
+__device__ __forceinline__ double wave_readlane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 
 // DPP move of a double (two 32-bit halves); CTRL is a DPP control word (quad_perm 0x00-0xFF, row_shr 0x110+n,
 // row_mirror 0x140, row_half_mirror 0x141)

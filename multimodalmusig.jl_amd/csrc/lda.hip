@@ -522,6 +522,35 @@ __global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double e
     }
 }
 
+// k_lda_mstep for wide vocabularies: 1024 threads per topic instead of one wave (V in the thousands), no folded exchange
+__global__ __launch_bounds__(1024) void k_lda_mstep_wide(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
+{
+    __shared__ double sh[16];
+    const int stop = r.ctl->stop;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c = r.t % 3;
+    if (k == (int)gridDim.x - 1) {
+        if (!stop && tid < 64) lda_tail_block(r, lane);
+        return;
+    }
+    if (stop) return;
+    const double* sums = r.stats + (size_t)k * V;
+    double part = 0.0;
+    for (int v = tid; v < V; v += 1024) part += eta + sums[v];
+    part = wave_sum(part);
+    if (lane == 0) sh[wid] = part;
+    __syncthreads();
+    double cs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) cs += sh[w];
+    const double psi = dev_digamma_pos(cs);
+    for (int v = tid; v < V; v += 1024) {
+        const double l = eta + sums[v];
+        const double el = dev_digamma_pos(l) - psi;
+        const size_t e = (size_t)k * V + v;
+        lambda.s[c][e] = l; Elnbeta.s[c][e] = el; expElnbeta.s[c][e] = exp(el); beta.s[c][e] = l / cs;
+    }
+}
+
 // ---- ILDA (src/ILDA.jl): LDA whose topic-term distribution factorises over I features of the term, beta_kv = prod_i
 // beta[i][f_vi, k].  The E-step, ll and ELBO document kernels run unchanged on EFFECTIVE V x K tables (Elnbeta_eff[v,k] =
 // sum_i Elnbeta[i][f_vi, k], exp of it, beta_eff = prod_i beta[i][f_vi, k]); only the topic M-step differs: the V x K
@@ -744,13 +773,27 @@ __global__ __launch_bounds__(kBlock) void k_lda_loglik(LdaDev c, const double* g
 // thousands).  Same pass structure and rings as the fused path, different data flow: the per-block statistics partials
 // (grid x K*V doubles) are out of the question here, and so is streaming phi (K*nnz doubles) out and back in a different
 // order.  Instead every phi_kw is evaluated TWICE, in two sweeps that each read 8 B per nonzero:
-//   * document-major (k_lda_estep_wide, one wave per document, table columns gathered through L2): Elntheta_t,
-//     a_d = exp(Elntheta_t) -> `aexp`, gamma_{t+1} = alpha + sum_w phi_t n, and (do_ll) the ll numerator of pass t-1;
+//   * document-major (k_lda_estep_wide, one wave per document, table rows gathered through L2 from term-major copies): Elntheta_t,
+//     a_d = exp(Elntheta_t) -> `aexp` (D x KP), gamma_{t+1} = alpha + sum_w phi_t n, and (do_ll) the ll numerator of pass t-1;
 //   * term-major (k_lda_stats_terms, one block per term over a posting list (doc, count) built at create): with the term's
-//     table column in scalar registers and a_d gathered from the L2-resident D x K array, stats[k][v] = sum_postings
+//     table column in scalar registers and a_d read from the L2-resident D x KP array (one contiguous row per posting), stats[k][v] = sum_postings
 //     n a_dk eB_kv / (sum_k' a_dk' eB_k'v) in posting order -- a fixed summation order, no atomics.
+// term-major copies of the two tables the document sweep gathers from ([v][KP], zero-padded): a lane then reads its term's
+// K values as one contiguous run (2-3 sectors) instead of K sectors V doubles apart -- 8x fewer L2 requests when documents
+// are sparse in the vocabulary, the same number when they are dense
+__global__ void k_lda_tables_by_term(int V, int K, int KP, const double* __restrict__ eB, const double* __restrict__ beta,
+                                     double* __restrict__ eBT, double* __restrict__ betaT)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)V * KP) return;
+    const int v = (int)(i / KP), k = (int)(i % KP);
+    eBT[i] = (k < K) ? eB[(size_t)k * V + v] : 0.0;
+    if (beta) betaT[i] = (k < K) ? beta[(size_t)k * V + v] : 0.0;
+}
+
 template <int KP>
-__global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* __restrict__ aexp)
+__global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* __restrict__ aexp, const double* __restrict__ eBT,
+                                                           const double* __restrict__ betaT)
 {
     __shared__ double shw[kWavesPerBlock];
     if (a.ctl->stop) return;
@@ -759,9 +802,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* 
     const double* __restrict__ gprev = a.gamma.s[(t + 2) % 3];
     double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
     double* __restrict__ Eln = a.Elntheta.s[t % 3];
-    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
-    const double* __restrict__ bprev = a.beta.s[(t + 2) % 3];
-    const int K = a.c.K, V = a.c.V, D = a.c.D;
+    const int K = a.c.K, D = a.c.D;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double wave_ll = 0.0;
     for (int d = blockIdx.x * kWavesPerBlock + wid; d < D; d += gridDim.x * kWavesPerBlock) {
@@ -770,7 +811,8 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* 
         const double ps = dev_digamma_pos(lane < K ? gk : S);          // lanes >= K hold psi(S)
         const double el = ps - wave_bcast(ps, K);
         const double ak = (lane < K) ? exp(el) : 0.0;
-        if (lane < K) { Eln[(size_t)d * K + lane] = el; aexp[(size_t)d * K + lane] = ak; }
+        if (lane < K) Eln[(size_t)d * K + lane] = el;
+        if (lane < KP) aexp[(size_t)d * KP + lane] = ak;      // D x KP rows, zero-padded
         double th = 0.0;
         if (a.do_ll) {
             const double gp = (lane < K) ? gprev[(size_t)d * K + lane] : 0.0;
@@ -778,23 +820,29 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* 
         }
         double av[KP], tv[KP], acc[KP];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) { av[k] = wave_bcast(ak, k); tv[k] = wave_bcast(th, k); acc[k] = 0.0; }
+        for (int k = 0; k < KP; ++k) { av[k] = wave_readlane(ak, k); tv[k] = wave_readlane(th, k); acc[k] = 0.0; }      // scalar registers
         const int64_t start = a.c.doc_ptr[d];
         const int W = (int)(a.c.doc_ptr[d + 1] - start);
         double ll = 0.0;
         for (int w = lane; w < W; w += MMM_WAVE) {
             const int2 tc = a.c.tc[start + w];
             const double n = (double)tc.y;
+            const double2* __restrict__ col = (const double2*)(eBT + (size_t)tc.x * KP);       // KP is even: 16-byte aligned
             double e[KP], s = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) { e[k] = (k < K) ? av[k] * eB[(size_t)k * V + tc.x] : 0.0; s += e[k]; }
+            for (int k = 0; k < KP; k += 2) {
+                const double2 b = col[k / 2];
+                e[k] = av[k] * b.x; e[k + 1] = av[k + 1] * b.y;          // padded topics: 0 * 0
+                s += e[k]; s += e[k + 1];
+            }
             const double rn = n / s;
 #pragma unroll
             for (int k = 0; k < KP; ++k) acc[k] = fma(e[k], rn, acc[k]);
             if (a.do_ll) {
+                const double2* __restrict__ bc = (const double2*)(betaT + (size_t)tc.x * KP);
                 double p = 0.0;
 #pragma unroll
-                for (int k = 0; k < KP; ++k) if (k < K) p = fma(tv[k], bprev[(size_t)k * V + tc.x], p);
+                for (int k = 0; k < KP; k += 2) { const double2 b = bc[k / 2]; p = fma(tv[k], b.x, p); p = fma(tv[k + 1], b.y, p); }
                 ll = fma(n, log(p), ll);
             }
         }
@@ -839,10 +887,10 @@ __global__ __launch_bounds__(512) void k_lda_stats_terms(int V, int K, const int
     const int64_t q0 = p0 + wid * seg, q1 = (q0 + seg < p1) ? q0 + seg : p1;
     for (int64_t j = q0 + lane; j < q1; j += MMM_WAVE) {
         const int2 dn = tpost[j];
-        const double* __restrict__ ad = aexp + (size_t)dn.x * K;
+        const double2* __restrict__ ad = (const double2*)(aexp + (size_t)dn.x * KP);      // one contiguous run per posting
         double e[KP], s = 0.0;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) { e[k] = (k < K) ? ad[k] * eb[k] : 0.0; s += e[k]; }
+        for (int k = 0; k < KP; k += 2) { const double2 x = ad[k / 2]; e[k] = x.x * eb[k]; e[k + 1] = x.y * eb[k + 1]; s += e[k]; s += e[k + 1]; }
         const double rn = (double)dn.y / s;
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[k] = fma(e[k], rn, acc[k]);
@@ -1053,7 +1101,8 @@ struct mmm_lda {
     bool wide = false;          // K*V tables larger than LDS: k_lda_estep_wide + k_lda_stats_terms, tables through L2
     DevBuf<int64_t> term_ptr;           // wide: the postings of term v are tpost[term_ptr[v] .. term_ptr[v+1])
     DevBuf<int2> tpost;                 // (document, count), documents ascending within a term
-    DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x K, written by the document sweep for the term sweep
+    DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x KP, written by the document sweep for the term sweep
+    DevBuf<double> tabT;                // wide: [2][V][KP] term-major copies of the pass's exp(Elnbeta) and beta tables
     int stats_waves = 1;                // waves per term block of k_lda_stats_terms
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
@@ -1128,7 +1177,11 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
     mmm_ctx* ctx = m->ctx;
     int rc = MMM_OK;
     if (m->wide) {
-        MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_estep_wide<KPV>, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, a, m->aexp.p); })
+        const size_t n = (size_t)m->V * m->KP;
+        const int slot = (a.t + 2) % 3;
+        hipLaunchKernelGGL(k_lda_tables_by_term, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->V, m->K, m->KP,
+                           (const double*)a.expElnbeta.s[slot], a.do_ll ? (const double*)a.beta.s[slot] : (const double*)nullptr, m->tabT.p, m->tabT.p + n);
+        MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_estep_wide<KPV>, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n); })
         MMM_LAUNCH_CHECK(ctx);
         return MMM_OK;
     }
@@ -1315,7 +1368,10 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             const int c = t % 3;
             hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                                m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0, r, 1);
-        } else
+        } else if (m->wide)
+            hipLaunchKernelGGL(k_lda_mstep_wide, dim3(m->K + 1), dim3(1024), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+                               m->ring(m->expElnbeta), m->ring(m->beta));
+        else
             hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(128), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
                                m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
@@ -1476,8 +1532,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
         for (int d = 0; d < D; ++d)
             for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) tpost[(size_t)fill[(size_t)term[e]]++] = make_int2(d, count[e]);
-        hipError_t e1 = m->term_ptr.alloc((size_t)V + 1), e2 = m->tpost.alloc((size_t)nnz), e3 = m->aexp.alloc(KD);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); delete m; return rc; }
+        hipError_t e1 = m->term_ptr.alloc((size_t)V + 1), e2 = m->tpost.alloc((size_t)nnz), e3 = m->aexp.alloc((size_t)KP * D), e4 = m->tabT.alloc((size_t)2 * V * KP);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); delete m; return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(m->term_ptr.p, tptr.data(), sizeof(int64_t) * ((size_t)V + 1), hipMemcpyHostToDevice, st));
         if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tpost.p, tpost.data(), sizeof(int2) * (size_t)nnz, hipMemcpyHostToDevice, st));
         // waves per term block: segments of >= 128 postings on average, at most 8
