@@ -104,3 +104,23 @@ def test_wide_ilda(mmm, oracle, monkeypatch):
     ll_o = o.fit(maxiter=14, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-8)
+
+
+def test_wide_degenerate_shapes(mmm, oracle, monkeypatch):
+    """K = 1, a single document, all documents empty but one, unused vocabulary tail, and a term listed twice in a document."""
+    for D, V, K, empty in [(5, 7, 1, ()), (1, 96, 10, ()), (6, 30, 4, (0, 1, 2, 4, 5)), (3, 200, 2, ())]:
+        X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, V, K, seed=900 + D + K, mean_n=50, empty=empty)
+        ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
+        ll_o = o.fit(maxiter=4, tol=0.0)
+        np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+        _cmp_state(g, o, 1e-9)
+        assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+        g.close()
+    X = [np.array([[1, 3], [2, 5], [1, 2]]), np.array([[2, 4], [3, 1]])]              # term 1 twice in document 0
+    lam0 = np.random.default_rng(1).integers(1, 101, size=(3, 2)).astype(np.float64)
+    monkeypatch.setenv("MMM_LDA_WIDE", "1")
+    g = mmm.LDA(2, 0.1, 0.1, 3, X, λ0=lam0)
+    monkeypatch.delenv("MMM_LDA_WIDE")
+    o = oracle.LdaOracle(2, 0.1, 0.1, X, V=3, lambda0=lam0)
+    np.testing.assert_allclose(mmm.fit(g, maxiter=5, tol=0.0, verbose=False), o.fit(maxiter=5, tol=0.0), rtol=1e-11)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(3, 2, order="F"), rtol=1e-11)

@@ -30,9 +30,11 @@ print("RESULT " + json.dumps({"transport": ctx.transport, "ll": ll.tolist(), "el
 """
 
 
-def _run(force, mailboxes=False):
+def _run(force, mailboxes=False, wide=False):
     env = dict(os.environ)
-    env.pop("MMM_FORCE_RCCL", None); env.pop("MMM_P2P_ONE_RANK", None)
+    env.pop("MMM_FORCE_RCCL", None); env.pop("MMM_P2P_ONE_RANK", None); env.pop("MMM_LDA_WIDE", None)
+    if wide:
+        env["MMM_LDA_WIDE"] = "1"
     if force:
         env["MMM_FORCE_RCCL"] = "1"
     if mailboxes:
@@ -64,3 +66,12 @@ def test_one_rank_mailbox_setup_over_rccl_and_folded_exchange():
     np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
     np.testing.assert_allclose([a["elbo"], a["lam"]], [b["elbo"], b["lam"]], rtol=1e-13)
     assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
+
+
+def test_one_rank_collectives_on_the_wide_vocabulary_path():
+    """The wide LDA data flow (tests/test_lda_wide_gpu.py) with its statistics going through the all-reduce: ncclAllReduce, and
+    the stand-alone mailbox kernel (the exchange is not folded into the wide kernels)."""
+    a = _run(False, wide=True)
+    for b in (_run(True, wide=True), _run(True, mailboxes=True, wide=True)):
+        np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
+        np.testing.assert_allclose([a["elbo"], a["lam"]], [b["elbo"], b["lam"]], rtol=1e-13)
