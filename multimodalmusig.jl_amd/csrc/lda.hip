@@ -315,6 +315,7 @@ __device__ void lda_pass_tail(const ReduceArgs& r)
 
 // the pass-tail block (one wave) of the M-step launches: finishes the ll numerator of pass t-1 -- sum of the k_lda_reduce_ll
 // partials and/or the peers' share -- and runs lda_pass_tail
+template <bool P2P>
 __device__ __forceinline__ void lda_tail_block(const ReduceArgs& r, int lane)
 {
     double v = 0.0;
@@ -325,10 +326,10 @@ __device__ __forceinline__ void lda_tail_block(const ReduceArgs& r, int lane)
     if (lane != 0) return;
     if (r.ll_in_k2) {
         if (r.do_ll) {
-            if (r.p2p) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
+            if (P2P && r.p2p) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
             r.stats[r.VK] = v;
         }
-    } else if (r.p2p) r.stats[r.VK] = p2p_recv_sum(r.px, r.p2p_seq, r.VK, r.stats[r.VK]);
+    } else if (P2P && r.p2p) r.stats[r.VK] = p2p_recv_sum(r.px, r.p2p_seq, r.VK, r.stats[r.VK]);
     lda_pass_tail(r);
 }
 
@@ -495,16 +496,18 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
 // ll_{t-1}, the stopping rule and the pass counter.
 // Blocks of two waves: with the mailbox exchange folded in, both waves receive (V <= 128 entries in ONE polling round);
 // wave 0 alone then runs the topic's M-step.
+// P2P = false: the build without the mailbox code (its polling arrays live in scratch memory; a single-GPU launch carries none).
+template <bool P2P>
 __global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
 {
     const int stop = r.ctl->stop;
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, c = r.t % 3;
     if (k == (int)gridDim.x - 1) {      // the extra block: pass tail, concurrent with the topic blocks (its loads are a dependent chain)
-        if (!stop && tid < 64) lda_tail_block(r, lane);
+        if (!stop && tid < 64) lda_tail_block<P2P>(r, lane);
         return;
     }
     double* sums = r.stats + (size_t)k * V;
-    if (r.p2p) {             // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
+    if (P2P && r.p2p) {             // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
         if (!stop) for (int v = tid; v < V; v += 128) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
         __syncthreads();
     }
@@ -522,28 +525,28 @@ __global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double e
     }
 }
 
-// k_lda_mstep for wide vocabularies: 1024 threads per topic instead of one wave (V in the thousands), no folded exchange
-__global__ __launch_bounds__(1024) void k_lda_mstep_wide(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
+// k_lda_mstep for wide vocabularies: 512 threads per topic instead of one wave (V in the thousands), no folded exchange
+__global__ __launch_bounds__(512) void k_lda_mstep_wide(ReduceArgs r, int V, double eta, Ring lambda, Ring Elnbeta, Ring expElnbeta, Ring beta)
 {
     __shared__ double sh[16];
     const int stop = r.ctl->stop;
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, c = r.t % 3;
     if (k == (int)gridDim.x - 1) {
-        if (!stop && tid < 64) lda_tail_block(r, lane);
+        if (!stop && tid < 64) lda_tail_block<false>(r, lane);
         return;
     }
     if (stop) return;
     const double* sums = r.stats + (size_t)k * V;
     double part = 0.0;
-    for (int v = tid; v < V; v += 1024) part += eta + sums[v];
+    for (int v = tid; v < V; v += 512) part += eta + sums[v];
     part = wave_sum(part);
     if (lane == 0) sh[wid] = part;
     __syncthreads();
     double cs = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) cs += sh[w];
+    for (int w = 0; w < 8; ++w) cs += sh[w];
     const double psi = dev_digamma_pos(cs);
-    for (int v = tid; v < V; v += 1024) {
+    for (int v = tid; v < V; v += 512) {
         const double l = eta + sums[v];
         const double el = dev_digamma_pos(l) - psi;
         const size_t e = (size_t)k * V + v;
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const 
     if (stop && *stop) return;
     const int k = blockIdx.x, lane = threadIdx.x, V = ds.V, K = ds.K;
     if (with_tail && k == K) {           // extra block of the fused pass: ll_{t-1}, stopping rule, pass counter (as k_lda_mstep)
-        lda_tail_block(tail, lane);
+        lda_tail_block<false>(tail, lane);      // (the ILDA exchange is never folded)
         return;
     }
     for (int i = 0; i < ds.I; ++i) {
@@ -1369,11 +1372,11 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                                m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0, r, 1);
         } else if (m->wide)
-            hipLaunchKernelGGL(k_lda_mstep_wide, dim3(m->K + 1), dim3(1024), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
+            hipLaunchKernelGGL(k_lda_mstep_wide, dim3(m->K + 1), dim3(512), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
                                m->ring(m->expElnbeta), m->ring(m->beta));
         else
-            hipLaunchKernelGGL(k_lda_mstep, dim3(m->K + 1), dim3(128), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
-                               m->ring(m->expElnbeta), m->ring(m->beta));
+            hipLaunchKernelGGL(r.p2p ? k_lda_mstep<true> : k_lda_mstep<false>, dim3(m->K + 1), dim3(128), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda),
+                               m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta));
         MMM_LAUNCH_CHECK(ctx);
         // host mirror, assuming no early stop (sync_ctl corrects it)
         if (do_ll) m->n_hist++;
@@ -1490,8 +1493,10 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     int waves = small ? swaves : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
-    // tables + one slab beyond LDS: the wide path (k_lda_estep_wide); MMM_LDA_WIDE=1 forces it for any shape (tests, A/B)
-    const bool wide = lds_for(waves) > 160 * 1024 || getenv("MMM_LDA_WIDE") != nullptr;
+    // tables + one slab beyond LDS: the wide path (k_lda_estep_wide).  It also takes K > 24: the LDS kernel's 32-topic build
+    // spills (10k x 96-term documents, K = 32: 264 us per iteration against 189).  MMM_LDA_WIDE=1 / 0 forces / avoids it (tests, A/B).
+    const char* wide_env = getenv("MMM_LDA_WIDE");
+    const bool wide = lds_for(waves) > 160 * 1024 || (wide_env ? atoi(wide_env) != 0 : KP >= 32);
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_lda* m = new mmm_lda();

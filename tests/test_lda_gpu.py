@@ -164,8 +164,10 @@ def test_invariants_at_full_size(mmm):
 
 
 @pytest.mark.parametrize("D,V,K", [(70, 50, 16), (50, 96, 20), (40, 30, 32), (45, 96, 13)])
-def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, D, V, K):
-    """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16."""
+def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, monkeypatch, D, V, K):
+    """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16.
+    (K > 24 goes to the wide-vocabulary kernels by default -- tests/test_lda_wide_gpu.py; here the LDS kernels are kept in play.)"""
+    monkeypatch.setenv("MMM_LDA_WIDE", "0")
     X, g, o = _pair(mmm, oracle, D, V, K, seed=300 + K, empty=(2,))
     ll_g = mmm.fit(g, maxiter=13, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=13, tol=0.0)
