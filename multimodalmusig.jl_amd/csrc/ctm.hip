@@ -220,8 +220,10 @@ struct CtmEArgs {
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
 // PH = 1: the two LD_MMA solves (few registers, high occupancy: the solves are latency-bound dependent chains)
-template <int L, int PH, int MKT = 0, int KMX = 16>
-__global__ __launch_bounds__(PH ? 256 : 512, PH ? 4 : 1) void k_ctm_estep(CtmEArgs a)
+// OCC (solve phase): 4 waves per SIMD -- 128 VGPRs, with a few spilled values for MK = 10 / 14 -- when the launch has the waves to
+// fill them; 3 -- no scratch at all, and no scratch set-up between dispatches -- for small launches (a 560-document fit: +7 %)
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4>
+__global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;
@@ -1089,11 +1091,11 @@ struct Scope { int rep0, nrep; const int* active; };
 inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
 inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
 
-template <int L, int PH, int MKT = 0, int KMX = 16>
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4>
 int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L, PH, MKT, KMX>;
+    auto k = k_ctm_estep<L, PH, MKT, KMX, OCC>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
@@ -1118,8 +1120,9 @@ template <int PH>
 int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
-        if (m->L == 16 && m->dm.MK == 10) return launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
-        if (m->L == 16 && m->dm.MK == 14) return launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
+        const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
+        if (m->L == 16 && m->dm.MK == 10) return small ? launch_estep_L<16, PH, 10, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
+        if (m->L == 16 && m->dm.MK == 14) return small ? launch_estep_L<16, PH, 14, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
         if (m->L == 32 && m->dm.MK == 28) return launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
     }
     if constexpr (PH == 0) {      // theta phase: a modality with more than 16 topics takes the build unrolled to 32
