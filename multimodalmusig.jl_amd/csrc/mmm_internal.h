@@ -99,7 +99,9 @@ constexpr int kP2PMaxRanks = 16;
 constexpr size_t kP2PCap = 8192;            // doubles per call (LDA: 961; CTM cfg 4: 2,450)
 
 struct P2PArgs {
-    unsigned long long* peer[kP2PMaxRanks];   // mailbox base of every rank (peer[rank] = the local one)
+    // mailbox base of every rank (peer[rank] = the local one): a table in device memory -- an array inside this by-value
+    // argument block would be indexed dynamically, which sends the whole block (and the kernel's other arguments) to scratch
+    unsigned long long* const* peer;
     int nranks, rank;
     size_t cap;
     int* err;                                 // device word: sequence number of a call that timed out (0 = none)

@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(P2PArgs a, double* buf, i
 
 struct mmm_p2p {
     P2PArgs args{};
+    unsigned long long* peer_h[kP2PMaxRanks] = {nullptr};     // host copy of the table args.peer points to
+    unsigned long long** peer_d = nullptr;
     void* local = nullptr;
     void* opened[kP2PMaxRanks] = {nullptr};
     int* err = nullptr;
@@ -53,7 +55,10 @@ static int p2p_alloc(mmm_ctx* ctx, int nranks)
     hipError_t e = hipExtMallocWithFlags(&p->local, p->bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) { delete p; return mmm_fail(ctx, MMM_ERR_HIP, "p2p: fine-grained allocation of %zu bytes: %s", p->bytes, hipGetErrorString(e)); }
     e = hipMalloc((void**)&p->err, sizeof(int));
-    if (e != hipSuccess) { (void)hipFree(p->local); delete p; return mmm_fail(ctx, MMM_ERR_HIP, "p2p: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipMalloc((void**)&p->peer_d, sizeof(unsigned long long*) * kP2PMaxRanks);
+    if (e != hipSuccess) { (void)hipFree(p->local); if (p->err) (void)hipFree(p->err); delete p; return mmm_fail(ctx, MMM_ERR_HIP, "p2p: %s", hipGetErrorString(e)); }
+    MMM_HIP(ctx, hipMemset(p->peer_d, 0, sizeof(unsigned long long*) * kP2PMaxRanks));
+    p->args.peer = p->peer_d;
     MMM_HIP(ctx, hipMemset(p->local, 0, p->bytes));
     MMM_HIP(ctx, hipMemset(p->err, 0, sizeof(int)));
     MMM_HIP(ctx, hipDeviceSynchronize());
@@ -73,6 +78,7 @@ void mmm_p2p_release(mmm_ctx* ctx)
     for (int r = 0; r < kP2PMaxRanks; ++r) if (p->opened[r]) (void)hipIpcCloseMemHandle(p->opened[r]);
     if (p->local) (void)hipFree(p->local);
     if (p->err) (void)hipFree(p->err);
+    if (p->peer_d) (void)hipFree(p->peer_d);
     delete p;
     ctx->p2p = nullptr; ctx->p2p_on = false;
 }
@@ -169,14 +175,15 @@ int mmm_p2p_attach(mmm_ctx* ctx, int nranks, int rank, const char* handles)
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     mmm_p2p* p = ctx->p2p;
     for (int r = 0; r < nranks; ++r) {
-        if (r == rank) { p->args.peer[r] = (unsigned long long*)p->local; continue; }
+        if (r == rank) { p->peer_h[r] = (unsigned long long*)p->local; continue; }
         hipIpcMemHandle_t h;
         memcpy(&h, handles + (size_t)r * MMM_P2P_HANDLE_BYTES, sizeof h);
         void* q = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) return mmm_fail(ctx, MMM_ERR_HIP, "mmm_p2p_attach: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
-        p->opened[r] = q; p->args.peer[r] = (unsigned long long*)q;
+        p->opened[r] = q; p->peer_h[r] = (unsigned long long*)q;
     }
+    MMM_HIP(ctx, hipMemcpy(p->peer_d, p->peer_h, sizeof p->peer_h, hipMemcpyHostToDevice));
     p->args.rank = rank;
     ctx->nranks = nranks; ctx->rank = rank;
     ctx->p2p_on = true;
@@ -199,7 +206,7 @@ int mmm_p2p_selftest(mmm_ctx* ctx, int* ok)
 int mmm_p2p_enable(mmm_ctx* ctx, int on)
 {
     if (!ctx) return MMM_ERR_ARG;
-    MMM_CHECK(ctx, !on || (ctx->p2p && ctx->p2p->args.peer[ctx->rank]), "mmm_p2p_enable: not attached");
+    MMM_CHECK(ctx, !on || (ctx->p2p && ctx->p2p->peer_h[ctx->rank]), "mmm_p2p_enable: not attached");
     ctx->p2p_on = on != 0;
     return MMM_OK;
 }
