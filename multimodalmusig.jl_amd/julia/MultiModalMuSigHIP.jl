@@ -463,6 +463,7 @@ mutable struct IMMCTM
         model.h = out[]
         finalizer(m -> ccall((:mmm_ctm_destroy, LIB), Cint, (Ptr{Cvoid},), m.h), model)
         model.converged = false
+        download!(model)
         return model
     end
 end
