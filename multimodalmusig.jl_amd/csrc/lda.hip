@@ -115,6 +115,23 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
         __builtin_amdgcn_sched_barrier(0);                                  // keep the two halves' live ranges apart
     }
     const double* bcol = sB + tcv.x;
+    if (KP >= 20) {
+        // many topics: the products are formed twice (a second LDS read of the column) instead of being kept -- 64 registers
+        // less, which is the difference between this build fitting its 256 and spilling
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k + 1 < KP; k += 2) { s0 = fma(av[k], bcol[k * V], s0); s1 = fma(av[k + 1], bcol[(k + 1) * V], s1); }
+        const double r = act ? n * dev_rcp(s0 + s1) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        double* scol = slab + tcv.x;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const double x = av[k] * bcol[k * V] * r;
+            acc[k] += x;
+            if (act) unsafeAtomicAdd(&scol[k * V], x);
+        }
+        return;
+    }
     double b[KP], s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) b[k] = av[k] * bcol[k * V];
