@@ -212,6 +212,7 @@ struct CtmEArgs {
     const double* lam_in; double* lam_out; double* nu; double* zeta; double* theta;
     double* sumth;          // [D][MK]: written by the theta phase, read by the solve phase
     double* partial;        // [gridDim][GT] (F_SLAB)
+    double* aexp;           // wide tables: [D][MK] exp(lambda - max) of the theta phase, for k_ctm_stats_terms
     int* nev_nu; int* nev_lam;   // per document (may be NULL)
     SolveOpts opt;
     int flags;
@@ -222,7 +223,10 @@ struct CtmEArgs {
 // PH = 1: the two LD_MMA solves (few registers, high occupancy: the solves are latency-bound dependent chains)
 // OCC (solve phase): 4 waves per SIMD -- 128 VGPRs, with a few spilled values for MK = 10 / 14 -- when the launch has the waves to
 // fill them; 3 -- no scratch at all, and no scratch set-up between dispatches -- for small launches (a 560-document fit: +7 %)
-template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4>
+// WIDE (theta phase): topic tables too large for LDS (a 1536-term modality, ...): the table is read through L2, no slabs --
+// the gamma statistics come from k_ctm_stats_terms, a term-major sweep over posting lists that evaluates theta_kw again from
+// the exp(lambda - max) rows this phase leaves in `aexp` (the scheme of the LDA wide path, lda.hip)
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false>
 __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
         for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = p_invSigma[i];
         for (int i = tid; i < MK; i += blockDim.x) sMu[i] = p_mu[i];
     } else {
-        if (flags & F_THETA_COMPUTE) for (int i = tid; i < GT; i += blockDim.x) sB[i] = p_expE[i];
-        if (flags & F_SLAB) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
+        if (!WIDE && (flags & F_THETA_COMPUTE)) for (int i = tid; i < GT; i += blockDim.x) sB[i] = p_expE[i];
+        if (!WIDE && (flags & F_SLAB)) for (int i = tid; i < NW * GT; i += blockDim.x) sSlab[i] = 0.0;
     }
     __syncthreads();
     double* slab = sSlab + (size_t)wid * GT;
@@ -297,10 +301,11 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
             }
             lds_wave_sync();
             scrA[l] = act ? exp(lam - mx) : 0.0;
+            if (WIDE && act && a.aexp && (flags & F_SLAB)) a.aexp[(rep * D + d) * MK + l] = scrA[l];
             lds_wave_sync();
             for (int m = 0; m < M; ++m) {
                 const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
-                const double* tb = sB + dm.goff[m];
+                const double* tb = WIDE ? p_expE + dm.goff[m] : sB + dm.goff[m];
                 double* sl = slab + dm.goff[m];
                 const int64_t* dp = a.c.doc_ptr + (size_t)m * (D + 1);
                 const int64_t start = valid ? dp[d] : 0;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
                         const double pn = e[k] * r;
                         acc[k] += pn;
                         if (aw && k < Km) {
-                            if (flags & F_SLAB) unsafeAtomicAdd(&sl[k * Vm + tcv.x], pn);
+                            if (!WIDE && (flags & F_SLAB)) unsafeAtomicAdd(&sl[k * Vm + tcv.x], pn);
                             if (flags & F_THETA_STORE) th[k] = e[k] * inv;
                         }
                     }
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
             if (p_nev_lam && valid && l == 0) p_nev_lam[d] = nev;
         }
     }
-    if (PH == 0 && (flags & F_SLAB)) {
+    if (PH == 0 && !WIDE && (flags & F_SLAB)) {
         __syncthreads();
         double* out = p_partial + (size_t)blockIdx.x * GT;
         for (int i = tid; i < GT; i += blockDim.x) {
@@ -399,6 +404,50 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
     const double f2 = no.eval<64>(v, g2);
     if (l == 0) { out[0] = -f1; out[1] = -f2; }
     if (act) { out[2 + l] = -g1; out[2 + MK + l] = -g2; }
+}
+
+// wide tables: gamma statistics of one (modality, term) per block -- sums[goff[m] + k V_m + v] = sum over the term's postings of
+// n theta_kw (MMCTM.jl:230-240), theta_kw = a_dk e_kv / sum_k' a_dk' e_k'v from the theta phase's a_d rows and the term's table
+// column (scalar registers).  Postings (doc, count) in document order, split over the block's waves in contiguous segments,
+// segment sums added in segment order: a fixed summation order, no atomics.
+template <int KMX>
+__global__ __launch_bounds__(512) void k_ctm_stats_terms(CtmDims dm, const int64_t* __restrict__ term_ptr, const int2* __restrict__ tpost,
+                                                         const double* __restrict__ aexp, const double* __restrict__ expE, double* __restrict__ out,
+                                                         size_t out_stride, const int* active)
+{
+    __shared__ double sh[8][KMX];
+    if (active && !active[blockIdx.y]) return;
+    const size_t rep = blockIdx.y;
+    int m = 0, v = blockIdx.x;
+    while (m + 1 < dm.M && v >= dm.V[m]) { v -= dm.V[m]; ++m; }
+    const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m], MK = dm.MK;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double* __restrict__ col = expE + rep * dm.GT + dm.goff[m] + v;
+    aexp += rep * (size_t)dm.D * MK + off;
+    double eb[KMX], acc[KMX];
+#pragma unroll
+    for (int k = 0; k < KMX; ++k) { eb[k] = (k < Km) ? col[(size_t)k * Vm] : 0.0; acc[k] = 0.0; }
+    const int64_t p0 = term_ptr[blockIdx.x], p1 = term_ptr[blockIdx.x + 1];
+    const int64_t seg = (p1 - p0 + nw - 1) / nw;
+    const int64_t q0 = p0 + wid * seg, q1 = (q0 + seg < p1) ? q0 + seg : p1;
+    for (int64_t j = q0 + lane; j < q1; j += MMM_WAVE) {
+        const int2 dn = tpost[j];
+        const double* __restrict__ ad = aexp + (size_t)dn.x * MK;
+        double e[KMX], s = 0.0;
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) { e[k] = (k < Km) ? ad[k] * eb[k] : 0.0; s += e[k]; }
+        const double rn = (double)dn.y / s;
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) acc[k] = fma(e[k], rn, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KMX; ++k) { const double tot = wave_sum(acc[k]); if (lane == 0) sh[wid][k] = tot; }
+    __syncthreads();
+    if ((int)threadIdx.x < Km) {
+        double tot = 0.0;
+        for (int w = 0; w < nw; ++w) tot += sh[w][threadIdx.x];
+        out[rep * out_stride + dm.goff[m] + (size_t)threadIdx.x * Vm + v] = tot;
+    }
 }
 
 // partial[nslab][n] -> out[n], fixed summation order; grid = ceil(n/16) blocks of (16, 64)
@@ -821,6 +870,7 @@ __global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmT
 // llpart[block][M]
 // gauss != 0: the launch carries one extra block (the last) that runs update_μ!/update_Σ! of the same pass -- the ll needs
 // only lambda and phi, the next E-step needs mu / Sigma^-1, so the 50 us single-block inversion hides behind the document sweep
+template <bool TAB_LDS>
 __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
                                                         int compute_ll, const int* active, MstepArgs ga, int gauss)
 {
@@ -839,9 +889,9 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * ndoc_blocks * M;
     if (props) props += (size_t)blockIdx.y * D * MK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    double* sP = smem;                       // [GT]
-    double* sPr = smem + GT + wid * 64;      // per-wave props
-    if (compute_ll) { for (int i = tid; i < GT; i += kBlockS) sP[i] = phieff[i]; }
+    const double* sP = TAB_LDS ? smem : phieff;                   // [GT]: staged, or (wide tables) read through L2
+    double* sPr = smem + (TAB_LDS ? GT : 0) + wid * 64;           // per-wave props
+    if (TAB_LDS && compute_ll) { for (int i = tid; i < GT; i += kBlockS) smem[i] = phieff[i]; }
     __syncthreads();
     int mod_l = 0;
     for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
@@ -918,6 +968,7 @@ __global__ void k_ll_store(int M, const double* num, size_t num_stride, const do
 
 // per-document ELBO pieces (MMCTM.jl:286-370): out[block][6] = {ElnPeta(without logdet/const), ElnPZ, ElnPX, ElnQeta, ElnQZ, count}
 // theta is rebuilt on the fly from (lam_prev, expE_prev) when theta == NULL
+template <bool TAB_LDS>
 __global__ __launch_bounds__(kBlockS) void k_ctm_elbo_docs(CtmDev c, const double* invSigma, const double* mu, const double* lam, const double* nu,
                                                            const double* zeta, const double* theta, const double* Eeff, double* out)
 {
@@ -926,9 +977,10 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_elbo_docs(CtmDev c, const doubl
     const CtmDims& dm = c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    double* sS = smem; double* sE = sS + MK * MK; double* scr = sE + GT + wid * 64;
+    double* sS = smem; double* sEl = sS + MK * MK; double* scr = sEl + (TAB_LDS ? GT : 0) + wid * 64;
+    const double* sE = TAB_LDS ? sEl : Eeff;
     for (int i = tid; i < MK * MK; i += kBlockS) sS[i] = invSigma[i];
-    for (int i = tid; i < GT; i += kBlockS) sE[i] = Eeff[i];
+    if (TAB_LDS) for (int i = tid; i < GT; i += kBlockS) sEl[i] = Eeff[i];
     __syncthreads();
     int mod_l = 0;
     for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
@@ -1078,6 +1130,12 @@ struct mmm_ctm {
     int theta_rep = -1;                       // replica whose theta is in the theta buffer (-1: none)
     int cap_hist = 0;
     int grid_e = 1, waves_e = 8, grid_s = 1, grid_m = 1, grid_v = 1, waves_s = 4;
+    // wide tables (sum_m K_m V_m beyond LDS): theta phase without table / slabs in LDS + k_ctm_stats_terms over posting lists
+    bool wide = false;
+    int stats_waves = 1, nterms = 0;
+    DevBuf<int64_t> term_ptr;      // [sum V + 1], modality-major
+    DevBuf<int2> tpost;            // (document, count) per posting
+    DevBuf<double> aexp;           // [R][D][MK]
     int nmom = 0, nalpha = 0; size_t s_stats = 0, s_llnum = 0;
     std::vector<double> hNm;
     CtmDev dev() const { return CtmDev{dm, doc_ptr.p, tc.p, Ndm.p}; }
@@ -1091,11 +1149,11 @@ struct Scope { int rep0, nrep; const int* active; };
 inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
 inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
 
-template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4>
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false>
 int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L, PH, MKT, KMX, OCC>;
+    auto k = k_ctm_estep<L, PH, MKT, KMX, OCC, WIDE>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
@@ -1105,6 +1163,7 @@ int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int wave
 size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 {
     const int G = MMM_WAVE / m->L;
+    if (m->wide) return sizeof(double) * (size_t)m->waves_e * G * 2 * m->L;
     size_t n = (size_t)m->dm.GT + (size_t)m->waves_e * G * 2 * m->L;
     if (flags & F_SLAB) n += (size_t)m->waves_e * m->dm.GT;
     return n * sizeof(double);
@@ -1128,6 +1187,12 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
     if constexpr (PH == 0) {      // theta phase: a modality with more than 16 topics takes the build unrolled to 32
         int kmax = 0;
         for (int i = 0; i < m->dm.M; ++i) kmax = std::max(kmax, m->dm.K[i]);
+        if (m->wide) {
+            if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32, 4, true>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32, 4, true>(m, a, lds, grid, waves, nrep);
+            if (m->L == 16) return launch_estep_L<16, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
+            if (m->L == 32) return launch_estep_L<32, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
+            return launch_estep_L<64, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
+        }
         if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32>(m, a, lds, grid, waves, nrep);
     }
     if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves, nrep);
@@ -1143,7 +1208,8 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
     CtmEArgs a{m->dev(), m->invSigma.p + r0 * MK * MK, m->mu.p + r0 * MK, expE ? expE + r0 * dm.GT : nullptr, lam_in + r0 * DMK,
                lam_out ? lam_out + r0 * DMK : nullptr, m->nu.p + r0 * DMK, m->zeta.p + r0 * dm.D * dm.M,
                (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->sumth.p + r0 * DMK,
-               m->partial.p + r0 * m->grid_e * dm.GT, m->nev_nu.p + r0 * dm.D, m->nev_lam.p + r0 * dm.D, m->opt, flags, sc.active};
+               m->wide ? nullptr : m->partial.p + r0 * m->grid_e * dm.GT, m->wide ? m->aexp.p + r0 * dm.D * MK : nullptr,
+               m->nev_nu.p + r0 * dm.D, m->nev_lam.p + r0 * dm.D, m->opt, flags, sc.active};
     int rc;
     if (flags & (F_ZETA | F_THETA_COMPUTE | F_THETA_STORED | F_SLAB)) {
         const size_t lds = estep_lds(m, flags);
@@ -1249,9 +1315,10 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     const int M = m->dm.M;
     const size_t r0 = sc.rep0;
     const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
-    const size_t lds = sizeof(double) * std::max((size_t)m->dm.GT + kWavesS * 64, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
-    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_ctm_loglik, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
+    const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
+    auto kll = m->wide ? k_ctm_loglik<false> : k_ctm_loglik<true>;
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kll, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
                        m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
                        mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
     MMM_LAUNCH_CHECK(ctx);
@@ -1346,7 +1413,15 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                        m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
     MMM_LAUNCH_CHECK(ctx);
-    {   // moments and gamma sums reduced by one launch
+    if (m->wide) {   // gamma sums by the term-major sweep, moments reduced on their own
+        int kmax = 0;
+        for (int i = 0; i < dm.M; ++i) kmax = std::max(kmax, dm.K[i]);
+        auto ks = kmax > 16 ? k_ctm_stats_terms<32> : k_ctm_stats_terms<16>;
+        hipLaunchKernelGGL(ks, dim3(m->nterms, sc.nrep), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, dm, m->term_ptr.p, m->tpost.p,
+                           m->aexp.p + r0 * dm.D * dm.MK, m->expEeff.p + r0 * dm.GT, m->stats.p + r0 * m->s_stats + m->nmom, m->s_stats, sc.active);
+        MMM_LAUNCH_CHECK(ctx);
+        if ((rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats))) return rc;
+    } else {   // moments and gamma sums reduced by one launch
         const int nb1 = (m->nmom + 15) / 16, nb2 = (dm.GT + 15) / 16;
         hipLaunchKernelGGL(k_reduce_partials, dim3(nb1 + nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + r0 * m->grid_m * m->nmom, m->grid_m,
                            m->nmom, m->stats.p + r0 * m->s_stats, m->s_stats, sc.active, nb1, m->partial.p + r0 * m->grid_e * dm.GT, m->grid_e, dm.GT,
@@ -1508,9 +1583,11 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     const int G = MMM_WAVE / m->L;
     m->waves_e = 8;
     while (m->waves_e > 1 && estep_lds(m, F_SLAB) > 150 * 1024) m->waves_e >>= 1;
-    if (estep_lds(m, F_SLAB) > 160 * 1024) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: topic tables need %zu B of LDS (> 160 KiB)", estep_lds(m, F_SLAB)); delete m; return rc; }
+    // table + one slab beyond LDS: the wide path (theta phase through L2, gamma statistics by k_ctm_stats_terms).  MMM_CTM_WIDE=1
+    // forces it for any shape (tests, A/B)
+    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr) { m->wide = true; m->waves_e = 8; }
     const int dpb = m->waves_e * G;
-    const int per_cu = std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
+    const int per_cu = m->wide ? 2 : std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
     if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
@@ -1529,7 +1606,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     A(lambda, Rz * DMK); A(lambda_prev, Rz * DMK); A(nu, Rz * DMK); A(sumth, Rz * DMK); A(zeta, Rz * D * M); A(props, Rz * DMK); A(theta, (size_t)toff);
     A(mu, Rz * MK); A(Sigma, Rz * MK * MK); A(invSigma, Rz * MK * MK); A(gamma, Rz * GM); A(Elnphi, Rz * GM); A(phi, Rz * GM);
     A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
-    A(partial, Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
+    A(partial, m->wide ? 1 : Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
     A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
     A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz);
 #undef A
@@ -1540,6 +1617,35 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     if (!featv.empty()) MMM_HIP(ctx, hipMemcpyAsync(m->features.p, featv.data(), sizeof(int) * featv.size(), hipMemcpyHostToDevice, st));
     for (size_t r = 0; r < Rz; ++r) MMM_HIP(ctx, hipMemcpyAsync(m->alpha.p + r * nalpha, alpha, sizeof(double) * nalpha, hipMemcpyHostToDevice, st));
     MMM_HIP(ctx, hipMemcpyAsync(m->gamma.p, gamma0, sizeof(double) * Rz * GM, hipMemcpyHostToDevice, st));
+    std::vector<int64_t> tptr;
+    std::vector<int2> tpost;
+    if (m->wide) {      // posting lists per (modality, term), documents ascending: the summation order of k_ctm_stats_terms
+        int nterms = 0;
+        std::vector<int> voff(M + 1, 0);
+        for (int i = 0; i < M; ++i) { voff[i + 1] = voff[i] + V[i]; }
+        nterms = voff[M];
+        tptr.assign((size_t)nterms + 1, 0);
+        for (int i = 0; i < M; ++i) {
+            const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
+            for (int64_t e = dp[0]; e < dp[D]; ++e) tptr[(size_t)voff[i] + term[e] + 1]++;
+        }
+        for (int t = 0; t < nterms; ++t) tptr[(size_t)t + 1] += tptr[(size_t)t];
+        tpost.resize((size_t)nnz);
+        std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+        for (int i = 0; i < M; ++i) {
+            const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
+            for (int d = 0; d < D; ++d)
+                for (int64_t e = dp[d]; e < dp[d + 1]; ++e) tpost[(size_t)fill[(size_t)voff[i] + term[e]]++] = make_int2(d, count[e]);
+        }
+        m->nterms = nterms;
+        hipError_t e1 = m->term_ptr.alloc((size_t)nterms + 1), e2 = m->tpost.alloc((size_t)nnz), e3 = m->aexp.alloc(Rz * DMK);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); delete m; return rc; }
+        MMM_HIP(ctx, hipMemcpyAsync(m->term_ptr.p, tptr.data(), sizeof(int64_t) * ((size_t)nterms + 1), hipMemcpyHostToDevice, st));
+        if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tpost.p, tpost.data(), sizeof(int2) * (size_t)nnz, hipMemcpyHostToDevice, st));
+        const int64_t avg = nnz / std::max(1, nterms);
+        m->stats_waves = 1;
+        while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
+    }
     MMM_HIP(ctx, hipMemsetAsync(m->status.p, 0, sizeof(int) * R, st));
     MMM_HIP(ctx, hipMemsetAsync(m->nev_nu.p, 0, sizeof(int) * std::max<size_t>(Rz * D, 1), st));
     MMM_HIP(ctx, hipMemsetAsync(m->nev_lam.p, 0, sizeof(int) * std::max<size_t>(Rz * D, 1), st));
@@ -1897,10 +2003,11 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     if (rc || (rc = materialise_theta(m))) return rc;
     const CtmDims& dm = m->dm;
     const size_t MKz = dm.MK, r = m->sel;
-    const size_t lds = sizeof(double) * (MKz * MKz + dm.GT + kWavesS * 64);
-    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_docs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = sizeof(double) * (MKz * MKz + (m->wide ? 0 : dm.GT) + kWavesS * 64);
+    auto kel = m->wide ? k_ctm_elbo_docs<false> : k_ctm_elbo_docs<true>;
+    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double* acc = m->elbopart.p + (size_t)m->grid_s * 5;     // [0..4] doc sums, [5..7] topic side
-    hipLaunchKernelGGL(k_ctm_elbo_docs, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p + r * MKz * MKz, m->mu.p + r * MKz,
+    hipLaunchKernelGGL(kel, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p + r * MKz * MKz, m->mu.p + r * MKz,
                        m->lambda.p + r * m->sDMK(), m->nu.p + r * m->sDMK(), m->zeta.p + r * dm.D * dm.M, m->theta.p, m->Eeff.p + r * dm.GT, m->elbopart.p);
     hipLaunchKernelGGL(k_sum_columns, dim3(5, 1), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc, (size_t)0, (const int*)nullptr);
     const size_t lds2 = sizeof(double) * 2 * MKz * MKz;

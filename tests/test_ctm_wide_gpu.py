@@ -1,0 +1,105 @@
+"""MMCTM / IMMCTM with topic tables beyond LDS (a 1536- or 3000-term modality): the wide path -- θ phase reading the table
+through L2, γ statistics from a term-major posting sweep that evaluates θ again (k_ctm_stats_terms), ll / ELBO kernels without the
+staged table -- against the CPU oracle and against the LDS path on the same inputs.  `MMM_CTM_WIDE=1` (read at create) forces it."""
+import numpy as np
+import pytest
+
+import np_ref
+from test_ctm_batch_gpu import FIELDS, _inits, _make
+from test_ctm_gpu import SNV3, _cmp_docs, _pair, _robust_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _wide_pair(mmm, oracle, monkeypatch, *a, **kw):
+    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+    out = _pair(mmm, oracle, *a, **kw)
+    monkeypatch.delenv("MMM_CTM_WIDE")
+    return out
+
+
+@pytest.mark.parametrize("case", ["mm2", "mm3", "imm", "k20"])
+def test_forced_wide_pass_against_oracle(mmm, oracle, monkeypatch, case):
+    D, K, V, means, feats = {"mm2": (64, [7, 7], [96, 48], [3000, 60], None), "mm3": (45, [10, 10, 8], [96, 38, 32], [2000, 150, 100], None),
+                             "imm": (50, [10], [96], [2500], SNV3), "k20": (40, [20, 12], [40, 25], [300, 200], None)}[case]
+    X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, K, V, seed=77, means=means, imm_features=feats)
+    MK, M = sum(K), len(K)
+    check = mmm._lib.check
+    for it in range(2):
+        check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        o.estep_range(0, D); o.update_mu(); o.update_Sigma(); o.update_gamma()
+        if feats is None:
+            o.update_props(); o.update_phi()
+        _cmp_docs(g, o, D, MK, M)
+        np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=1e-5)
+        np.testing.assert_allclose(g.μ, o.mu, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(g._get("theta"), o.theta, rtol=1e-5, atol=1e-12)          # rebuilt on demand through the wide θ phase
+    ll = np.zeros(2 * M); n = mmm._lib.C.c_int()
+    check(mmm.lib().mmm_ctm_ll_history(g._h, ll.ctypes.data, 2, mmm._lib.C.byref(n)), g.ctx.h)
+    np.testing.assert_allclose(ll.reshape(2, M)[-1], o.loglik(), rtol=1e-6)
+    assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
+
+
+def test_wide_first_pass_equals_lds_path(mmm, monkeypatch):
+    """One pass from the same state through both data flows: the γ statistics differ by summation order only."""
+    D, K, V = 120, [7, 7], [96, 48]
+    X, g0 = np_ref.synth_mm(D, V, K, seed=3, means=[3000, 60], empty_frac=0.1)
+    a = mmm.MMCTM(K, [0.1, 0.1], V, X, γ0=g0)
+    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+    b = mmm.MMCTM(K, [0.1, 0.1], V, X, γ0=g0)
+    monkeypatch.delenv("MMM_CTM_WIDE")
+    for m in (a, b):
+        mmm._lib.check(mmm.lib().mmm_ctm_iterate(m._h, 1, 1), m.ctx.h, "iterate")
+    # the two θ-loop builds round sumθ differently in the last bits, which the solves carry through (and, rarely, a stopping
+    # decision amplifies): tight for nearly all documents, loose bound for the rest
+    MK = sum(K)
+    _robust_close(a._get("lambda").reshape(D, MK), b._get("lambda").reshape(D, MK))
+    _robust_close(a._get("nu").reshape(D, MK), b._get("nu").reshape(D, MK))
+    np.testing.assert_allclose(a._get("zeta"), b._get("zeta"), rtol=1e-12)
+    np.testing.assert_allclose(a._get("gamma"), b._get("gamma"), rtol=1e-4)
+    np.testing.assert_allclose(mmm.calculate_loglikelihoods(a), mmm.calculate_loglikelihoods(b), rtol=1e-7)
+
+
+@pytest.mark.parametrize("case", ["mm_3000", "imm_1536"])
+def test_tables_beyond_lds(mmm, oracle, case):
+    """Shapes the LDS path refuses: an MMCTM whose first modality has 3000 terms (K·V = 18,000 doubles + a 48-term modality), and
+    an IMMCTM over a 1536-term vocabulary factorised into five 4/6-valued features."""
+    if case == "mm_3000":
+        D, K, V, means, feats = 70, [6, 4], [3000, 48], [2500, 80], None
+    else:
+        ctx5 = np.array([[(t // 384) % 4 + 1, (t // 96) % 4 + 1, (t // 16) % 6 + 1, (t // 4) % 4 + 1, t % 4 + 1] for t in range(1536)])
+        D, K, V, means, feats = 60, [12], [1536], [4000], [ctx5]
+    X, g, o = _pair(mmm, oracle, D, K, V, seed=21, means=means, imm_features=feats)
+    MK, M = sum(K), len(K)
+    ll_g = mmm.fit(g, maxiter=14, tol=1e-4, verbose=False)
+    ll_o = o.fit(maxiter=14, tol=1e-4)
+    assert len(ll_g) == len(ll_o)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-5)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-5)
+    ge = np.abs(g._get("gamma") - o.gamma) / np.maximum(np.abs(o.gamma), 1e-9)
+    assert np.median(ge) < 1e-3
+    # mass conservation of the term sweep: the γ statistics of a modality add up to its total count
+    if feats is None:
+        goff = g._goff
+        Nm = [sum(int(x[m][:, 1].sum()) for x in X) for m in range(M)]
+        for m in range(M):
+            tot = g._get("gamma")[goff[m]:goff[m + 1]].sum() - 0.1 * K[m] * V[m]
+            assert tot == pytest.approx(Nm[m], rel=1e-10)
+
+
+def test_wide_batch_is_bitwise_the_single_fit(mmm, monkeypatch):
+    D, K, V, R = 70, [5, 4], [40, 24], 3
+    X, _ = np_ref.synth_mm(D, V, K, seed=12, means=[600, 80], empty_frac=0.1)
+    g0 = _inits(K, V, R, 99)
+    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+    batch = _make(mmm, K, V, X, g0, None, restarts=R)
+    hists = mmm.fit_restarts(batch, maxiter=20, tol=2e-3)
+    for r in range(R):
+        single = _make(mmm, K, V, X, g0[r], None)
+        h = mmm.fit(single, maxiter=20, tol=2e-3, verbose=False)
+        assert np.array_equal(h, hists[r])
+        batch.select(r)
+        for f in FIELDS:
+            assert np.array_equal(batch._get(f), single._get(f)), "restart %d field %s" % (r, f)
+        single.close()
+    monkeypatch.delenv("MMM_CTM_WIDE")
