@@ -584,21 +584,35 @@ struct IldaDesc {
 
 // mode 0: lambda = eta + folded sums (update_λ!, ILDA.jl:107-126); 1: from the stored lambda (update_Elnβ!/update_β!,
 // :97-104,128-130); 2: effective tables only, from the stored Elnbeta / beta (after an upload).  One wave per topic.
-__global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const double* sums, double* ilam, double* iEln, double* ibeta,
+__global__ __launch_bounds__(64 * kIldaMaxI) void k_ilda_mstep(IldaDesc ds, int mode, const double* sums, double* ilam, double* iEln, double* ibeta,
                                                    double* Eeff, double* expEeff, double* beff, const int* stop, int write_beta_only,
                                                    ReduceArgs tail, int with_tail)
 {
     __shared__ double sE[kIldaMaxSJ], sB[kIldaMaxSJ];
     if (stop && *stop) return;
-    const int k = blockIdx.x, lane = threadIdx.x, V = ds.V, K = ds.K;
+    // one wave per feature (launch: 64 * I threads): the features' folds and digamma chains run side by side
+    const int k = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwv = blockDim.x >> 6, V = ds.V, K = ds.K;
     if (with_tail && k == K) {           // extra block of the fused pass: ll_{t-1}, stopping rule, pass counter (as k_lda_mstep)
-        lda_tail_block<false>(tail, lane);      // (the ILDA exchange is never folded)
+        if (wid == 0) lda_tail_block<false>(tail, lane);      // (the ILDA exchange is never folded)
         return;
     }
-    for (int i = 0; i < ds.I; ++i) {
+    // V <= 256 (the 96 SNV contexts): the topic's statistics are fetched once, four per lane, and every masked sum below runs
+    // out of registers (same lane assignment and order as the general loop, so the same bits)
+    const bool in_regs = mode == 0 && V <= 256;
+    double sv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int v = lane + 64 * q; if (v < V) sv[q] = sums[(size_t)k * V + v]; }
+    }
+    for (int i = wid; i < ds.I; i += nwv) {
         const int Ji = ds.J[i];
         const size_t base = (size_t)K * ds.joff[i] + (size_t)Ji * k;
         const int* f = ds.features + (size_t)i * V;
+        int fv[4] = {-1, -1, -1, -1};
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int v = lane + 64 * q; if (v < V) fv[q] = f[v]; }
+        }
         double part = 0.0;
         for (int j0 = 0; j0 < Ji; j0 += 64) {
             const int j = j0 + lane;
@@ -608,7 +622,11 @@ __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const 
                 // value (a lane-per-value loop over V global loads is a 60 us dependent chain)
                 for (int jj = j0; jj < min(Ji, j0 + 64); ++jj) {
                     double t = 0.0;
-                    for (int v = lane; v < V; v += 64) t += (f[v] == jj) ? sums[(size_t)k * V + v] : 0.0;
+                    if (in_regs) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) t += (fv[q] == jj) ? sv[q] : 0.0;
+                    } else
+                        for (int v = lane; v < V; v += 64) t += (f[v] == jj) ? sums[(size_t)k * V + v] : 0.0;
                     t = wave_sum(t);
                     if (lane == jj - j0) l = ds.eta[i] + t;
                 }
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(64) void k_ilda_mstep(IldaDesc ds, int mode, const 
         }
     }
     __syncthreads();
-    for (int v = lane; v < V; v += 64) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
         double e = 0.0, b = 1.0;
         for (int i = 0; i < ds.I; ++i) { const int j = ds.features[(size_t)i * V + v]; e += sE[ds.joff[i] + j]; b *= sB[ds.joff[i] + j]; }
         const size_t o = (size_t)k * V + v;
@@ -1320,7 +1338,7 @@ int run_topic_update(mmm_lda* m, bool from_sums)
     const int c = m->cur();
     if (from_sums) { int rc = mmm_allreduce_sum(ctx, m->scratch.p, (size_t)m->V * m->K); if (rc) return rc; }
     if (m->ilda) {
-        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, from_sums ? 0 : 1, m->scratch.p, m->ilam[c].p, m->iEln[c].p,
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64 * m->ids.I), 0, ctx->stream, m->ids, from_sums ? 0 : 1, m->scratch.p, m->ilam[c].p, m->iEln[c].p,
                            m->ibeta[c].p, m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 0, ReduceArgs{}, 0);
         MMM_LAUNCH_CHECK(ctx);
         return MMM_OK;
@@ -1386,7 +1404,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (!r.p2p && (rc = mmm_allreduce_sum(ctx, m->stats[t & 1].p, (size_t)VK + 1))) return rc;
         if (m->ilda) {
             const int c = t % 3;
-            hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+            hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K + 1), dim3(64 * m->ids.I), 0, ctx->stream, m->ids, 0, m->stats[t & 1].p, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                                m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)&m->ctl.p->stop, 0, r, 1);
         } else if (m->wide)
             hipLaunchKernelGGL(k_lda_mstep_wide, dim3(m->K + 1), dim3(512), 0, ctx->stream, r, m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta),
@@ -1592,7 +1610,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
     if (!ilda) hipLaunchKernelGGL(k_lda_topic, dim3(K), dim3(256), 0, st, V, eta, (const double*)nullptr, m->lambda[0].p, m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, 0);
-    else hipLaunchKernelGGL(k_ilda_mstep, dim3(K), dim3(64), 0, st, m->ids, 1, (const double*)nullptr, m->ilam[0].p, m->iEln[0].p, m->ibeta[0].p,
+    else hipLaunchKernelGGL(k_ilda_mstep, dim3(K), dim3(64 * m->ids.I), 0, st, m->ids, 1, (const double*)nullptr, m->ilam[0].p, m->iEln[0].p, m->ibeta[0].p,
                             m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, (const int*)nullptr, 0, ReduceArgs{}, 0);      // ILDA.jl:36-40 (+ tables)
     if (KD) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma[0].p, KD, 1.0);
@@ -1704,7 +1722,7 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     }
     if (field == MMM_ILDA_ELNBETA || field == MMM_ILDA_BETA) {      // effective tables follow the uploaded factors
         const int c = m->cur();
-        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, ctx->stream, m->ids, 2, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64 * m->ids.I), 0, ctx->stream, m->ids, 2, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                            m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, field == MMM_ILDA_BETA ? 1 : 0, ReduceArgs{}, 0);
         MMM_LAUNCH_CHECK(ctx);
     }
@@ -1755,7 +1773,7 @@ int mmm_lda_update_beta(mmm_lda* m)
     if (rc) return rc;
     const int c = m->cur();
     if (m->ilda)
-        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64), 0, m->ctx->stream, m->ids, 1, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
+        hipLaunchKernelGGL(k_ilda_mstep, dim3(m->K), dim3(64 * m->ids.I), 0, m->ctx->stream, m->ids, 1, (const double*)nullptr, m->ilam[c].p, m->iEln[c].p, m->ibeta[c].p,
                            m->Elnbeta[c].p, m->expElnbeta[c].p, m->beta[c].p, (const int*)nullptr, 1, ReduceArgs{}, 0);
     else
     hipLaunchKernelGGL(k_lda_topic, dim3(m->K), dim3(256), 0, m->ctx->stream, m->V, m->eta, (const double*)nullptr, m->lambda[c].p,
