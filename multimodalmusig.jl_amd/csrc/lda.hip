@@ -528,13 +528,13 @@ __global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double e
         if (!stop) for (int v = tid; v < V; v += 128) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
         __syncthreads();
     }
-    if (tid >= 64) return;
+    // both waves form the column sum (same loads, same order: same bits, and no barrier); each then takes every other 64 entries
     double part = 0.0;
     for (int v = lane; v < V; v += 64) part += eta + sums[v];
     if (stop) return;
     const double cs = wave_sum(part);
     const double psi = dev_digamma_pos(cs);
-    for (int v = lane; v < V; v += 64) {
+    for (int v = tid; v < V; v += 128) {
         const double l = eta + sums[v];
         const double el = dev_digamma_pos(l) - psi;
         const size_t e = (size_t)k * V + v;
