@@ -192,7 +192,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
     for (int i = tid; i < KP * V; i += blockDim.x) {
         sB[i] = (i < K * V) ? eB[i] : 0.0;
-        sBeta[i] = (LL && i < K * V) ? bprev[i] : 0.0;
+        if (LL) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
     }
     MMM_STAMP(1);
 
