@@ -189,9 +189,16 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     int64_t start = valid ? a.c.doc_ptr[d] : 0;
     int W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+    // SINGLE: the table stays in registers (<= 4 entries per thread: KP*V <= 960, >= 4 waves) until just before the barrier, so
+    // that the prologue arithmetic below runs while these loads are in flight instead of after them
+    double tb[4] = {0.0, 0.0, 0.0, 0.0};
+    if (SINGLE) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = tid + q * (int)blockDim.x; if (i < K * V) tb[q] = eB[i]; }
+    }
     for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
     for (int i = tid; i < KP * V; i += blockDim.x) {
-        sB[i] = (i < K * V) ? eB[i] : 0.0;
+        if (!SINGLE) sB[i] = (i < K * V) ? eB[i] : 0.0;
         if (LL) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
     }
     MMM_STAMP(1);
@@ -226,6 +233,10 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         }
         if (first) {
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
+            if (SINGLE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int i = tid + q * (int)blockDim.x; if (i < KP * V) sB[i] = tb[q]; }
+            }
             __syncthreads();
             first = false;
             MMM_STAMP(2);
