@@ -54,10 +54,35 @@ struct LdaCtl {
     int stop_iter;   // iteration at which it was met
     int t;           // completed iterations
     int n_hist;      // ll values written
-    int pad[3];
+    int wait_timeout;   // a device-side wait of the merged reduce + M-step launch gave up (sync_ctl reports it)
+    int pad[2];
 };
 
 struct Ring { double* s[3]; };
+
+// 16-byte cells {low half | seq} {high half | seq} in device memory: how blocks of one launch hand each other a double without
+// a fence or a flag (k_lda_reduce_ll_mstep; the mailbox format of p2p.hip)
+__device__ __forceinline__ void cell_store(unsigned long long* c, double v, unsigned int seq)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)seq << 32;
+    __hip_atomic_store(c, (bits & 0xffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 1, (bits >> 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ double cell_wait(const unsigned long long* c, unsigned int seq, LdaCtl* ctl)
+{
+    unsigned long long w0 = 0, w1 = 0;
+    for (int it = 0; it < (1 << 22); ++it) {
+        w0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1 = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)(w0 >> 32) == seq && (unsigned int)(w1 >> 32) == seq)
+            return __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+        __builtin_amdgcn_s_sleep(1);
+    }
+    ctl->wait_timeout = 1;
+    return 0.0;
+}
+
 constexpr int kIldaMaxI = 8, kIldaMaxSJ = 512;
 
 struct EstepArgs {
@@ -366,7 +391,7 @@ __device__ __forceinline__ void lda_tail_block(const ReduceArgs& r, int lane)
 // E-step), 64/L documents per wave step, beta staged in LDS -- the ll half of the E-step's chunk loop, moved out of it.
 template <int KP, int L>
 __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, const double* __restrict__ bprev, double* llpart2, int lb, int nlb,
-                             double* smem)
+                             double* smem, unsigned long long* cell = nullptr, unsigned int seq = 0)
 {
     __shared__ double s_w[16];
     const int tid = threadIdx.y * 16 + threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -467,7 +492,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += s_w[w];
-        llpart2[lb] = v;
+        if (cell) cell_store(cell, v, seq); else llpart2[lb] = v;
     }
 }
 
@@ -517,6 +542,92 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
     if (r.ctl->stop) return;
     constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);       // K <= KP: the E-step's lane-group width (K = 16 -> KP = 16 -> 32 lanes)
     lda_ll_block<KP, L>(c, gprev, bprev, llpart2, (int)blockIdx.x - nred, (int)gridDim.x - nred, smem);
+}
+
+// ---- single GPU, 16 | V <= 256: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
+// reduce blocks of that topic; they hand each other their partial column sums through 16-byte cells in device memory --
+// {low half | seq} {high half | seq}, complete when both words carry this launch's sequence number, so no fence and no
+// flag (the mailbox format of p2p.hip) -- and then run the M-step of their own 16 entries, in parallel, while the ll blocks
+// are still sweeping.  Wave 1 of the first reduce block collects the ll blocks' numerators the same way and runs the pass tail.
+// The reduce blocks have the lowest block ids (dispatched first; putting the ll blocks first was 0.4 us slower) and wait only for
+// each other and for the ll blocks, which wait for nothing; every wait has an iteration cap (ctl->wait_timeout, reported by the
+// next host synchronisation).
+struct MergeArgs {
+    int V; double eta;
+    Ring lambda, Elnbeta, expElnbeta, beta;
+    unsigned long long* cells;      // [nred] column-sum cells, then [512] ll cells
+    unsigned int seq;               // never reused (a discarded pass must not leave valid-looking cells behind)
+    int nred;
+};
+
+template <int KP>
+__global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, MergeArgs ms)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sm[64][17];
+    const int stop = r.ctl->stop;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
+    if ((int)blockIdx.x >= ms.nred) {        // ---- ll block: numerator of pass t-1 into its cell
+        if (stop) return;
+        constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
+        const int lb = (int)blockIdx.x - ms.nred;
+        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, (int)gridDim.x - ms.nred, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        return;
+    }
+    // ---- reduce block: 16 entries of the statistics (as lda_reduce_block)
+    const int rb = (int)blockIdx.x;             // reduce block
+    const int e = rb * 16 + tx;
+    double acc = 0.0;
+    for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
+    if (stop) return;
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty < 8) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += sm[ty * 8 + j][tx];
+        sm[ty * 8][tx] = v;
+    }
+    __syncthreads();
+    if (ty == 0) {                           // lanes 0..15 of wave 0
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
+        r.stats[e] = v;
+        // ---- M-step of these 16 entries (LDA.jl:96-112): column sum = the topic's block sums in block order
+        const int V = ms.V, nb = V / 16, k = e / V, slot = r.t % 3;
+        const double lam = ms.eta + v;
+        const double part = group_sum<16>(lam);
+        if (tx == 0) cell_store(ms.cells + 2 * rb, part, ms.seq);
+        const double got = (tx < nb) ? cell_wait(ms.cells + 2 * (k * nb + tx), ms.seq, r.ctl) : 0.0;
+        double cs = 0.0;
+        for (int j = 0; j < nb; ++j) cs += __shfl(got, j, 16);
+        const double el = dev_digamma_pos(lam) - dev_digamma_pos(cs);
+        ms.lambda.s[slot][e] = lam; ms.Elnbeta.s[slot][e] = el; ms.expElnbeta.s[slot][e] = exp(el); ms.beta.s[slot][e] = lam / cs;
+    }
+    if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
+        const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred;
+        // what the tail needs from memory is fetched before the wait, not after it (lda_pass_tail's dependent loads)
+        const int n = r.ctl->n_hist;
+        const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
+        double v = 0.0;
+        if (r.do_ll) {
+            for (int i = lane; i < n_ll; i += 64) v += cell_wait(ms.cells + 2 * (ms.nred + i), ms.seq, r.ctl);
+            v = wave_sum(v);
+        }
+        if (lane == 0) {
+            int halt = 0;
+            if (r.do_ll) {
+                r.stats[r.VK] = v;
+                const double ll = v / r.Nglobal;
+                r.ll_hist[n] = ll;
+                r.ctl->n_hist = n + 1;
+                if (n + 1 - r.conv_base > 10 && fabs(prev - ll) / fabs(ll) < r.tol) { halt = 1; r.ctl->stop = 1; r.ctl->stop_iter = r.t - 1; }      // common.jl:53-56
+            }
+            if (!halt) r.ctl->t = r.t;
+            r.ctl->ticket = 0;
+        }
+    }
 }
 
 // M-step of pass t from the (all-reduced) statistics, one wave per topic (no inter-block dependency: Elnbeta_k needs
@@ -1142,7 +1253,10 @@ struct mmm_lda {
     bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
-    bool attr_e[2] = {false, false}, attr_m = false;
+    bool attr_e[2] = {false, false}, attr_m = false, attr_mm = false;
+    DevBuf<unsigned long long> cells;   // k_lda_reduce_ll_mstep: [2 * (512 + 512)] exchange cells
+    unsigned int kseq = 0;              // sequence number of its launches
+    bool merge_default = true;
     bool stop_seen = false;     // the device stop flag may be set
     bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
     bool phi_table_beta = false; // phi of the current state is exp(Elntheta) .* beta normalised (unsmoothed_update_ϕ!, LDA.jl:226)
@@ -1284,6 +1398,7 @@ int sync_ctl(mmm_lda* m)
     MMM_HIP(ctx, hipMemcpyAsync(&h, m->ctl.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     { int rc = mmm_p2p_check(ctx); if (rc) return rc; }
+    if (h.wait_timeout) return mmm_fail(ctx, MMM_ERR_HIP, "LDA: a block of the merged reduce + M-step launch gave up waiting for its neighbours");
     const bool stopped = h.stop != 0;
     if (stopped) m->stop_seen = true;
     m->t = h.t; m->n_hist = h.n_hist;
@@ -1399,6 +1514,25 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         if (rc) return rc;
         const int nred = (VK + 15) / 16;
+        // one GPU, 16 | V <= 256, plain LDA: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep); MMM_LDA_MERGE=0/1
+        // avoids / requests it (A/B)
+        static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
+        const bool merged = merge_env != 0 && ll_in_k2 && !r.p2p && !mmm_comm_active(ctx) && !m->ilda && !m->wide && m->V % 16 == 0 && m->V <= 256 &&
+                            (merge_env == 1 || m->merge_default);
+        if (merged) {
+            const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+            MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
+            MMM_KP_SWITCH(m, {
+                auto k = k_lda_reduce_ll_mstep<KPV>;
+                if (!m->attr_mm) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm = true; }
+                hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms);
+            })
+            MMM_LAUNCH_CHECK(ctx);
+            if (do_ll) m->n_hist++;
+            m->t = t;
+            m->ll_pending = true;
+            continue;
+        }
         if (m->wide) {
             MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_stats_terms<KPV>, dim3(m->V + 1), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, m->V, m->K,
                                                   m->term_ptr.p, m->tpost.p, m->aexp.p, m->expElnbeta[(t + 2) % 3].p, r); })
@@ -1564,7 +1698,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
     A(partial, wide ? 1 : (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
-    A(ctl, 1);
+    A(ctl, 1); A(cells, 2 * 1024);
     if (ilda) {
         A(features, (size_t)I * V);
         for (int i = 0; i < 3; ++i) { A(ilam[i], (size_t)SJ * K); A(iEln[i], (size_t)SJ * K); A(ibeta[i], (size_t)SJ * K); }
@@ -1617,6 +1751,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         for (int i = 0; i < 3; ++i) MMM_HIP(ctx, hipMemsetAsync(m->lambda[i].p, 0, sizeof(double) * VK, st));      // unused for ILDA
     }
     MMM_HIP(ctx, hipMemsetAsync(m->ctl.p, 0, sizeof(LdaCtl), st));
+    MMM_HIP(ctx, hipMemsetAsync(m->cells.p, 0, sizeof(unsigned long long) * 2 * 1024, st));
     if (KD) MMM_HIP(ctx, hipMemsetAsync(m->theta.p, 0, sizeof(double) * KD, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
