@@ -544,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
     lda_ll_block<KP, L>(c, gprev, bprev, llpart2, (int)blockIdx.x - nred, (int)gridDim.x - nred, smem);
 }
 
-// ---- single GPU, 16 | V <= 256: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
+// ---- 16 | V <= 256, plain LDA, no RCCL in the path: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
 // reduce blocks of that topic; they hand each other their partial column sums through 16-byte cells in device memory --
 // {low half | seq} {high half | seq}, complete when both words carry this launch's sequence number, so no fence and no
 // flag (the mailbox format of p2p.hip) -- and then run the M-step of their own 16 entries, in parallel, while the ll blocks
@@ -560,7 +560,9 @@ struct MergeArgs {
     int nred;
 };
 
-template <int KP>
+// P2P: several GPUs with the mailboxes up -- a reduce block sends its 16 sums to the peers and adds theirs (rank order) before the
+// column-sum exchange, the tail wave does the same with the ll numerator: the all-reduce rides inside this launch.
+template <int KP, bool P2P>
 __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, MergeArgs ms)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -593,6 +595,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         double v = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
+        if (P2P) { p2p_send(r.px, r.p2p_seq, e, v); v = p2p_recv_sum(r.px, r.p2p_seq, e, v); }
         r.stats[e] = v;
         // ---- M-step of these 16 entries (LDA.jl:96-112): column sum = the topic's block sums in block order
         const int V = ms.V, nb = V / 16, k = e / V, slot = r.t % 3;
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         if (r.do_ll) {
             for (int i = lane; i < n_ll; i += 64) v += cell_wait(ms.cells + 2 * (ms.nred + i), ms.seq, r.ctl);
             v = wave_sum(v);
+            if (P2P && lane == 0) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
         }
         if (lane == 0) {
             int halt = 0;
@@ -1253,7 +1257,7 @@ struct mmm_lda {
     bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
-    bool attr_e[2] = {false, false}, attr_m = false, attr_mm = false;
+    bool attr_e[2] = {false, false}, attr_m = false, attr_mm[2] = {false, false};
     DevBuf<unsigned long long> cells;   // k_lda_reduce_ll_mstep: [2 * (512 + 512)] exchange cells
     unsigned int kseq = 0;              // sequence number of its launches
     bool merge_default = true;
@@ -1514,17 +1518,17 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         if (rc) return rc;
         const int nred = (VK + 15) / 16;
-        // one GPU, 16 | V <= 256, plain LDA: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep); MMM_LDA_MERGE=0/1
+        // 16 | V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep); MMM_LDA_MERGE=0/1
         // avoids / requests it (A/B)
         static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
-        const bool merged = merge_env != 0 && ll_in_k2 && !r.p2p && !mmm_comm_active(ctx) && !m->ilda && !m->wide && m->V % 16 == 0 && m->V <= 256 &&
+        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->ilda && !m->wide && m->V % 16 == 0 && m->V <= 256 &&
                             (merge_env == 1 || m->merge_default);
         if (merged) {
             const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
             MMM_KP_SWITCH(m, {
-                auto k = k_lda_reduce_ll_mstep<KPV>;
-                if (!m->attr_mm) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm = true; }
+                auto k = r.p2p ? k_lda_reduce_ll_mstep<KPV, true> : k_lda_reduce_ll_mstep<KPV, false>;
+                if (!m->attr_mm[r.p2p]) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm[r.p2p] = true; }
                 hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms);
             })
             MMM_LAUNCH_CHECK(ctx);
