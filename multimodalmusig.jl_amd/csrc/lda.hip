@@ -8,7 +8,8 @@
 //   phi        [nnz][K] (= per-doc K x W_d blocks, k fastest); materialised only when asked for
 //   ctl        device control block: ticket, stop flag, iteration counter t, ll-history length
 //
-// One outer iteration t (the body of fit!, LDA.jl:201-209) = THREE launches:
+// One outer iteration t (the body of fit!, LDA.jl:201-209) = TWO launches (k_lda_estep, k_lda_reduce_ll_mstep) for plain LDA with
+// 16 | V <= 256 on one GPU or over the mailboxes, THREE otherwise (k_lda_estep, k_lda_reduce[_ll], k_lda_mstep / k_ilda_mstep):
 //
 // k_lda_estep<KP, L, LL, VT, SINGLE> (dominant): a wave handles 64/L documents at a time, L lanes per document (L = 16 for
 //   K <= 15), lanes over the document's nonzero terms.
@@ -23,6 +24,8 @@
 //     materialised on demand from (Elntheta_t, Elnbeta_{t-1}), which reproduces the stored phi
 //   * LL = true: also the log-likelihood numerator of iteration t-1 (LDA.jl:174-188: needs beta_{t-1}, only known after
 //     M-step t-1; "lagged ll") -- used when the statistics go through ncclAllReduce and by the frozen-topic passes
+// k_lda_reduce_ll_mstep: the two kernels below in one launch -- the reduce blocks of a topic exchange their partial column sums
+//   through seq-tagged cells in device memory and run the M-step of their own entries; see the comment at the kernel.
 // k_lda_reduce_ll / k_lda_reduce: blocks of (16 entries x 64 slab lanes) sum the per-block partials in fixed order
 //   (deterministic); with the mailbox transport they send each statistic to the peer GPUs as it is produced.  The "_ll"
 //   launch carries extra blocks that evaluate the lagged log-likelihood beside the reduction (default on one GPU and
