@@ -9,7 +9,7 @@
 //   ctl        device control block: ticket, stop flag, iteration counter t, ll-history length
 //
 // One outer iteration t (the body of fit!, LDA.jl:201-209) = TWO launches (k_lda_estep, k_lda_reduce_ll_mstep) for plain LDA with
-// 16 | V <= 256 on one GPU or over the mailboxes, THREE otherwise (k_lda_estep, k_lda_reduce[_ll], k_lda_mstep / k_ilda_mstep):
+// V <= 256 on one GPU or over the mailboxes, THREE otherwise (k_lda_estep, k_lda_reduce[_ll], k_lda_mstep / k_ilda_mstep):
 //
 // k_lda_estep<KP, L, LL, VT, SINGLE> (dominant): a wave handles 64/L documents at a time, L lanes per document (L = 16 for
 //   K <= 15), lanes over the document's nonzero terms.
@@ -92,10 +92,11 @@ struct EstepArgs {
     LdaDev c;
     const LdaCtl* ctl;
     Ring gamma, Elntheta, expElnbeta, beta;
-    double* partial;   // [gridDim][K*V]
+    double* partial;   // [gridDim][K*pstride]
     double* llpart;    // [gridDim]
     int do_ll;
     int t;             // this pass (1-based); the host's count, valid unless ctl->stop is set
+    int pstride;       // row stride of a block's partial: V, or V rounded up to 16 for k_lda_reduce_ll_mstep (pad entries stay 0)
 };
 
 #ifdef MMM_DIAG_STAMPS
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     if (LL) ll_acc = wave_sum(ll_acc);
     __syncthreads();
     if (LL && lane == 0) sA[wid] = ll_acc;      // sA is free now
-    double* out = a.partial + (size_t)blockIdx.x * K * V;
+    double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
     for (int i = tid; i < K * V; i += blockDim.x) {
         double v8[kMaxWavesE];
 #pragma unroll
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kMaxWavesE; ++w) s += v8[w];
-        out[i] = s;
+        out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = s;
     }
     if (LL) {
         __syncthreads();
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
     lda_ll_block<KP, L>(c, gprev, bprev, llpart2, (int)blockIdx.x - nred, (int)gridDim.x - nred, smem);
 }
 
-// ---- 16 | V <= 256, plain LDA, no RCCL in the path: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
+// ---- V <= 256, plain LDA, no RCCL in the path: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
 // reduce blocks of that topic; they hand each other their partial column sums through 16-byte cells in device memory --
 // {low half | seq} {high half | seq}, complete when both words carry this launch's sequence number, so no fence and no
 // flag (the mailbox format of p2p.hip) -- and then run the M-step of their own 16 entries, in parallel, while the ll blocks
@@ -600,16 +601,19 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
         if (P2P) { p2p_send(r.px, r.p2p_seq, e, v); v = p2p_recv_sum(r.px, r.p2p_seq, e, v); }
         r.stats[e] = v;
-        // ---- M-step of these 16 entries (LDA.jl:96-112): column sum = the topic's block sums in block order
-        const int V = ms.V, nb = V / 16, k = e / V, slot = r.t % 3;
-        const double lam = ms.eta + v;
+        // ---- M-step of these 16 entries (LDA.jl:96-112): column sum = the topic's block sums in block order.  Rows are padded
+        //      to a multiple of 16 (Vp): a block never straddles two topics; pad entries carry zeros and are not written back
+        const int V = ms.V, Vp = (V + 15) & ~15, nb = Vp / 16, k = e / Vp, vv = e - k * Vp, slot = r.t % 3;
+        const bool real = vv < V;
+        const double lam = real ? ms.eta + v : 0.0;
         const double part = group_sum<16>(lam);
         if (tx == 0) cell_store(ms.cells + 2 * rb, part, ms.seq);
         const double got = (tx < nb) ? cell_wait(ms.cells + 2 * (k * nb + tx), ms.seq, r.ctl) : 0.0;
         double cs = 0.0;
         for (int j = 0; j < nb; ++j) cs += __shfl(got, j, 16);
-        const double el = dev_digamma_pos(lam) - dev_digamma_pos(cs);
-        ms.lambda.s[slot][e] = lam; ms.Elnbeta.s[slot][e] = el; ms.expElnbeta.s[slot][e] = exp(el); ms.beta.s[slot][e] = lam / cs;
+        const double el = dev_digamma_pos(real ? lam : 1.0) - dev_digamma_pos(cs);
+        const size_t o = (size_t)k * V + vv;
+        if (real) { ms.lambda.s[slot][o] = lam; ms.Elnbeta.s[slot][o] = el; ms.expElnbeta.s[slot][o] = exp(el); ms.beta.s[slot][o] = lam / cs; }
     }
     if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
         const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred;
@@ -1263,7 +1267,6 @@ struct mmm_lda {
     bool attr_e[2] = {false, false}, attr_m = false, attr_mm[2] = {false, false};
     DevBuf<unsigned long long> cells;   // k_lda_reduce_ll_mstep: [2 * (512 + 512)] exchange cells
     unsigned int kseq = 0;              // sequence number of its launches
-    bool merge_default = true;
     bool stop_seen = false;     // the device stop flag may be set
     bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
     bool phi_table_beta = false; // phi of the current state is exp(Elntheta) .* beta normalised (unsmoothed_update_ϕ!, LDA.jl:226)
@@ -1506,13 +1509,19 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
         r.p2p = 0; r.p2p_seq = 0;
         static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
-        if (fold && !m->ilda && !m->wide && mmm_p2p_begin(ctx, (size_t)VK + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
+        const int Vp = (m->V + 15) & ~15;
+        if (fold && !m->ilda && !m->wide && mmm_p2p_begin(ctx, (size_t)Vp * m->K + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
         const bool ll_in_k2 = !ll_estep_env && !m->wide && (r.p2p || !mmm_comm_active(ctx));
+        // V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep), statistics
+        // rows padded to a multiple of 16; MMM_LDA_MERGE=0 keeps the split kernels (A/B)
+        static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
+        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->ilda && !m->wide && m->V <= 256;
+        if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
         r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t};
+                    m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
             ProfSpan span(ctx);
@@ -1520,12 +1529,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             for (int q = 0; q < reps && !rc; ++q) rc = launch_estep(m, a);
         }
         if (rc) return rc;
-        const int nred = (VK + 15) / 16;
-        // 16 | V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep); MMM_LDA_MERGE=0/1
-        // avoids / requests it (A/B)
-        static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
-        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->ilda && !m->wide && m->V % 16 == 0 && m->V <= 256 &&
-                            (merge_env == 1 || m->merge_default);
+        const int nred = (r.VK + 15) / 16;
         if (merged) {
             const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
@@ -1598,7 +1602,7 @@ int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_b
         Ring g = m->ring(m->gamma);
         g.s[(t + 2) % 3] = g.s[t % 3];
         EstepArgs a{m->dev(), m->ctl.p, g, m->ring(m->Elntheta), unsmoothed ? m->ring(m->beta) : m->ring(m->expElnbeta), m->ring(m->beta),
-                    m->partial.p, m->llpart.p, 1, t};
+                    m->partial.p, m->llpart.p, 1, t, m->V};
         { ProfSpan span(ctx); rc = launch_estep(m, a); }
         if (rc) return rc;
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, 1, conv_base, 1};
@@ -1704,7 +1708,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
-    A(partial, wide ? 1 : (size_t)m->grid_e * VK); A(stats[0], VK + 16); A(stats[1], VK + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
+    const size_t VKp = (size_t)((V + 15) & ~15) * K;       // rows padded to 16 (k_lda_reduce_ll_mstep)
+    A(partial, wide ? 1 : (size_t)m->grid_e * VKp); A(stats[0], VKp + 16); A(stats[1], VKp + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1); A(cells, 2 * 1024);
     if (ilda) {
         A(features, (size_t)I * V);
@@ -1759,6 +1764,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     }
     MMM_HIP(ctx, hipMemsetAsync(m->ctl.p, 0, sizeof(LdaCtl), st));
     MMM_HIP(ctx, hipMemsetAsync(m->cells.p, 0, sizeof(unsigned long long) * 2 * 1024, st));
+    if (!wide) MMM_HIP(ctx, hipMemsetAsync(m->partial.p, 0, sizeof(double) * (size_t)m->grid_e * VKp, st));      // pad entries are never written
     if (KD) MMM_HIP(ctx, hipMemsetAsync(m->theta.p, 0, sizeof(double) * KD, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
     // constructor state (LDA.jl:36-49): Elnbeta from lambda0; gamma = 1 -> Elntheta; phi = 1/K
