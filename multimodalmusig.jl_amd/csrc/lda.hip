@@ -1333,7 +1333,7 @@ int go_estep3(mmm_lda* m, const EstepArgs& a)
 template <int KPV, int LV, bool LLV, int VT>
 int go_estep2(mmm_lda* m, const EstepArgs& a)
 {
-    if constexpr (VT == 96) { if (m->single_step) return go_estep3<KPV, LV, LLV, VT, true>(m, a); }
+    if constexpr (LV == 16 && KPV <= 10) { if (m->single_step) return go_estep3<KPV, LV, LLV, VT, true>(m, a); }
     return go_estep3<KPV, LV, LLV, VT, false>(m, a);
 }
 
@@ -1675,7 +1675,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const size_t tabB = (size_t)KP * V * sizeof(double);
     // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
     // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
-    const bool small = (V == 96) && (KP == 8 || KP == 10) && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
+    const bool small = (V <= 96) && KP <= 10 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
                        !getenv("MMM_LDA_WAVES");
     // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
     // per SIMD = shorter step); MMM_LDA_SWAVES overrides for experiments
