@@ -218,12 +218,13 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     int64_t start = valid ? a.c.doc_ptr[d] : 0;
     int W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
-    // SINGLE: the table stays in registers (<= 4 entries per thread: KP*V <= 960, >= 4 waves) until just before the barrier, so
+    // SINGLE: the table stays in registers (<= 5 entries per thread: KP*V <= 12 * 96, >= 4 waves) until just before the barrier, so
     // that the prologue arithmetic below runs while these loads are in flight instead of after them
-    double tb[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int TB = KP <= 10 ? 4 : 5;
+    double tb[TB];
     if (SINGLE) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int i = tid + q * (int)blockDim.x; if (i < K * V) tb[q] = eB[i]; }
+        for (int q = 0; q < TB; ++q) { const int i = tid + q * (int)blockDim.x; tb[q] = (i < K * V) ? eB[i] : 0.0; }
     }
     for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
     for (int i = tid; i < KP * V; i += blockDim.x) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
             if (SINGLE) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int i = tid + q * (int)blockDim.x; if (i < KP * V) sB[i] = tb[q]; }
+                for (int q = 0; q < TB; ++q) { const int i = tid + q * (int)blockDim.x; if (i < KP * V) sB[i] = tb[q]; }
             }
             __syncthreads();
             first = false;
@@ -1333,7 +1334,7 @@ int go_estep3(mmm_lda* m, const EstepArgs& a)
 template <int KPV, int LV, bool LLV, int VT>
 int go_estep2(mmm_lda* m, const EstepArgs& a)
 {
-    if constexpr (LV == 16 && KPV <= 10) { if (m->single_step) return go_estep3<KPV, LV, LLV, VT, true>(m, a); }
+    if constexpr (LV == 16 && KPV <= 12) { if (m->single_step) return go_estep3<KPV, LV, LLV, VT, true>(m, a); }
     return go_estep3<KPV, LV, LLV, VT, false>(m, a);
 }
 
@@ -1675,7 +1676,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const size_t tabB = (size_t)KP * V * sizeof(double);
     // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
     // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
-    const bool small = (V <= 96) && KP <= 10 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
+    const bool small = (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
                        !getenv("MMM_LDA_WAVES");
     // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
     // per SIMD = shorter step); MMM_LDA_SWAVES overrides for experiments
