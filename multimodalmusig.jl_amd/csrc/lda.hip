@@ -23,7 +23,7 @@
 //     same pass with DPP row reductions, so phi never round-trips through HBM inside the loop; phi is
 //     materialised on demand from (Elntheta_t, Elnbeta_{t-1}), which reproduces the stored phi
 //   * LL = true: also the log-likelihood numerator of iteration t-1 (LDA.jl:174-188: needs beta_{t-1}, only known after
-//     M-step t-1; "lagged ll") -- used when the statistics go through ncclAllReduce and by the frozen-topic passes
+//     M-step t-1; "lagged ll") -- used by the frozen-topic passes (and MMM_LDA_LL_IN_ESTEP=1)
 // k_lda_reduce_ll_mstep: the two kernels below in one launch -- the reduce blocks of a topic exchange their partial column sums
 //   through seq-tagged cells in device memory and run the M-step of their own entries; see the comment at the kernel.
 // k_lda_reduce_ll / k_lda_reduce: blocks of (16 entries x 64 slab lanes) sum the per-block partials in fixed order
@@ -351,6 +351,9 @@ struct ReduceArgs {
     // the log-likelihood of pass t-1 evaluated by extra blocks of the reduce launch (k_lda_reduce_ll) instead of inside the
     // E-step kernel: per-block numerators in llpart2[n_ll], summed (and exchanged) by the pass-tail block
     const double* llpart2; int n_ll, ll_in_k2;
+    // RCCL transport: the numerator has to sit in stats[VK] before ncclAllReduce, so wave 1 of reduce block 0 collects the ll blocks'
+    // numerators inside the reduce launch, through seq-tagged cells (as k_lda_reduce_ll_mstep does); the tail then only finishes
+    unsigned long long* ll_cells; unsigned int ll_seq;
 };
 
 // ll_{t-1}, the convergence test of common.jl:53-56 after > 10 values (LDA.jl:215) and t += 1 (one thread)
@@ -377,12 +380,13 @@ template <bool P2P>
 __device__ __forceinline__ void lda_tail_block(const ReduceArgs& r, int lane)
 {
     double v = 0.0;
-    if (r.ll_in_k2 && r.do_ll) {
+    const bool from_parts = r.ll_in_k2 && !r.ll_cells;
+    if (from_parts && r.do_ll) {
         for (int i = lane; i < r.n_ll; i += 64) v += r.llpart2[i];
         v = wave_sum(v);
     }
     if (lane != 0) return;
-    if (r.ll_in_k2) {
+    if (from_parts) {
         if (r.do_ll) {
             if (P2P && r.p2p) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
             r.stats[r.VK] = v;
@@ -527,7 +531,14 @@ __device__ void lda_reduce_block(const ReduceArgs& r)
         r.stats[e] = v;
         if (r.p2p) p2p_send(r.px, r.p2p_seq, e, v);
     }
-    if (blockIdx.x == 0 && ty == 1 && !r.ll_in_k2) {       // wave 1 of block 0: ll numerator of pass t-1 (from the E-step's partials)
+    if (blockIdx.x == 0 && ty >= 4 && ty < 8 && r.ll_cells && r.do_ll) {      // wave 1 of block 0: ll numerator of pass t-1 from the ll blocks' cells
+        const int lane = (ty * 16 + tx) & 63;
+        double v = 0.0;
+        for (int i = lane; i < r.n_ll; i += 64) v += cell_wait(r.ll_cells + 2 * i, r.ll_seq, r.ctl);
+        v = wave_sum(v);
+        if (lane == 0) r.stats[r.VK] = v;
+    }
+    if (blockIdx.x == 0 && ty == 1 && !r.ll_in_k2 && !r.ll_cells) {       // wave 1 of block 0: ll numerator of pass t-1 (from the E-step's partials)
         double v = 0.0;
         for (int i = tx + 16 * 0; i < r.nslab; i += 16) v += r.llpart[i];
         v = group_sum<16>(v);
@@ -546,7 +557,8 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
     if ((int)blockIdx.x < nred) { lda_reduce_block(r); return; }
     if (r.ctl->stop) return;
     constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);       // K <= KP: the E-step's lane-group width (K = 16 -> KP = 16 -> 32 lanes)
-    lda_ll_block<KP, L>(c, gprev, bprev, llpart2, (int)blockIdx.x - nred, (int)gridDim.x - nred, smem);
+    const int lb = (int)blockIdx.x - nred;
+    lda_ll_block<KP, L>(c, gprev, bprev, llpart2, lb, (int)gridDim.x - nred, smem, r.ll_cells ? r.ll_cells + 2 * lb : nullptr, r.ll_seq);
 }
 
 // ---- V <= 256, plain LDA, no RCCL in the path: the reduction, the ll sweep AND the M-step in one launch.  A topic's column sum needs the V/16
@@ -1512,13 +1524,15 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
         const int Vp = (m->V + 15) & ~15;
         if (fold && !m->ilda && !m->wide && mmm_p2p_begin(ctx, (size_t)Vp * m->K + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
-        const bool ll_in_k2 = !ll_estep_env && !m->wide && (r.p2p || !mmm_comm_active(ctx));
+        const bool ll_in_k2 = !ll_estep_env && !m->wide;
+        const bool via_cells = ll_in_k2 && !r.p2p && mmm_comm_active(ctx);      // RCCL transport
         // V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep), statistics
         // rows padded to a multiple of 16; MMM_LDA_MERGE=0 keeps the split kernels (A/B)
         static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
         const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->ilda && !m->wide && m->V <= 256;
         if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
+        r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
         r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
