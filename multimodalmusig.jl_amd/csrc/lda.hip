@@ -1516,8 +1516,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
         // Where the ll of pass t-1 is evaluated: in extra blocks of the reduce launch (the reduction occupies 60 CUs for ~6 us,
         // the ll sweep fits beside it and the E-step kernel sheds 43 % of its chunk-loop instructions and half its table
-        // reads), unless the statistics go through ncclAllReduce -- then the numerator has to exist before that call and the
-        // E-step kernel keeps producing it.  MMM_LDA_LL_IN_ESTEP=1 forces the older placement (A/B).
+        // reads).  MMM_LDA_LL_IN_ESTEP=1 forces the older placement (A/B).
         static const bool ll_estep_env = getenv("MMM_LDA_LL_IN_ESTEP") != nullptr;
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
         r.p2p = 0; r.p2p_seq = 0;

@@ -1,6 +1,7 @@
 """The RCCL code path on a single-GPU box: a one-rank communicator with MMM_FORCE_RCCL=1 makes every all-reduce of the
 packed sufficient statistics go through ncclAllReduce on the context stream.  Results must equal the plain path (a one-rank
-sum is the identity): exactly for the CTM path, to the last bits for LDA (whose RCCL path runs a different E-step instantiation).  Runs in a child process because the flag is read once per process."""
+sum is the identity): exactly for the CTM path, to the last bits for LDA (whose single-GPU path merges the M-step into the reduce launch and sums a topic's
+column in a different order).  Runs in a child process because the flag is read once per process."""
 import json
 import os
 import subprocess
@@ -47,10 +48,8 @@ def _run(force, mailboxes=False, wide=False):
 
 def test_one_rank_rccl_path_equals_plain_path():
     a, b = _run(False), _run(True)
-    # LDA: the statistics path is bitwise the same; the log-likelihood numerator is summed in a different order (with RCCL it
-    # has to exist before the ncclAllReduce call, so the E-step kernel produces it; otherwise extra blocks of the reduce launch do)
-    # ... and the two E-step instantiations (with / without the ll in the chunk loop) are scheduled differently by the compiler:
-    # last-bit differences, nothing more
+    # LDA: same statistics, but the merged single-GPU launch adds a topic's column sum block by block while k_lda_mstep adds it lane
+    # by lane: last-bit differences, nothing more
     np.testing.assert_allclose(a["ll"], b["ll"], rtol=1e-13)
     np.testing.assert_allclose([a["elbo"], a["lam"]], [b["elbo"], b["lam"]], rtol=1e-13)
     assert a["llc"] == b["llc"] and a["elboc"] == b["elboc"] and a["mu"] == b["mu"]
