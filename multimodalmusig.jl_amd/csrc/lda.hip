@@ -569,6 +569,21 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll(ReduceArgs r, LdaDev c, 
 // The reduce blocks have the lowest block ids (dispatched first; putting the ll blocks first was 0.4 us slower) and wait only for
 // each other and for the ll blocks, which wait for nothing; every wait has an iteration cap (ctl->wait_timeout, reported by the
 // next host synchronisation).
+struct IldaDesc {
+    int I, V, K, SJ;
+    int J[kIldaMaxI], joff[kIldaMaxI + 1];     // joff = prefix sums of J
+    double eta[kIldaMaxI];
+    const int* features;                       // [i*V + v], 0-based feature values
+};
+
+// ILDA in the merged launch: the factor arrays of the pass's ring slot and the cells the blocks of a topic use to hand each other
+// their partial folds (16 per block: sum(J) <= 16)
+struct IldaMerge {
+    IldaDesc ds;
+    double* ilam; double* iEln; double* ibeta;
+    unsigned long long* fcells;
+};
+
 struct MergeArgs {
     int V; double eta;
     Ring lambda, Elnbeta, expElnbeta, beta;
@@ -579,8 +594,11 @@ struct MergeArgs {
 
 // P2P: several GPUs with the mailboxes up -- a reduce block sends its 16 sums to the peers and adds theirs (rank order) before the
 // column-sum exchange, the tail wave does the same with the ll numerator: the all-reduce rides inside this launch.
-template <int KP, bool P2P>
-__global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, MergeArgs ms)
+// ILDA (sum(J) <= 16, one GPU): the blocks of a topic exchange their partial FOLDS of the statistics onto the feature values
+// (one cell per (feature, value)) instead of one column sum, every block forms the topic's lambda[i][j] from them in block
+// order, and writes the effective tables of its own 16 entries; the topic's first block also writes the factor arrays.
+template <int KP, bool P2P, bool ILDA>
+__global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, MergeArgs ms, IldaMerge im)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sm[64][17];
@@ -618,6 +636,48 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         //      to a multiple of 16 (Vp): a block never straddles two topics; pad entries carry zeros and are not written back
         const int V = ms.V, Vp = (V + 15) & ~15, nb = Vp / 16, k = e / Vp, vv = e - k * Vp, slot = r.t % 3;
         const bool real = vv < V;
+        if (ILDA) {
+            const IldaDesc& ds = im.ds;
+            const int K = ds.K, SJ = ds.SJ;
+            // (feature, value) of lane q = tx; partial fold of this block's 16 entries onto it (ILDA.jl:107-126)
+            int qi = 0, qj = 0;
+            double mine = 0.0;
+            for (int i = 0; i < ds.I; ++i) {
+                const int fi = real ? ds.features[(size_t)i * V + vv] : -1;
+                for (int j = 0; j < ds.J[i]; ++j) {
+                    const double pq = group_sum<16>(fi == j ? v : 0.0);
+                    if (tx == ds.joff[i] + j) { mine = pq; qi = i; qj = j; }
+                }
+            }
+            if (tx < SJ) cell_store(im.fcells + 2 * ((size_t)rb * 16 + tx), mine, ms.seq);
+            double lam = 0.0;
+            if (tx < SJ) {
+                lam = ds.eta[qi];
+                for (int b = 0; b < nb; ++b) lam += cell_wait(im.fcells + 2 * ((size_t)(k * nb + b) * 16 + tx), ms.seq, r.ctl);
+            }
+            double cs = 0.0;
+            for (int i = 0; i < ds.I; ++i) {
+                const double ci = group_sum<16>((tx < SJ && qi == i) ? lam : 0.0);
+                if (tx < SJ && qi == i) cs = ci;
+            }
+            double el = 0.0, bq = 1.0;
+            if (tx < SJ) {
+                el = dev_digamma_pos(lam) - dev_digamma_pos(cs); bq = lam / cs;
+                if (vv == tx) {         // the topic's first block (its lane 0 sits on entry 0 of the row) keeps the model arrays (ILDA.jl:6-9 layout)
+                    const size_t o = (size_t)K * ds.joff[qi] + (size_t)ds.J[qi] * k + qj;
+                    im.ilam[o] = lam; im.iEln[o] = el; im.ibeta[o] = bq;
+                }
+            }
+            lds_wave_sync();
+            sm[1][tx] = el; sm[2][tx] = bq;          // (the reduction tree above is done with sm)
+            lds_wave_sync();
+            if (real) {
+                double ee = 0.0, bb = 1.0;
+                for (int i = 0; i < ds.I; ++i) { const int q = ds.joff[i] + ds.features[(size_t)i * V + vv]; ee += sm[1][q]; bb *= sm[2][q]; }
+                const size_t o = (size_t)k * V + vv;
+                ms.Elnbeta.s[slot][o] = ee; ms.expElnbeta.s[slot][o] = exp(ee); ms.beta.s[slot][o] = bb;
+            }
+        } else {
         const double lam = real ? ms.eta + v : 0.0;
         const double part = group_sum<16>(lam);
         if (tx == 0) cell_store(ms.cells + 2 * rb, part, ms.seq);
@@ -627,6 +687,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         const double el = dev_digamma_pos(real ? lam : 1.0) - dev_digamma_pos(cs);
         const size_t o = (size_t)k * V + vv;
         if (real) { ms.lambda.s[slot][o] = lam; ms.Elnbeta.s[slot][o] = el; ms.expElnbeta.s[slot][o] = exp(el); ms.beta.s[slot][o] = lam / cs; }
+        }
     }
     if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
         const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred;
@@ -721,12 +782,6 @@ __global__ __launch_bounds__(512) void k_lda_mstep_wide(ReduceArgs r, int V, dou
 // beta[i][f_vi, k].  The E-step, ll and ELBO document kernels run unchanged on EFFECTIVE V x K tables (Elnbeta_eff[v,k] =
 // sum_i Elnbeta[i][f_vi, k], exp of it, beta_eff = prod_i beta[i][f_vi, k]); only the topic M-step differs: the V x K
 // statistics are folded onto the feature values.  Model layout: lambda[i] is J_i x K column-major at K * sum_{q<i} J_q.
-struct IldaDesc {
-    int I, V, K, SJ;
-    int J[kIldaMaxI], joff[kIldaMaxI + 1];     // joff = prefix sums of J
-    double eta[kIldaMaxI];
-    const int* features;                       // [i*V + v], 0-based feature values
-};
 
 // mode 0: lambda = eta + folded sums (update_λ!, ILDA.jl:107-126); 1: from the stored lambda (update_Elnβ!/update_β!,
 // :97-104,128-130); 2: effective tables only, from the stored Elnbeta / beta (after an upload).  One wave per topic.
@@ -1277,8 +1332,9 @@ struct mmm_lda {
     bool gnext_valid = false;   // gamma[(t+1)%3] holds gamma_{t+1}
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
-    bool attr_e[2] = {false, false}, attr_m = false, attr_mm[2] = {false, false};
+    bool attr_e[2] = {false, false}, attr_m = false, attr_mm[3] = {false, false, false};
     DevBuf<unsigned long long> cells;   // k_lda_reduce_ll_mstep: [2 * (512 + 512)] exchange cells
+    DevBuf<unsigned long long> fcells;  // ILDA: [2 * 512 * 16] fold cells
     unsigned int kseq = 0;              // sequence number of its launches
     bool stop_seen = false;     // the device stop flag may be set
     bool lag_ll = true;         // the passes in flight evaluate the ll one pass late (training); false: frozen-topic passes
@@ -1528,7 +1584,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         // V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep), statistics
         // rows padded to a multiple of 16; MMM_LDA_MERGE=0 keeps the split kernels (A/B)
         static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
-        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->ilda && !m->wide && m->V <= 256;
+        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
+                            (!m->ilda || (m->ids.SJ <= 16 && !mmm_comm_active(ctx)));
         if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
@@ -1547,10 +1604,14 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (merged) {
             const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
+            const int c3 = t % 3;
+            IldaMerge im{};
+            if (m->ilda) im = IldaMerge{m->ids, m->ilam[c3].p, m->iEln[c3].p, m->ibeta[c3].p, m->fcells.p};
             MMM_KP_SWITCH(m, {
-                auto k = r.p2p ? k_lda_reduce_ll_mstep<KPV, true> : k_lda_reduce_ll_mstep<KPV, false>;
-                if (!m->attr_mm[r.p2p]) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm[r.p2p] = true; }
-                hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms);
+                auto k = m->ilda ? k_lda_reduce_ll_mstep<KPV, false, true> : (r.p2p ? k_lda_reduce_ll_mstep<KPV, true, false> : k_lda_reduce_ll_mstep<KPV, false, false>);
+                const int ai = m->ilda ? 2 : r.p2p;
+                if (!m->attr_mm[ai]) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm[ai] = true; }
+                hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms, im);
             })
             MMM_LAUNCH_CHECK(ctx);
             if (do_ll) m->n_hist++;
@@ -1726,6 +1787,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     A(partial, wide ? 1 : (size_t)m->grid_e * VKp); A(stats[0], VKp + 16); A(stats[1], VKp + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1); A(cells, 2 * 1024);
     if (ilda) {
+        A(fcells, (size_t)2 * 512 * 16);
         A(features, (size_t)I * V);
         for (int i = 0; i < 3; ++i) { A(ilam[i], (size_t)SJ * K); A(iEln[i], (size_t)SJ * K); A(ibeta[i], (size_t)SJ * K); }
     }
@@ -1778,6 +1840,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     }
     MMM_HIP(ctx, hipMemsetAsync(m->ctl.p, 0, sizeof(LdaCtl), st));
     MMM_HIP(ctx, hipMemsetAsync(m->cells.p, 0, sizeof(unsigned long long) * 2 * 1024, st));
+    if (ilda) MMM_HIP(ctx, hipMemsetAsync(m->fcells.p, 0, sizeof(unsigned long long) * 2 * 512 * 16, st));
     if (!wide) MMM_HIP(ctx, hipMemsetAsync(m->partial.p, 0, sizeof(double) * (size_t)m->grid_e * VKp, st));      // pad entries are never written
     if (KD) MMM_HIP(ctx, hipMemsetAsync(m->theta.p, 0, sizeof(double) * KD, st));
     MMM_HIP(ctx, hipStreamSynchronize(st));   // tc (host vector) must outlive the copy
