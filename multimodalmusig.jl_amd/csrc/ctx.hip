@@ -45,6 +45,8 @@ int mmm_ctx_destroy(mmm_ctx* ctx)
     if (!ctx) return MMM_OK;
     (void)hipSetDevice(ctx->device);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->pin_ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     mmm_p2p_release(ctx);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);

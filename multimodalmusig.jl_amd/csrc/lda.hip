@@ -2115,15 +2115,32 @@ int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_ite
     const int base = m->n_hist, t0 = m->t;
     // The stopping rule (LDA.jl:215 + common.jl:53-56) is evaluated on the device in the M-step tail of pass i+1 for
     // pass i (lagged ll); later launches are no-ops once it fires.  The host only looks at the flag between chunks.
-    int done = 0;
-    bool stopped = false;
-    while (done < maxiter && !stopped) {
-        const int chunk = std::min(maxiter - done, done == 0 ? 12 : 8);
-        if ((rc = fused_passes(m, chunk, tol, base))) return rc;
-        if ((rc = sync_ctl(m))) return rc;
-        stopped = (m->t - t0) < done + chunk;       // the device discarded passes after the criterion fired
-        done = m->t - t0;
+    // Chunks are pipelined: the control block is snapshotted in-stream (pinned memory + event) after every chunk, and the host
+    // examines chunk i's snapshot only after chunk i+1 has been enqueued -- no bubble on the GPU between chunks; the cost is at most
+    // one chunk of no-op launches after the criterion has fired.
+    static_assert(sizeof(LdaCtl) <= 64, "control block larger than a pinned slot");
+    if (!ctx->pin_ctl) {
+        MMM_HIP(ctx, hipHostMalloc(&ctx->pin_ctl, 128, hipHostMallocDefault));
+        for (int i = 0; i < 2; ++i) MMM_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
     }
+    int enq = 0, slot = 0;
+    bool have_prev = false;
+    while (enq < maxiter) {
+        const int chunk = std::min(maxiter - enq, enq == 0 ? 12 : 8);
+        if ((rc = fused_passes(m, chunk, tol, base))) return rc;
+        enq += chunk;
+        LdaCtl* snap = (LdaCtl*)((char*)ctx->pin_ctl + 64 * slot);
+        MMM_HIP(ctx, hipMemcpyAsync(snap, m->ctl.p, sizeof(LdaCtl), hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+        if (have_prev) {
+            MMM_HIP(ctx, hipEventSynchronize(ctx->pin_ev[slot ^ 1]));
+            const LdaCtl* prev = (const LdaCtl*)((const char*)ctx->pin_ctl + 64 * (slot ^ 1));
+            if (prev->stop || prev->wait_timeout) break;
+        }
+        have_prev = true; slot ^= 1;
+    }
+    if ((rc = sync_ctl(m))) return rc;
+    const bool stopped = (m->t - t0) < enq;       // the device discarded passes after the criterion fired
     if (stopped) *converged = 1;
     else {
         // maxiter passes ran; the ll of the last one is still pending and its convergence test is done here

@@ -32,6 +32,10 @@ struct mmm_ctx {
     int prof_repeat = 1;          // launches of the dominant kernel inside each profiled span (differential timing)
     std::vector<hipEvent_t> ev;   // pairs: ev[2i] start, ev[2i+1] stop
     size_t ev_used = 0;
+    // pipelined fits: two pinned 64-byte slots + events for in-stream snapshots of a model's control block, so that the host
+    // can look at chunk i's stop flag while chunk i+1 is already running (lazily created)
+    void* pin_ctl = nullptr;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
 
 // RAII span: records an event pair around a launch while profiling is on
