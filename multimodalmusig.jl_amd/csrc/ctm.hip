@@ -948,22 +948,46 @@ __global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, i
 }
 
 // k_sum_columns + k_ll_store in one launch (single GPU: no exchange between them)
-__global__ __launch_bounds__(64) void k_ll_finish(const double* part, int n, int M, const double* Nm, double* num, size_t num_stride, double* dst,
-                                                  size_t dst_stride, const int* active)
+// The stopping rule of fit! on the device (MMCTM.jl:481-489 + common.jl:48-51: after > 10 rows, stop when the largest relative change
+// of the per-modality ll is < tol; a NaN propagates like Julia's `maximum` and never stops): the replica's `active` flag is
+// cleared, every later launch of the fit skips the replica, and the host -- which reads the flags one pass late, so that it never
+// stalls the stream -- stops enqueueing when none is left.  npass counts the rows a replica has written.
+struct StopArgs { int enable; double tol; int* active_w; int* npass; };
+
+__device__ __forceinline__ void ll_stop_rule(const StopArgs& st, int rep, int M, const double* row)
 {
-    const int j = blockIdx.x;
+    if (st.npass) st.npass[rep] += 1;
+    if (!st.enable || !st.active_w) return;
+    double rel = 0.0;
+    for (int q = 0; q < M; ++q) {
+        const double a = row[q - M], b = row[q];          // previous row, this row
+        const double rr = fabs(a - b) / fabs(b);
+        if (rr > rel || rr != rr) rel = rr;
+    }
+    if (rel < st.tol) st.active_w[rep] = 0;
+}
+
+// grid (1, replicas), one wave per modality: column sums of the ll partials, division by N_m, history row, stopping rule
+__global__ __launch_bounds__(64 * kMaxM) void k_ll_finish(const double* part, int n, int M, const double* Nm, double* num, size_t num_stride, double* dst,
+                                                          size_t dst_stride, const int* active, StopArgs st)
+{
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (active && !active[blockIdx.y]) return;
     part += (size_t)blockIdx.y * n * M;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 64) acc += part[(size_t)i * M + j];
+    for (int i = lane; i < n; i += 64) acc += part[(size_t)i * M + j];
     acc = wave_sum(acc);
-    if (threadIdx.x == 0) { num[blockIdx.y * num_stride + j] = acc; dst[blockIdx.y * dst_stride + j] = acc / Nm[j]; }
+    if (lane == 0) { num[blockIdx.y * num_stride + j] = acc; dst[blockIdx.y * dst_stride + j] = acc / Nm[j]; }
+    __syncthreads();
+    if (threadIdx.x == 0) ll_stop_rule(st, blockIdx.y, M, dst + blockIdx.y * dst_stride);
 }
 
-__global__ void k_ll_store(int M, const double* num, size_t num_stride, const double* Nm, double* dst, size_t dst_stride, const int* active)
+__global__ void k_ll_store(int M, const double* num, size_t num_stride, const double* Nm, double* dst, size_t dst_stride, const int* active, StopArgs st)
 {
     if (active && !active[blockIdx.y]) return;
     if ((int)threadIdx.x < M) dst[blockIdx.y * dst_stride + threadIdx.x] = num[blockIdx.y * num_stride + threadIdx.x] / Nm[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) ll_stop_rule(st, blockIdx.y, M, dst + blockIdx.y * dst_stride);
 }
 
 // per-document ELBO pieces (MMCTM.jl:286-370): out[block][6] = {ElnPeta(without logdet/const), ElnPZ, ElnPX, ElnQeta, ElnQZ, count}
@@ -1120,7 +1144,9 @@ struct mmm_ctm {
     DevBuf<double> theta;                                                        // ONE replica (the selected one), on demand
     DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff, expEeff_prev, phieff;   // [R][...]
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
-    DevBuf<int> nev_nu, nev_lam, status, active;
+    DevBuf<int> nev_nu, nev_lam, status, active, npass;
+    int stop_enable = 0; double stop_tol = 0.0;     // set by fit_scope around a pass: the ll kernels apply the stopping rule
+    int* pin_flags = nullptr;                       // pinned [2][2R]: snapshots of (active | status) the host reads one pass late
     std::vector<int> h_active, n_hist;        // per replica
     // theta (the largest array) exists once, not per replica.  Per replica we know how to rebuild it:
     // 0 = constructor value 1/K, 1 = update_θ! on (lambda_prev, expEeff_prev) -- the theta the last pass used --,
@@ -1323,9 +1349,11 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
                        mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
     MMM_LAUNCH_CHECK(ctx);
     if (!compute_ll) return MMM_OK;
+    // inside a fit (fit_scope sets stop_enable / sc.active): the stopping rule and the pass counter ride on the row's last kernel
+    const StopArgs st{(m->stop_enable && sc.active) ? 1 : 0, m->stop_tol, sc.active ? m->active.p + r0 : nullptr, sc.active ? m->npass.p + r0 : nullptr};
     if (!mmm_comm_active(ctx)) {        // nothing to exchange: column sums and the division by N_m in one launch
-        hipLaunchKernelGGL(k_ll_finish, dim3(M, sc.nrep), dim3(64), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->Nm.p,
-                           m->llnum.p + r0 * m->s_llnum, m->s_llnum, dst_dev, dst_stride, sc.active);
+        hipLaunchKernelGGL(k_ll_finish, dim3(1, sc.nrep), dim3(64 * M), 0, ctx->stream, m->llpart.p + r0 * m->grid_s * M, m->grid_s, M, m->Nm.p,
+                           m->llnum.p + r0 * m->s_llnum, m->s_llnum, dst_dev, dst_stride, sc.active, st);
         MMM_LAUNCH_CHECK(ctx);
         return MMM_OK;
     }
@@ -1334,7 +1362,7 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     MMM_LAUNCH_CHECK(ctx);
     int rc = mmm_allreduce_sum(ctx, m->llnum.p + r0 * m->s_llnum, (size_t)sc.nrep * m->s_llnum);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ll_store, dim3(1, sc.nrep), dim3(64), 0, ctx->stream, M, m->llnum.p + r0 * m->s_llnum, m->s_llnum, m->Nm.p, dst_dev, dst_stride, sc.active);
+    hipLaunchKernelGGL(k_ll_store, dim3(1, sc.nrep), dim3(64), 0, ctx->stream, M, m->llnum.p + r0 * m->s_llnum, m->s_llnum, m->Nm.p, dst_dev, dst_stride, sc.active, st);
     MMM_LAUNCH_CHECK(ctx);
     return MMM_OK;
 }
@@ -1608,7 +1636,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
     A(partial, m->wide ? 1 : Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
     A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
-    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz);
+    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz);
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * M * (D + 1), hipMemcpyHostToDevice, st));
@@ -1723,6 +1751,7 @@ int mmm_ctm_destroy(mmm_ctm* m)
     if (!m) return MMM_OK;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->pin_flags) (void)hipHostFree(m->pin_flags);
     delete m;
     return MMM_OK;
 }
@@ -2041,51 +2070,65 @@ static int fit_scope(mmm_ctm* m, Scope sc, int maxiter, double tol, int update_s
                      int infer_flags = -1)
 {
     mmm_ctx* ctx = m->ctx;
-    const int M = m->dm.M, nrep = sc.nrep;
+    const int M = m->dm.M, nrep = sc.nrep, rep0 = sc.rep0;
     int rc;
     std::vector<int> base(nrep), done(nrep, 0);
-    for (int i = 0; i < nrep; ++i) { base[i] = m->n_hist[sc.rep0 + i]; converged[i] = 0; }
-    const bool batch = sc.active != nullptr;
-    if (batch) {
-        for (int i = 1; i < nrep; ++i) MMM_CHECK(ctx, base[i] == base[0], "mmm_ctm_fit_batch: replicas have different histories (%d vs %d passes)", base[i], base[0]);
-        std::fill(m->h_active.begin(), m->h_active.end(), 1);
-        if ((rc = upload_active(m))) return rc;
-    }
-    std::vector<double> ll((size_t)nrep * maxiter * M);
-    int pass = 0, nactive = nrep;
-    while (pass < maxiter && nactive > 0) {
-        // the stopping rule needs > 10 values: the first 11 passes run without a host check
-        const int chunk = (pass == 0) ? std::min(maxiter, 11) : 1;
-        for (int i = 0; i < chunk; ++i)
-            if ((rc = infer_flags < 0 ? fused_pass(m, sc, update_sigma) : frozen_pass(m, sc, infer_flags))) return rc;
-        // the new rows of every replica of the scope in ONE strided copy (base is common to the scope; rows of replicas that
-        // have already stopped are stale and never read: done[i] bounds what is returned)
-        MMM_HIP(ctx, hipMemcpy2DAsync(ll.data() + (size_t)pass * M, sizeof(double) * maxiter * M,
-                                      m->ll_hist.p + ((size_t)sc.rep0 * m->cap_hist + base[0] + pass) * M, sizeof(double) * m->cap_hist * M,
-                                      sizeof(double) * chunk * M, (size_t)nrep, hipMemcpyDeviceToHost, ctx->stream));
-        if ((rc = check_status(m, sc))) return rc;
-        pass += chunk;
-        bool changed = false;
-        for (int i = 0; i < nrep; ++i) {
-            const int r = sc.rep0 + i;
-            if (batch && !m->h_active[r]) continue;
-            done[i] = pass;
-            if (pass > 10) {          // common.jl:48-51
-                double rel = 0.0;
-                for (int q = 0; q < M; ++q) {
-                    const double a = ll[((size_t)i * maxiter + pass - 2) * M + q], b = ll[((size_t)i * maxiter + pass - 1) * M + q];
-                    const double rr = fabs(a - b) / fabs(b);
-                    if (rr > rel || rr != rr) rel = rr;       // NaN propagates like Julia's maximum
-                }
-                if (rel < tol) { converged[i] = 1; if (batch) { m->h_active[r] = 0; changed = true; } --nactive; }
-            }
+    for (int i = 0; i < nrep; ++i) { base[i] = m->n_hist[rep0 + i]; converged[i] = 0; }
+    for (int i = 1; i < nrep; ++i) MMM_CHECK(ctx, base[i] == base[0], "mmm_ctm_fit_batch: replicas have different histories (%d vs %d passes)", base[i], base[0]);
+    // The stopping rule runs on the device (k_ll_finish / k_ll_store clear a replica's `active` flag; every launch of the scope skips
+    // inactive replicas), so the host never has to wait for a pass before enqueueing the next: it reads the flags -- and the status
+    // words of update_Σ! -- from in-stream snapshots taken every few passes and examined one snapshot late, and stops enqueueing
+    // when no replica is left.  Cost: a few passes of no-op launches after the last replica has stopped.
+    for (int i = 0; i < nrep; ++i) m->h_active[rep0 + i] = 1;
+    if ((rc = upload_active(m))) return rc;
+    sc.active = m->active.p + rep0;
+    MMM_HIP(ctx, hipMemsetAsync(m->npass.p + rep0, 0, sizeof(int) * nrep, ctx->stream));
+    if (!m->pin_flags) MMM_HIP(ctx, hipHostMalloc((void**)&m->pin_flags, sizeof(int) * 4 * (size_t)m->R, hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) if (!ctx->pin_ev[i]) MMM_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    constexpr int kSnapEvery = 4;       // => at most 2 * kSnapEvery no-op passes after the last replica has stopped
+    int pass = 0, slot = 0;
+    bool have_prev = false;
+    m->stop_tol = tol;
+    while (pass < maxiter) {
+        m->stop_enable = (pass + 1 > 10) ? 1 : 0;          // the rule needs > 10 rows (MMCTM.jl:481)
+        rc = infer_flags < 0 ? fused_pass(m, sc, update_sigma) : frozen_pass(m, sc, infer_flags);
+        m->stop_enable = 0;
+        if (rc) return rc;
+        ++pass;
+        if (pass <= 10 || (pass < maxiter && (pass - 11) % kSnapEvery != 0)) continue;      // a snapshot costs the host two copies and an event
+        int* snap = m->pin_flags + (size_t)slot * 2 * m->R;
+        MMM_HIP(ctx, hipMemcpyAsync(snap, m->active.p + rep0, sizeof(int) * nrep, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(snap + m->R, m->status.p + rep0, sizeof(int) * nrep, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+        if (have_prev) {
+            MMM_HIP(ctx, hipEventSynchronize(ctx->pin_ev[slot ^ 1]));
+            const int* prev = m->pin_flags + (size_t)(slot ^ 1) * 2 * m->R;
+            int nactive = 0, bad = 0;
+            for (int i = 0; i < nrep; ++i) { nactive += prev[i] != 0; bad |= prev[m->R + i]; }
+            if (nactive == 0 || bad) break;
         }
-        if (!batch && converged[0]) break;
-        if (changed && (rc = upload_active(m))) return rc;
+        have_prev = true; slot ^= 1;
     }
+    // settle: status (singular Σ), pass counts, final flags
+    if ((rc = check_status(m, Scope{rep0, nrep, nullptr}))) return rc;
+    std::vector<int> hn(nrep), ha(nrep);
+    MMM_HIP(ctx, hipMemcpyAsync(hn.data(), m->npass.p + rep0, sizeof(int) * nrep, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipMemcpyAsync(ha.data(), m->active.p + rep0, sizeof(int) * nrep, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int maxdone = 0;
     for (int i = 0; i < nrep; ++i) {
+        done[i] = hn[i]; converged[i] = ha[i] ? 0 : 1;
+        m->h_active[rep0 + i] = ha[i];
+        m->n_hist[rep0 + i] = base[i] + done[i];           // the host counted the no-op passes of replicas that had stopped
+        maxdone = std::max(maxdone, done[i]);
         n_iter[i] = done[i];
-        if (ll_hist) memcpy(ll_hist + (size_t)i * maxiter * M, ll.data() + (size_t)i * maxiter * M, sizeof(double) * done[i] * M);
+    }
+    if (ll_hist && maxdone > 0) {
+        std::vector<double> ll((size_t)nrep * maxdone * M);
+        MMM_HIP(ctx, hipMemcpy2DAsync(ll.data(), sizeof(double) * maxdone * M, m->ll_hist.p + ((size_t)rep0 * m->cap_hist + base[0]) * M,
+                                      sizeof(double) * m->cap_hist * M, sizeof(double) * maxdone * M, (size_t)nrep, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < nrep; ++i) memcpy(ll_hist + (size_t)i * maxiter * M, ll.data() + (size_t)i * maxdone * M, sizeof(double) * done[i] * M);
     }
     return MMM_OK;
 }
