@@ -1707,6 +1707,36 @@ int prepare_call(mmm_lda* m)
 
 } // namespace
 
+// Chunks of passes, pipelined: the control block is snapshotted in-stream (pinned memory + event) after every chunk, and the host
+// examines chunk i's snapshot only after chunk i+1 has been enqueued -- no bubble on the GPU between chunks; the cost is at most
+// one chunk of no-op launches after the device-side criterion has fired.  *enq = passes enqueued.
+template <class Enqueue>
+static int run_chunks_pipelined(mmm_lda* m, int maxiter, int* enq_out, Enqueue enqueue)
+{
+    mmm_ctx* ctx = m->ctx;
+    static_assert(sizeof(LdaCtl) <= 64, "control block larger than a pinned slot");
+    if (!ctx->pin_ctl) MMM_HIP(ctx, hipHostMalloc(&ctx->pin_ctl, 128, hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) if (!ctx->pin_ev[i]) MMM_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
+    int enq = 0, slot = 0, rc;
+    bool have_prev = false;
+    while (enq < maxiter) {
+        const int chunk = std::min(maxiter - enq, enq == 0 ? 12 : 8);
+        if ((rc = enqueue(chunk))) return rc;
+        enq += chunk;
+        LdaCtl* snap = (LdaCtl*)((char*)ctx->pin_ctl + 64 * slot);
+        MMM_HIP(ctx, hipMemcpyAsync(snap, m->ctl.p, sizeof(LdaCtl), hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+        if (have_prev) {
+            MMM_HIP(ctx, hipEventSynchronize(ctx->pin_ev[slot ^ 1]));
+            const LdaCtl* prev = (const LdaCtl*)((const char*)ctx->pin_ctl + 64 * (slot ^ 1));
+            if (prev->stop || prev->wait_timeout) break;
+        }
+        have_prev = true; slot ^= 1;
+    }
+    *enq_out = enq;
+    return MMM_OK;
+}
+
 #ifdef MMM_DIAG_STAMPS
 extern "C" int mmm_diag_lda_stamps(unsigned long long out[16])
 {
@@ -2115,30 +2145,8 @@ int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_ite
     const int base = m->n_hist, t0 = m->t;
     // The stopping rule (LDA.jl:215 + common.jl:53-56) is evaluated on the device in the M-step tail of pass i+1 for
     // pass i (lagged ll); later launches are no-ops once it fires.  The host only looks at the flag between chunks.
-    // Chunks are pipelined: the control block is snapshotted in-stream (pinned memory + event) after every chunk, and the host
-    // examines chunk i's snapshot only after chunk i+1 has been enqueued -- no bubble on the GPU between chunks; the cost is at most
-    // one chunk of no-op launches after the criterion has fired.
-    static_assert(sizeof(LdaCtl) <= 64, "control block larger than a pinned slot");
-    if (!ctx->pin_ctl) {
-        MMM_HIP(ctx, hipHostMalloc(&ctx->pin_ctl, 128, hipHostMallocDefault));
-        for (int i = 0; i < 2; ++i) MMM_HIP(ctx, hipEventCreateWithFlags(&ctx->pin_ev[i], hipEventDisableTiming));
-    }
-    int enq = 0, slot = 0;
-    bool have_prev = false;
-    while (enq < maxiter) {
-        const int chunk = std::min(maxiter - enq, enq == 0 ? 12 : 8);
-        if ((rc = fused_passes(m, chunk, tol, base))) return rc;
-        enq += chunk;
-        LdaCtl* snap = (LdaCtl*)((char*)ctx->pin_ctl + 64 * slot);
-        MMM_HIP(ctx, hipMemcpyAsync(snap, m->ctl.p, sizeof(LdaCtl), hipMemcpyDeviceToHost, ctx->stream));
-        MMM_HIP(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
-        if (have_prev) {
-            MMM_HIP(ctx, hipEventSynchronize(ctx->pin_ev[slot ^ 1]));
-            const LdaCtl* prev = (const LdaCtl*)((const char*)ctx->pin_ctl + 64 * (slot ^ 1));
-            if (prev->stop || prev->wait_timeout) break;
-        }
-        have_prev = true; slot ^= 1;
-    }
+    int enq = 0;
+    if ((rc = run_chunks_pipelined(m, maxiter, &enq, [&](int chunk) { return fused_passes(m, chunk, tol, base); }))) return rc;
     if ((rc = sync_ctl(m))) return rc;
     const bool stopped = (m->t - t0) < enq;       // the device discarded passes after the criterion fired
     if (stopped) *converged = 1;
@@ -2186,16 +2194,10 @@ int mmm_lda_infer(mmm_lda* m, int unsmoothed, int maxiter, double tol, double* l
     }
     *converged = 0;
     const int base = m->n_hist;
-    int done = 0;
-    bool stopped = false;
-    while (done < maxiter && !stopped) {
-        const int chunk = std::min(maxiter - done, done == 0 ? 12 : 8);
-        if ((rc = frozen_passes(m, chunk, unsmoothed, tol, base))) return rc;
-        if ((rc = sync_ctl(m))) return rc;
-        stopped = m->stop_seen;
-        done = m->n_hist - base;
-    }
-    if (stopped) *converged = 1;
+    int enq = 0;
+    if ((rc = run_chunks_pipelined(m, maxiter, &enq, [&](int chunk) { return frozen_passes(m, chunk, unsmoothed, tol, base); }))) return rc;
+    if ((rc = sync_ctl(m))) return rc;
+    if (m->stop_seen) *converged = 1;
     const int n = m->n_hist - base;
     *n_iter = n;
     if (ll_hist && n > 0) MMM_HIP(ctx, hipMemcpyAsync(ll_hist, m->ll_hist.p + base, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
