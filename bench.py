@@ -4,8 +4,9 @@
 A "step" = one outer EM iteration (the body of fit!, LDA.jl:201-209: E-step over every document, M-step
 reduction, log-likelihood) over one batch of synthetic documents resident in HBM.
 N = 1: BASELINE configs[1] -- LDA K=10, alpha=eta=0.1, D=10,000 documents x 96 SNV terms (SURVEY §8d generator).
-N > 1: weak scaling -- every rank holds its own 10,000-document shard (global corpus 10,000 x N), one RCCL
-all-reduce of the packed lambda statistics (+ one of the ll numerator) per iteration.
+N > 1: weak scaling -- every rank holds its own 10,000-document shard (global corpus 10,000 x N), one all-reduce of the packed
+lambda statistics and the ll numerator per iteration (xGMI mailboxes inside the reduce + M-step launch, ncclAllReduce as fallback;
+the line reports which in config.allreduce).
 
 Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both
 sides; MAX over ranks; rank 0 prints ONE JSON line.
@@ -15,6 +16,10 @@ import json
 import os
 import sys
 import time
+
+# dmabuf IPC (the only kind the host driver supports): RCCL and the xGMI mailboxes both map peer memory through it.  Already
+# exported on the GPU boxes; set here as well so that a launcher with a scrubbed environment still works.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
