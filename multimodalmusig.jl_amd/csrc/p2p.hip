@@ -5,9 +5,10 @@
 // fine-grained (uncached, peer-visible) device memory, [2 slots][nranks][cap] cells of 16 bytes; one kernel per call
 //   1. stores its own contribution into every peer's mailbox, directly over xGMI, and
 //   2. polls its own mailbox for the peers' contributions and sums them in RANK ORDER (same bits on every rank, deterministic).
-// A cell carries one double as two 8-byte words {low half | seq} {high half | seq}: 8-byte stores are atomic, so a cell is
+// A cell carries one double as two 8-byte words {low half | seq} {high half | seq}: each word is written whole, so a cell is
 // complete exactly when both words show the sequence number of this call -- no fence, no flag, no ordering requirement
-// between stores (the "LL" idea of collective libraries).  seq is a per-context call counter (identical on all ranks, which
+// (the "LL" idea of collective libraries).  A sender writes a cell with ONE 16-byte write-through store (half the xGMI write
+// transactions of two 8-byte ones); should the fabric split it, the reader simply sees mismatching tags for a moment.  seq is a per-context call counter (identical on all ranks, which
 // issue the same calls in the same order); slot = seq & 1 suffices because a rank cannot start call s+2 before every rank
 // has finished reading call s (it needs their s+1 contributions, which they send after their call-s kernel has ended).
 // Every poll loop has a wall-clock exit (default 20 s): on expiry the kernel records the failure and ends, and the next
