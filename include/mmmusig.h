@@ -198,6 +198,15 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
  * solves that hit max_eval, and (optional, D ints each) per-document evaluation counts */
 int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped,
                          int* per_doc_nu, int* per_doc_lambda);
+/* Launch geometry that fixes the ORDER of the sums across documents (and so their bits): out[0] = lanes per document L,
+ * [1] = theta-phase blocks, [2] = waves per theta-phase block, [3] = blocks of the moment sums, [4] = 1 when the handle
+ * takes the wide-table path (term-major posting sweep instead of LDS slabs), [5..7] = 0.  The parity tests hand it to the
+ * order-matched CPU restatement (oracle/mmm_twin.c), which then reproduces a whole fit bit for bit. */
+int mmm_ctm_geometry(const mmm_ctm* m, int out[8]);
+/* Parity probe: out[i] = op(a[i], b[i]) evaluated by the device functions the kernels use (csrc/mmm_arith.h, dev_math.h).
+ * op 0 exp, 1 log, 2 digamma (x > 0), 3 a / b, 4 sqrt, 5 / 6 / 7 sum over consecutive groups of 16 / 32 / 64 values in the
+ * lane-butterfly order of the document groups (out[i] = total of i's group; n a multiple of 64), 8 the full-wave butterfly. */
+int mmm_debug_math(mmm_ctx* ctx, int op, size_t n, const double* a, const double* b, double* out);
 /* Fused hot path: n_iter passes of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) */
 /* fit_flags: keyword arguments of fit! (MMCTM.jl:457-458): MMM_FIT_UPDATE_SIGMA = updateΣ (IMMCTM always updates Σ,
  * IMMCTM.jl:445), MMM_FIT_AUTO_ALPHA = autoα (update_α! after update_γ!, MMCTM.jl:472-474) */

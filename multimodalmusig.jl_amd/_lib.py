@@ -93,6 +93,8 @@ _SIGS = {
     "mmm_ctm_loglik": (C.c_int, [vp, f64p]),
     "mmm_ctm_elbo": (C.c_int, [vp, C.POINTER(C.c_double), vp]),
     "mmm_ctm_objectives": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), f64p, C.POINTER(C.c_double), f64p]),
+    "mmm_ctm_geometry": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "mmm_debug_math": (C.c_int, [vp, C.c_int, C.c_size_t, f64p, vp, f64p]),
     "mmm_ctm_solver_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]),
     "mmm_ctm_iterate": (C.c_int, [vp, C.c_int, C.c_int]),
     "mmm_ctm_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),

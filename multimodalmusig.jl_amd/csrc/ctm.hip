@@ -84,9 +84,9 @@ struct NuObj {
     template <int L>
     __device__ __forceinline__ double eval(double x, double& g) const
     {
-        const double E = exp(lam + 0.5 * x);
+        const double E = ar_exp(lam + 0.5 * x);
         g = act ? 0.5 * Sll + 0.5 * c * E - dev_div(1.0, 2.0 * x) : 0.0;
-        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * dev_log_pos(x) : 0.0;
+        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * ar_log(x) : 0.0;
         return group_sum<L>(t);
     }
 };
@@ -126,7 +126,7 @@ struct LamObj {
             }
             Sd = (s0 + s1) + (s2 + s3);
         }
-        const double E = exp(x + 0.5 * nu);
+        const double E = ar_exp(x + 0.5 * nu);
         g = act ? Sd - sumth + c * E : 0.0;
         const double t = act ? 0.5 * diff * Sd - x * sumth + c * E : 0.0;
         return group_sum<L>(t);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
         // ---- update_ζ! (MMCTM.jl:172-181) -------------------------------------------------------------------------
         double zl = 1.0;
         if (PH == 0 && (flags & F_ZETA)) {
-            const double E = act ? exp(lam + 0.5 * nu) : 0.0;
+            const double E = act ? ar_exp(lam + 0.5 * nu) : 0.0;
             for (int m = 0; m < M; ++m) {
                 const double zm = group_sum<L>((act && mod_l == m) ? E : 0.0);
                 if (mod_l == m) zl = zm;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
                 if (mod_l == m) mx = mm;
             }
             lds_wave_sync();
-            scrA[l] = act ? exp(lam - mx) : 0.0;
+            scrA[l] = act ? ar_exp(lam - mx) : 0.0;
             if (WIDE && act && a.aexp && (flags & F_SLAB)) a.aexp[(rep * D + d) * MK + l] = scrA[l];
             lds_wave_sync();
             for (int m = 0; m < M; ++m) {
@@ -717,11 +717,11 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
         if ((tid & 63) == 0) sh[tid >> 6] = part;
         __syncthreads();
         const double cs = sh[0] + sh[1] + sh[2] + sh[3];
-        const double pcs = dev_digamma(cs);
+        const double pcs = dev_digamma_ar(cs);
         for (int v = tid; v < Vm; v += nt) {
             const double gm = q.gamma[go + k * Vm + v];
-            const double el = dev_digamma(gm) - pcs;
-            q.Elnphi[go + k * Vm + v] = el; q.Eeff[go + k * Vm + v] = el; q.expEeff[go + k * Vm + v] = exp(el);
+            const double el = dev_digamma_ar(gm) - pcs;
+            q.Elnphi[go + k * Vm + v] = el; q.Eeff[go + k * Vm + v] = el; q.expEeff[go + k * Vm + v] = ar_exp(el);
             const double ph = gm / cs;
             if (q.phi) q.phi[go + k * Vm + v] = ph;
             q.phieff[go + k * Vm + v] = ph;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
             double cs = 0.0;
             for (int j = 0; j < tp.J[ao + i]; ++j) cs += q.gamma[mg + k * SJ + jo + j];
-            q.Elnphi[mg + k * SJ + e] = dev_digamma(q.gamma[mg + k * SJ + e]) - dev_digamma(cs);
+            q.Elnphi[mg + k * SJ + e] = dev_digamma_ar(q.gamma[mg + k * SJ + e]) - dev_digamma_ar(cs);
         }
         __syncthreads();
         // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
                 pp *= q.gamma[mg + k * SJ + jo + f] / cs;
                 jo += Ji;
             }
-            q.Eeff[go + k * Vm + v] = se; q.expEeff[go + k * Vm + v] = exp(se); q.phieff[go + k * Vm + v] = pp;
+            q.Eeff[go + k * Vm + v] = se; q.expEeff[go + k * Vm + v] = ar_exp(se); q.phieff[go + k * Vm + v] = pp;
         }
     }
 }
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmT
     const int k = blockIdx.x - dm.koff[m];
     const int Vm = dm.V[m], go = dm.goff[m];
     if (!tp.immctm) {
-        if (Elnphi) for (int v = tid; v < Vm; v += nt) { const double el = Elnphi[go + k * Vm + v]; Eeff[go + k * Vm + v] = el; expEeff[go + k * Vm + v] = exp(el); }
+        if (Elnphi) for (int v = tid; v < Vm; v += nt) { const double el = Elnphi[go + k * Vm + v]; Eeff[go + k * Vm + v] = el; expEeff[go + k * Vm + v] = ar_exp(el); }
     } else {
         const int mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
         const int* feat = tp.features + tp.foff[m];
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmT
                 }
                 jo += Ji;
             }
-            if (Elnphi) { Eeff[go + k * Vm + v] = se; expEeff[go + k * Vm + v] = exp(se); }
+            if (Elnphi) { Eeff[go + k * Vm + v] = se; expEeff[go + k * Vm + v] = ar_exp(se); }
             if (gamma) phieff[go + k * Vm + v] = pp;
         }
     }
@@ -1998,6 +1998,52 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
     if (n_capped) *n_capped = cap;
     if (per_doc_nu && D) memcpy(per_doc_nu, a.data(), sizeof(int) * D);
     if (per_doc_lambda && D) memcpy(per_doc_lambda, b.data(), sizeof(int) * D);
+    return MMM_OK;
+}
+
+int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
+{
+    if (!m || !out) return MMM_ERR_ARG;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = out[6] = out[7] = 0;
+    return MMM_OK;
+}
+
+namespace {
+__global__ void k_debug_math(int op, size_t n, const double* a, const double* b, double* out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // n is a multiple of 64 for the collectives: no early return
+    const double x = i < n ? a[i] : 0.0, y = (i < n && b) ? b[i] : 1.0;
+    double r = 0.0;
+    switch (op) {
+    case 0: r = ar_exp(x); break;
+    case 1: r = ar_log(x); break;
+    case 2: r = dev_digamma_ar(x); break;
+    case 3: r = dev_div(x, y); break;
+    case 4: r = dev_sqrt(x); break;
+    case 5: r = group_sum<16>(x); break;
+    case 6: r = group_sum<32>(x); break;
+    case 7: r = group_sum<64>(x); break;
+    case 8: r = wave_sum(x); break;
+    }
+    if (i < n) out[i] = r;
+}
+}
+
+int mmm_debug_math(mmm_ctx* ctx, int op, size_t n, const double* a, const double* b, double* out)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, a && out && op >= 0 && op <= 8, "mmm_debug_math: bad arguments");
+    MMM_CHECK(ctx, op < 5 || n % 64 == 0, "mmm_debug_math: the collectives need n %% 64 == 0");
+    if (!n) return MMM_OK;
+    MMM_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> da, db, dout;
+    MMM_HIP(ctx, da.alloc(n)); MMM_HIP(ctx, dout.alloc(n));
+    MMM_HIP(ctx, hipMemcpyAsync(da.p, a, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (b) { MMM_HIP(ctx, db.alloc(n)); MMM_HIP(ctx, hipMemcpyAsync(db.p, b, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream)); }
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, n, da.p, b ? db.p : nullptr, dout.p);
+    MMM_LAUNCH_CHECK(ctx);
+    MMM_HIP(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
 }
 

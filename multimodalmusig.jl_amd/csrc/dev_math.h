@@ -85,6 +85,10 @@ __device__ __forceinline__ double dev_sqrt(double x)
     return x == 0.0 ? 0.0 : g3;
 }
 
+// exp / log / digamma whose bits the parity tests' order-matched CPU restatement reproduces (one source for both sides)
+#include "mmm_arith.h"
+__device__ __forceinline__ double dev_digamma_ar(double x) { return (x > 0.0 && x < 1e40) ? ar_digamma_pos(x) : dev_digamma(x); }
+
 // natural log for finite x > 0 (normal or subnormal-free inputs: probabilities and Dirichlet parameters), fdlibm-style:
 // x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f/(2+f), log(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))).
 // ~35 instructions (ocml's log is ~90); error < 2 ulp.

@@ -1,12 +1,12 @@
 /* mmm_arith.h -- the scalar functions whose BITS decide where an LD_MMA solve stops (exp, log, digamma), written once
- * and compiled on both sides: by hipcc into the gfx950 kernels (csrc/ctm.hip) and by gcc into the order-matched variant
- * of the CPU oracle (oracle/mmm_twin.c).  Every operation is an IEEE-754 basic operation or an fma with a fixed
+ * and compiled on both sides: by hipcc into the gfx950 kernels (csrc/ctm.hip) and by gcc into the order-matched CPU
+ * restatement the parity tests check those kernels against.  Every operation is an IEEE-754 basic operation or an fma with a fixed
  * association, both compilers run with -ffp-contract=off, so the two sides produce identical bits for identical inputs.
  *
  * Why: NLopt's LD_MMA (call sites MMCTM.jl:127-170) stops on discontinuous tests (gval >= fcur, fcur < fbest, the
  * x-tolerance).  A 1-ulp difference in exp() between two libm's moves a stopping decision now and then, that document's
  * lambda by < xtol = 1e-4, and through the M-step every document of the next pass.  With one restatement of exp/log/
- * digamma on both sides the device and the oracle take the same decisions.
+ * digamma on both sides the device and the CPU checker take the same decisions.
  *
  * exp: the algorithm of fdlibm's e_exp.c (argument reduction by ln2 in two pieces, degree-5 minimax in r^2, one
  * division); log: fdlibm's e_log.c kernel; both < 1 ulp.  digamma (x > 0): psi(x) = psi(x+7) - Q'(x)/Q(x), Q = prod_{v<7}

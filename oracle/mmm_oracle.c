@@ -826,6 +826,7 @@ void orc_ctm_update_nu(orc_ctm* m, int d)
     ctm_cb cb = { m->lambda + (size_t)n * d, Ndz, NULL, m->mu, m->invSigma };
     double minf; int no;
     int nev = orc_mma_minimize(n, cb_nu, &cb, lb, NULL, m->nu + (size_t)n * d, &minf, m->xtol_rel, m->xtol_abs, m->xtol_rule, m->max_eval, &no);
+    if (m->nev_nu) m->nev_nu[d] = nev;
     if (nev < 0) m->n_solver_cap++; else m->n_eval_nu += nev;
     free(buf);
 }
@@ -841,6 +842,7 @@ void orc_ctm_update_lambda(orc_ctm* m, int d)
     ctm_cb cb = { m->nu + (size_t)n * d, Ndz, st, m->mu, m->invSigma };
     double minf; int no;
     int nev = orc_mma_minimize(n, cb_lambda, &cb, NULL, NULL, m->lambda + (size_t)n * d, &minf, m->xtol_rel, m->xtol_abs, m->xtol_rule, m->max_eval, &no);
+    if (m->nev_lambda) m->nev_lambda[d] = nev;
     if (nev < 0) m->n_solver_cap++; else m->n_eval_lambda += nev;
     free(buf);
 }
@@ -1156,7 +1158,7 @@ void orc_ctm_init(orc_ctm* m)
         const int64_t* dp = m->doc_ptr + (size_t)mod * (m->D + 1);
         for (int64_t e = dp[0]; e < dp[m->D]; ++e) { double* th = ctm_theta(m, mod, e); for (int k = 0; k < m->K[mod]; ++k) th[k] = 1.0 / m->K[mod]; }
     }
-    orc_ctm_update_Elnphi(m);
+    if (m->arith) orc_twin_topics(m, NULL); else orc_ctm_update_Elnphi(m);
     if (m->phi) { size_t tot = ctm_goff(m, m->M); for (size_t i = 0; i < tot; ++i) m->phi[i] = m->gamma[i]; } /* MMCTM.jl:80 deepcopy(gamma) */
     for (size_t i = 0; i < (size_t)n * m->D; ++i) { m->lambda[i] = 0.0; m->nu[i] = 1.0; }
     for (int d = 0; d < m->D; ++d) orc_ctm_update_zeta(m, d);
@@ -1168,10 +1170,13 @@ int orc_ctm_fit(orc_ctm* m, int maxiter, double tol, int update_sigma, int auto_
 {
     *converged = 0; int it = 0;
     for (int iter = 1; iter <= maxiter; ++iter) {
-        for (int d = 0; d < m->D; ++d) orc_ctm_fitdoc(m, d);
-        orc_ctm_update_mu(m);
-        if (update_sigma || m->n_feat) orc_ctm_update_Sigma(m);
-        orc_ctm_update_gamma(m);
+        if (m->arith) orc_twin_pass(m, update_sigma || m->n_feat);      /* the same steps in device order (mmm_twin.c) */
+        else {
+            for (int d = 0; d < m->D; ++d) orc_ctm_fitdoc(m, d);
+            orc_ctm_update_mu(m);
+            if (update_sigma || m->n_feat) orc_ctm_update_Sigma(m);
+            orc_ctm_update_gamma(m);
+        }
         if (auto_alpha) orc_ctm_update_alpha(m);                 /* MMCTM.jl:472-474 / IMMCTM.jl:448-450 */
         if (!m->n_feat) { orc_ctm_update_props(m); orc_ctm_update_phi(m); }
         orc_ctm_loglik(m, ll_hist + (size_t)m->M * it); ++it;

@@ -135,7 +135,25 @@ typedef struct {
     double xtol_rel, xtol_abs, nu_lower; int xtol_rule; int max_eval;
     /* statistics out */
     int64_t n_eval_lambda, n_eval_nu, n_solver_cap;
+    /* order-matched variant (mmm_twin.c).  arith = 0: every sum in index order (mmm_oracle.c); arith = 1: every sum
+     * associated as the gfx950 kernels associate it, exp/log/digamma from csrc/mmm_arith.h.  The sums across documents
+     * follow the launch geometry of the device handle (mmm_ctm_geometry): L lanes per document, grid_e blocks of waves_e
+     * waves in the theta phase, grid_m blocks in the moment sums. */
+    int arith;
+    int L, grid_e, waves_e, grid_m;
+    int* nev_nu; int* nev_lambda;   /* objective evaluations per document in the last pass (either variant; may be NULL) */
+    double* expE;                   /* arith = 1: exp(Elnphi) in the effective [m][k][v] layout, sum_m K_m V_m doubles */
 } orc_ctm;
+
+/* the pieces of one pass in device order (mmm_twin.c) */
+void orc_twin_topics(orc_ctm* m, const double* sG);
+void orc_twin_estep(orc_ctm* m, double* sG);
+void orc_twin_moments(const orc_ctm* m, double* mom);
+int  orc_twin_gauss(orc_ctm* m, const double* mom, int do_sigma);
+int  orc_twin_pass(orc_ctm* m, int update_sigma);
+void orc_ar_exp_vec(int n, const double* x, double* out);
+void orc_ar_log_vec(int n, const double* x, double* out);
+void orc_ar_digamma_vec(int n, const double* x, double* out);
 
 void orc_ctm_update_zeta(orc_ctm* m, int d);
 void orc_ctm_update_theta(orc_ctm* m, int d);

@@ -22,7 +22,8 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 def build(force=False):
     so = os.path.join(_HERE, "build", "libmmm_oracle.so")
     so_omp = os.path.join(_HERE, "build", "libmmm_oracle_omp.so")
-    src = [os.path.join(_HERE, f) for f in ("mmm_oracle.c", "mmm_oracle.h", "mmm_oracle_omp.c")]
+    src = [os.path.join(_HERE, f) for f in ("mmm_oracle.c", "mmm_oracle.h", "mmm_oracle_omp.c", "mmm_twin.c")]
+    src.append(os.path.join(_HERE, "..", "multimodalmusig.jl_amd", "csrc", "mmm_arith.h"))
     stale = (not os.path.exists(so)) or (not os.path.exists(so_omp)) or any(os.path.getmtime(s) > min(os.path.getmtime(so), os.path.getmtime(so_omp)) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
@@ -41,6 +42,8 @@ class OrcCtm(C.Structure):
         ("xtol_rel", C.c_double), ("xtol_abs", C.c_double), ("nu_lower", C.c_double),
         ("xtol_rule", C.c_int), ("max_eval", C.c_int),
         ("n_eval_lambda", C.c_int64), ("n_eval_nu", C.c_int64), ("n_solver_cap", C.c_int64),
+        ("arith", C.c_int), ("L", C.c_int), ("grid_e", C.c_int), ("waves_e", C.c_int), ("grid_m", C.c_int),
+        ("nev_nu", C.c_void_p), ("nev_lambda", C.c_void_p), ("expE", C.c_void_p),
     ]
 
 
@@ -112,6 +115,13 @@ def lib():
                               C.POINTER(C.c_double)]
     L.orc_ctm_unsmoothed_update_theta.argtypes = [P, C.c_int]
     L.orc_ctm_infer.argtypes = [P, C.c_int, C.c_int, C.c_double, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_twin_topics.argtypes = [P, C.c_void_p]
+    L.orc_twin_estep.argtypes = [P, f64p]
+    L.orc_twin_moments.argtypes = [P, f64p]
+    L.orc_twin_gauss.argtypes = [P, f64p, C.c_int]; L.orc_twin_gauss.restype = C.c_int
+    L.orc_twin_pass.argtypes = [P, C.c_int]; L.orc_twin_pass.restype = C.c_int
+    for name in ("exp", "log", "digamma"):
+        getattr(L, "orc_ar_%s_vec" % name).argtypes = [C.c_int, f64p, f64p]
     _LIB = L
     return L
 
@@ -410,7 +420,10 @@ class CtmOracle:
     features: None (MMCTM) or list of (V_m x I_m) 1-based integer matrices (IMMCTM).
     """
 
-    def __init__(self, K, alpha, X, V=None, features=None, gamma0=None, seed=0, xtol_rule=0, max_eval=100000):
+    def __init__(self, K, alpha, X, V=None, features=None, gamma0=None, seed=0, xtol_rule=0, max_eval=100000, geometry=None):
+        """geometry: None -> every sum in index order (mmm_oracle.c).  A dict {L, grid_e, waves_e, grid_m} (the launch
+        geometry of a device handle, `MMCTM.geometry()`) -> the order-matched variant (mmm_twin.c): same algorithm, sums
+        associated as the gfx950 kernels associate them, exp/log/digamma from csrc/mmm_arith.h."""
         self.K = np.asarray(K, dtype=np.int32); self.M = len(K); self.MK = int(self.K.sum())
         self.D = len(X)
         self.doc_ptr, self.term, self.count = flatten_mm(X, self.M)
@@ -472,6 +485,14 @@ class CtmOracle:
         s.lambda_ = self.lam.ctypes.data; s.nu = self.nu.ctypes.data; s.zeta = self.zeta.ctypes.data
         s.props = self.props.ctypes.data; s.theta = self.theta.ctypes.data
         s.xtol_rel = 1e-4; s.xtol_abs = 1e-4; s.nu_lower = 1e-7; s.xtol_rule = xtol_rule; s.max_eval = max_eval
+        self.nev_nu = np.zeros(max(D, 1), dtype=np.int32); self.nev_lambda = np.zeros(max(D, 1), dtype=np.int32)
+        s.nev_nu = self.nev_nu.ctypes.data; s.nev_lambda = self.nev_lambda.ctypes.data
+        self.expE = np.zeros(int(sum(int(self.K[m]) * int(self.V[m]) for m in range(self.M))))
+        s.expE = self.expE.ctypes.data
+        if geometry is not None:
+            s.arith = 1
+            s.L, s.grid_e, s.waves_e, s.grid_m = (int(geometry[k]) for k in ("L", "grid_e", "waves_e", "grid_m"))
+            assert s.L in (16, 32, 64) and s.L >= self.MK and s.grid_e >= 1 and s.waves_e >= 1 and s.grid_m >= 1
         self.s = s
         lib().orc_ctm_init(C.byref(s))
 
@@ -502,6 +523,15 @@ class CtmOracle:
         t = np.empty(7); e = lib().orc_ctm_elbo(C.byref(self.s), t); return e, t
 
     def update_alpha(self): lib().orc_ctm_update_alpha(C.byref(self.s))
+
+    # ---- the pieces of one pass in device order (geometry given) ----
+    def twin_pass(self, update_sigma=True):
+        assert self.s.arith
+        return lib().orc_twin_pass(C.byref(self.s), int(update_sigma or self.immctm))
+
+    def twin_estep(self):
+        assert self.s.arith
+        sG = np.zeros(self.expE.size); lib().orc_twin_estep(C.byref(self.s), sG); return sG
 
     def fit(self, maxiter=100, tol=1e-4, update_sigma=True, auto_alpha=False):
         ll = np.zeros(self.M * maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
