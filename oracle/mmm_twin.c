@@ -484,6 +484,21 @@ int orc_twin_pass(orc_ctm* m, int update_sigma)
     return rc;
 }
 
+/* the two objectives at (lambda, nu) in the reference's MAXIMISATION form (common.jl:11-36), evaluated by the functions the
+ * solves above use: vals = {lambda_objective, nu_objective}; for the known-answer tests (test/common.jl:79-97) */
+void orc_twin_objectives(int n, const double* lambda, const double* nu, const double* Ndivzeta, const double* sumtheta,
+                         const double* mu, const double* invSigma, double* vals, double* grad_lambda, double* grad_nu)
+{
+    const int L = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+    double g[64];
+    tw_obj o = { n, L, nu, Ndivzeta, sumtheta, mu, invSigma };
+    vals[0] = -tw_lam_eval(&o, lambda, g);
+    for (int i = 0; i < n; ++i) grad_lambda[i] = -g[i];
+    o.other = lambda;
+    vals[1] = -tw_nu_eval(&o, nu, g);
+    for (int i = 0; i < n; ++i) grad_nu[i] = -g[i];
+}
+
 /* ---- vector entry points for the arithmetic tests ------------------------------------------------------------------- */
 void orc_ar_exp_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_exp(x[i]); }
 void orc_ar_log_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_log(x[i]); }

@@ -49,6 +49,19 @@ c = orc.CtmOracle([7, 7], [0.1, 0.1], X3, V=[96, 48], gamma0=np.concatenate([x.r
 llc = c.fit(maxiter=12, tol=0.0)
 out["config3_mmctm_77"] = {"gamma0_seed": 2, "maxiter": 12, "ll": [[float(x) for x in row] for row in llc], "elbo": float(c.elbo_value),
                            "mu": [float(x) for x in c.mu], "gamma_sum": float(c.gamma.sum())}
+# the same fit by the order-matched variant (oracle/mmm_twin.c) in the launch geometry the library picks for 560 documents with
+# sum K = 14 (16 lanes per document, 8-wave theta blocks -> 18 blocks; 18 moment blocks): the device reproduces it bit for bit
+GEO3 = {"L": 16, "grid_e": 18, "waves_e": 8, "grid_m": 18}
+t = orc.CtmOracle([7, 7], [0.1, 0.1], X3, V=[96, 48], gamma0=np.concatenate([x.ravel() for x in g0]), geometry=GEO3)
+llt = t.fit(maxiter=12, tol=0.0)
+out["config3_mmctm_77_device_order"] = {
+    "geometry": GEO3, "maxiter": 12, "ll": [[float(x) for x in row] for row in llt], "elbo": float(t.elbo_value),
+    "mu": [float(x) for x in t.mu], "invSigma_diag": [float(x) for x in t.invSigma.reshape(14, 14).diagonal()],
+    "gamma_first_topic": [float(x) for x in t.gamma[:96]], "gamma_sum": float(t.gamma.sum()),
+    "lambda_doc0": [float(x) for x in t.lam[:14]], "nu_doc0": [float(x) for x in t.nu[:14]],
+    "lambda_sum": float(t.lam.sum()), "nu_sum": float(t.nu.sum()),
+    "nev_nu_last_pass": [int(x) for x in t.nev_nu[:560]], "nev_lambda_last_pass": [int(x) for x in t.nev_lambda[:560]],
+    "fork_vs_index_order_ll_rel": [float(x) for x in (np.abs(llt - llc).max(axis=1) / np.abs(llc).max(axis=1))]}
 with open(os.path.join(HERE, "oracle_trajectories.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print("wrote oracle_trajectories.json", len(ll), "LDA passes")

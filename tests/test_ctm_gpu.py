@@ -1,9 +1,15 @@
 """GPU parity tests for the MMCTM / IMMCTM path: the HIP backend through the C ABI / host mirror against (i) the reference's
 own known-answer tests (test/mmctm.jl, test/immctm.jl, test/common.jl), (ii) the CPU oracle on seeded synthetic corpora.
 
-MMA note: the optimiser stops on discontinuous tests, so a 1-ulp difference in an objective value can, rarely,
-change an iteration count and move that document's lambda/nu by up to the 1e-4 x-tolerance.  Per-document solver outputs are
-therefore compared robustly (>= 95 % of documents to 1e-7, all to 2e-3 absolute), globals and ELBO at the 1e-5 bar."""
+Two variants of the oracle are used (both restate the same reference lines; oracle/mmm_oracle.h):
+* order="device": sums associated as the kernels associate them and exp/log/digamma from the header both sides compile
+  (oracle/mmm_twin.c).  The HIP path must reproduce it BIT FOR BIT over whole fits: every document's LD_MMA solves take the same
+  number of evaluations, lambda / nu / mu / invSigma / gamma are identical, ll / ELBO / theta / props agree far inside the
+  1e-5 bar of the north star.
+* order="index" (every sum in index order, libm exp): LD_MMA stops on discontinuous tests, so a 1-ulp difference in an objective
+  value can change an iteration count and move that document's lambda/nu by up to the 1e-4 x-tolerance.  Against this variant
+  single stages from identical state are compared robustly (>= 95 % of documents to 1e-7, all to 2e-3 absolute); whole fits
+  drift apart exactly as the two CPU variants drift apart from each other (tests/test_twin_cpu.py::test_fork_...)."""
 import numpy as np
 import pytest
 
@@ -173,18 +179,35 @@ def test_elbo_and_fit_shapes(mmm, kats, imm):               # test/mmctm.jl:337-
 
 
 # ------------------------------------------------------------------------------------------ differential vs the oracle
-def _pair(mmm, oracle, D, K, V, seed, means, imm_features=None, empty_frac=0.15, rule=0):
+def _pair(mmm, oracle, D, K, V, seed, means, imm_features=None, empty_frac=0.15, rule=0, order="index"):
     X, g0 = np_ref.synth_mm(D, V, K, seed=seed, means=means, empty_frac=empty_frac)
     alpha = [0.1] * len(K)
     if imm_features is None:
         g = mmm.MMCTM(K, alpha, V, X, γ0=g0, xtol_rule=rule)
-        o = oracle.CtmOracle(K, alpha, X, V=V, gamma0=np.concatenate([x.ravel() for x in g0]), xtol_rule=rule)
+        geo = g.geometry() if order == "device" else None
+        o = oracle.CtmOracle(K, alpha, X, V=V, gamma0=np.concatenate([x.ravel() for x in g0]), xtol_rule=rule, geometry=geo)
     else:
         GM = sum(K[m] * int(np.asarray(imm_features[m]).max(axis=0).sum()) for m in range(len(K)))
         g0f = np.random.default_rng(seed).integers(1, 101, size=GM).astype(np.float64)
         g = mmm.IMMCTM(K, alpha, imm_features, X, γ0=g0f, xtol_rule=rule)
-        o = oracle.CtmOracle(K, alpha, X, features=imm_features, gamma0=g0f, xtol_rule=rule)
+        geo = g.geometry() if order == "device" else None
+        o = oracle.CtmOracle(K, alpha, X, features=imm_features, gamma0=g0f, xtol_rule=rule, geometry=geo)
+    assert geo is None or not geo["wide"]
     return X, g, o
+
+
+def _same_bits(a, b, what):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel(); b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    n = int((a.view(np.int64) != b.view(np.int64)).sum())
+    assert n == 0, "%s: %d of %d values differ in their bits (max abs diff %.3g)" % (what, n, a.size, np.abs(a - b).max())
+
+
+def _same_state(g, o, D, MK):
+    """the state that feeds the next pass, bit for bit"""
+    _same_bits(g.lam_matrix(), o.lam, "lambda"); _same_bits(g.nu_matrix(), o.nu, "nu"); _same_bits(g._get("zeta"), o.zeta, "zeta")
+    _same_bits(g.μ, o.mu, "mu"); _same_bits(np.asarray(g.Σ).ravel(order="F"), o.Sigma, "Sigma")
+    _same_bits(np.asarray(g.invΣ).ravel(order="F"), o.invSigma, "invSigma")
+    _same_bits(g._get("gamma"), o.gamma, "gamma"); _same_bits(g._get("Elnphi"), o.Elnphi, "Elnphi")
 
 
 def _robust_close(a, b, frac=0.95, tight=1e-7, loose=2e-3):
@@ -270,30 +293,82 @@ def test_fused_pass_matches_stage_sequence_and_oracle(mmm, oracle, rule):
     assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
 
 
+def _fit_case(case):
+    if case == "mm":
+        return dict(D=80, K=[5, 4], V=[40, 24], seed=5, means=[600, 80])
+    if case == "mm_k20":      # a modality with more than 16 topics
+        return dict(D=90, K=[20, 6], V=[96, 32], seed=15, means=[2500, 120])
+    if case == "cfg3_shape":  # K = [7, 7] over 96 + 48 terms (BASELINE config 3's shape; the BRCA tables themselves: test_brca_gpu.py)
+        return dict(D=560, K=[7, 7], V=[96, 48], seed=25, means=[3000, 60])
+    if case == "cfg4_shape":  # K = [10, 10, 8] over 96 + 38 + 32 terms (BASELINE config 4's shape)
+        return dict(D=700, K=[10, 10, 8], V=[96, 38, 32], seed=26, means=[2000, 150, 100])
+    return dict(D=70, K=[6], V=[96], seed=6, means=[1500], imm_features=SNV3)
+
+
 @pytest.mark.parametrize("case", ["mm", "imm", "mm_k20"])
 def test_fit_matches_oracle(mmm, oracle, case):
-    """fit! with the reference's stopping rule: same number of passes, ll history / phi / ELBO within the 1e-5 bar."""
-    if case == "mm":
-        X, g, o = _pair(mmm, oracle, 80, [5, 4], [40, 24], seed=5, means=[600, 80])
-    elif case == "mm_k20":      # a modality with more than 16 topics
-        X, g, o = _pair(mmm, oracle, 90, [20, 6], [96, 32], seed=15, means=[2500, 120])
-    else:
-        X, g, o = _pair(mmm, oracle, 70, [6], [96], seed=6, means=[1500], imm_features=SNV3)
+    """fit! with the reference's stopping rule against the order-matched oracle: same number of passes, the state identical
+    in every bit, ll history / ELBO / theta / props / gamma inside the 1e-5 bar of the north star (by eight orders)."""
+    kw = _fit_case(case)
+    D, MK, M = kw["D"], sum(kw["K"]), len(kw["K"])
+    X, g, o = _pair(mmm, oracle, order="device", **kw)
     ll_g = mmm.fit(g, maxiter=40, tol=1e-4, verbose=False)
     ll_o = o.fit(maxiter=40, tol=1e-4)
     assert len(ll_g) == len(ll_o) and g.converged == o.converged
-    # 26-dimensional solves on heavy counts flip more often (same deviation with K = [13, 13] or [16, 10], the 16-unrolled build):
-    # the ll trajectory is compared at 5e-4 there, the ELBO at the 1e-5 bar everywhere
+    _same_state(g, o, D, MK)
+    st = g.solver_stats(per_doc=True)
+    assert st["n_capped"] == 0
+    assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+    rtol = 1e-5          # the north-star tolerance; what is observed is printed below
+    np.testing.assert_allclose(ll_g, ll_o, rtol=rtol)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=rtol)
+    np.testing.assert_allclose(g._get("theta"), o.theta, rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=rtol)
+    if case != "imm":
+        o.update_props()
+        np.testing.assert_allclose(g._get("props"), o.props, rtol=rtol)
+        np.testing.assert_allclose(g._get("phi"), o.phi, rtol=rtol)
+    obs = (np.abs(ll_g / ll_o - 1).max(), abs(g.elbo / o.elbo_value - 1), np.abs(g._get("theta") / np.maximum(o.theta, 1e-300) - 1).max())
+    print("fit parity [%s], %d passes: ll rel err %.1e, ELBO %.1e, theta %.1e (bar 1e-5); state bit-identical" % ((case, len(ll_g)) + obs))
+    assert max(obs) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["cfg3_shape", "cfg4_shape", "imm"])
+def test_per_document_mma_evaluation_counts(mmm, oracle, case):
+    """SURVEY section 7 hard-part 1: the observable that says where two trajectories fork is the number of objective
+    evaluations of each document's two LD_MMA solves (MMCTM.jl:141,168; common.jl:11-36).  Twelve passes, compared after
+    every pass: equal for 100 % of the documents, and lambda / nu / the M-step globals equal in every bit."""
+    kw = _fit_case(case)
+    D, MK = kw["D"], sum(kw["K"])
+    X, g, o = _pair(mmm, oracle, order="device", **kw)
+    for it in range(12):
+        mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        assert o.twin_pass(True) == 0
+        st = g.solver_stats(per_doc=True)
+        assert st["n_capped"] == 0
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]), "pass %d: nu solves of %d documents took a different number of evaluations" % (it + 1, (st["per_doc_nu"] != o.nev_nu[:D]).sum())
+        assert np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D]), "pass %d: lambda solves differ for %d documents" % (it + 1, (st["per_doc_lambda"] != o.nev_lambda[:D]).sum())
+        _same_state(g, o, D, MK)
+    print("%s: %d documents x 12 passes, evaluations per pass nu %d lambda %d -- all equal" % (case, D, st["n_eval_nu"], st["n_eval_lambda"]))
+
+
+@pytest.mark.parametrize("case", ["mm", "mm_k20"])
+def test_fit_against_index_order_oracle(mmm, oracle, case):
+    """The same fits against the index-order variant (libm exp, sequential sums).  The two CPU variants themselves drift apart by
+    1e-8 ... 1e-5 on the ll within 15 passes (tests/test_twin_cpu.py); the device, being bit-identical to one of them, shows
+    the same drift against the other -- objective-level quantities stay within the fork's magnitude, parameters within the
+    solver's x-tolerance scale."""
+    kw = _fit_case(case)
+    X, g, o = _pair(mmm, oracle, order="index", **kw)
+    ll_g = mmm.fit(g, maxiter=40, tol=1e-4, verbose=False)
+    ll_o = o.fit(maxiter=40, tol=1e-4)
+    assert len(ll_g) == len(ll_o) and g.converged == o.converged
+    np.testing.assert_allclose(ll_g[:2], ll_o[:2], rtol=1e-10)
     np.testing.assert_allclose(ll_g, ll_o, rtol=5e-4 if case == "mm_k20" else 1e-5)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-5)
-    # Over a whole fit the rare MMA stopping flips (module docstring) feed back through the M-step: topic parameters agree
-    # to ~1e-2 worst case / ~1e-4 typical, while the objective-level quantities above agree at the 1e-5 bar.
     ge = np.abs(g._get("gamma") - o.gamma) / np.maximum(np.abs(o.gamma), 1e-9)
-    th_err = np.abs(g._get("theta") - o.theta) / np.maximum(np.abs(o.theta), 1e-9)
-    print("fit parity [%s]: gamma rel err median %.2e max %.2e; theta rel err median %.2e, 99%% %.2e" %
-          (case, np.median(ge), ge.max(), np.median(th_err), np.quantile(th_err, 0.99)))
+    print("fork against the index-order oracle [%s]: ll %.1e, gamma median %.1e max %.1e" % (case, np.abs(ll_g / ll_o - 1).max(), np.median(ge), ge.max()))
     assert ge.max() < 5e-2 and np.median(ge) < 1e-3
-    assert np.median(th_err) < 1e-3
 
 
 @pytest.mark.parametrize("K,V", [([16, 16, 12], [30, 20, 12]), ([3], [25]), ([9, 9, 9, 9], [12, 12, 12, 12]),
