@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- E-step docs/sec of the MI355X backend on BASELINE.json's configuration.
+"""bench.py -- E-step docs/sec of the MI355X backend on BASELINE.json's configurations.
 
-A "step" = one outer EM iteration (the body of fit!, LDA.jl:201-209: E-step over every document, M-step
-reduction, log-likelihood) over one batch of synthetic documents resident in HBM.
-N = 1: BASELINE configs[1] -- LDA K=10, alpha=eta=0.1, D=10,000 documents x 96 SNV terms (SURVEY §8d generator).
-N > 1: weak scaling -- every rank holds its own 10,000-document shard (global corpus 10,000 x N), one all-reduce of the packed
-lambda statistics and the ll numerator per iteration (xGMI mailboxes inside the reduce + M-step launch, ncclAllReduce as fallback;
-the line reports which in config.allreduce).
+A "step" = one outer EM iteration (the body of fit!: E-step over every document, M-step reduction, log-likelihood;
+LDA.jl:201-209, MMCTM.jl:462-479, IMMCTM.jl:440-451) over one batch of synthetic documents resident in HBM.
 
-Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both
-sides; MAX over ranks; rank 0 prints ONE JSON line.
+  --config 2 (default)  BASELINE configs[1]: LDA K=10, alpha=eta=0.1, 10,000 documents x 96 SNV terms      (headline metric)
+  --config 4            BASELINE configs[3]: MMCTM K=[10,10,8], 50,000 documents x (96,38,32) terms
+  --config 5            BASELINE configs[4]: IMMCTM K=[10], 100,000 documents x 96 terms, features I=3, J=[6,4,4]
+  --scaling weak        (default) every rank holds its own corpus of the configuration's size
+  --scaling strong      the ONE corpus of the configuration's size, documents sharded over the ranks (balanced by nonzeros)
+
+N > 1: one all-reduce of the packed sufficient statistics and of the ll numerators per iteration (xGMI mailboxes, ncclAllReduce
+as fallback; the line reports which in config.allreduce).
+
+Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over
+ranks.  That timed region is repeated R times (--repeats, default 9): `ms_per_step` / `value` are the MEDIAN region, min / max beside
+them (a 20-step region of config 2 lasts 0.5 ms; one region alone carries the +-40 us of the bracketing synchronisations).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,17 +32,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz: 39.3 T fma/s
+
+CONFIGS = {
+    2: dict(model="lda", K=10, V=96, docs=10000, name="LDA K=10 alpha=eta=0.1, %d docs x 96 SNV terms (BASELINE configs[1])"),
+    4: dict(model="mmctm", K=[10, 10, 8], V=[96, 38, 32], docs=50000, name="MMCTM K=[10,10,8] alpha=0.1, %d docs x (96,38,32) terms (BASELINE configs[3])"),
+    5: dict(model="immctm", K=[10], V=[96], docs=100000, name="IMMCTM K=[10] alpha=0.1, %d docs x 96 terms, features I=3 J=[6,4,4] (BASELINE configs[4])"),
+}
 
 
-def synth(D, V, K, seed):
-    import np_ref
-    return np_ref.synth_lda(D, V, K, seed=seed)
+def host_cores():
+    """cores this process may actually use: the cgroup CPU quota if there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
-def cpu_baseline(X, lam0, K, alpha, eta, target_s=12.0):
-    """The CPU oracle (a compiled, allocation-free C port of the reference's Julia loop; 1 thread like the
-    reference) timed on a bounded number of passes over the SAME 10k-document corpus."""
+def snv3():
+    import numpy as np
+    return [np.array([[t // 16 + 1, (t // 4) % 4 + 1, t % 4 + 1] for t in range(96)])]      # SURVEY section 8d cfg 5 factorisation
+
+
+# ----------------------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_lda(X, lam0, K, alpha, eta, target_s=12.0):
+    """The CPU oracle (a compiled, allocation-free C port of the reference's Julia loop; 1 thread like the reference) timed on a
+    bounded number of passes over the SAME corpus."""
     from oracle import oracle as orc
     V = lam0.shape[0]
     o = orc.LdaOracle(K, alpha, eta, X, V=V, lambda0=lam0)
@@ -53,27 +80,51 @@ def cpu_baseline(X, lam0, K, alpha, eta, target_s=12.0):
     res = {"value": len(X) * n / dt, "unit": "docs/s", "cores": 1, "kind": "port",
            "sample": "%d passes over the same %d-doc corpus, %.1f s, single thread (C oracle; the Julia reference "
                      "cannot run on this box)" % (n, len(X), dt)}
-    # the same iteration with its document loops on every host core (OpenMP; SURVEY §8d asks for both figures)
+    # the same iteration with its document loops on every core the box grants (OpenMP; SURVEY section 8d asks for both figures)
     try:
-        nthr = orc.lib_omp().orc_omp_threads()
+        cores = host_cores()
+        L = orc.lib_omp()
+        L.orc_omp_set_threads(cores)
         t0 = time.perf_counter(); o.pass_omp(); t1 = time.perf_counter() - t0
         m = max(2, min(2000, int(4.0 / max(t1, 1e-4))))
         t0 = time.perf_counter()
         for _ in range(m):
             o.pass_omp()
         dtm = time.perf_counter() - t0
-        res["all_cores"] = {"value": len(X) * m / dtm, "unit": "docs/s", "cores": int(nthr), "kind": "port (OpenMP over documents)",
-                            "sample": "%d passes, %.1f s" % (m, dtm)}
+        res["all_cores"] = {"value": len(X) * m / dtm, "unit": "docs/s", "cores": int(cores), "threads": int(L.orc_omp_threads()),
+                            "kind": "port (OpenMP over documents)",
+                            "sample": "%d passes, %.1f s; cores = cgroup quota / affinity of this process" % (m, dtm)}
     except Exception as e:       # noqa: BLE001 -- the single-thread figure is the contract; this one is an extra
         res["all_cores"] = {"error": str(e)}
     return res
 
 
-def parity_probe(pkg, K, alpha, eta, V, seed):
-    """ELBO / phi relative error GPU vs oracle on a bounded sample (200 docs, 12 passes)."""
+def cpu_baseline_ctm(cfg, X, g0, target_s=14.0):
+    """fit!(::MMCTM / ::IMMCTM) by the index-order C oracle, one thread, on a bounded sample of the same corpus: whole passes
+    (E-step with the two LD_MMA solves per document, M-step, log-likelihood)."""
     import numpy as np
     from oracle import oracle as orc
-    X, lam0 = synth(200, V, K, seed)
+    Ds = min(len(X), 4000)
+    alpha = [0.1] * len(cfg["K"])
+    if cfg["model"] == "mmctm":
+        o = orc.CtmOracle(cfg["K"], alpha, X[:Ds], V=cfg["V"], gamma0=np.concatenate([g.ravel() for g in g0]))
+    else:
+        o = orc.CtmOracle(cfg["K"], alpha, X[:Ds], features=snv3(), gamma0=g0)
+    t0 = time.perf_counter(); o.fit(maxiter=1, tol=0.0); t1 = time.perf_counter() - t0
+    n = max(2, min(200, int(target_s / max(t1, 1e-3))))
+    t0 = time.perf_counter(); o.fit(maxiter=n, tol=0.0); dt = time.perf_counter() - t0
+    return {"value": Ds * n / dt, "unit": "docs/s", "cores": 1, "kind": "port",
+            "sample": "%d passes over the first %d documents of the same corpus, %.1f s, single thread (C oracle, index-order "
+                      "variant; the Julia reference cannot run on this box)" % (n, Ds, dt)}
+
+
+# ----------------------------------------------------------------------------------------------------------- parity probes
+def parity_probe_lda(pkg, K, alpha, eta, V, seed):
+    """ELBO / phi relative error GPU vs oracle on a bounded sample (200 docs, 12 passes)."""
+    import numpy as np
+    import np_ref
+    from oracle import oracle as orc
+    X, lam0 = np_ref.synth_lda(200, V, K, seed=seed)
     g = pkg.LDA(K, alpha, eta, V, X, λ0=lam0)
     pkg.fit(g, maxiter=12, tol=0.0, verbose=False)
     o = orc.LdaOracle(K, alpha, eta, X, V=V, lambda0=lam0)
@@ -85,19 +136,57 @@ def parity_probe(pkg, K, alpha, eta, V, seed):
     return {"elbo_rel_err_vs_oracle": rel_elbo, "phi_max_rel_err_vs_oracle": rel_phi}
 
 
+def parity_probe_ctm(pkg, cfg, seed):
+    """ELBO / theta relative error and per-document LD_MMA evaluation counts, GPU vs the order-matched oracle, on a bounded sample
+    (400 docs, 12 passes)."""
+    import numpy as np
+    import np_ref
+    from oracle import oracle as orc
+    K, V = cfg["K"], cfg["V"]
+    alpha = [0.1] * len(K)
+    X, g0 = np_ref.synth_mm(400, V, K, seed=seed)
+    if cfg["model"] == "mmctm":
+        g = pkg.MMCTM(K, alpha, V, X, γ0=g0)
+        o = orc.CtmOracle(K, alpha, X, V=V, gamma0=np.concatenate([x.ravel() for x in g0]), geometry=g.geometry())
+    else:
+        GM = sum(K[i] * int(f.max(axis=0).sum()) for i, f in enumerate(snv3()))
+        g0f = np.random.default_rng(seed).integers(1, 101, size=GM).astype(np.float64)
+        g = pkg.IMMCTM(K, alpha, snv3(), X, γ0=g0f)
+        o = orc.CtmOracle(K, alpha, X, features=snv3(), gamma0=g0f, geometry=g.geometry())
+    pkg.fit(g, maxiter=12, tol=0.0, verbose=False)
+    o.fit(maxiter=12, tol=0.0)
+    st = g.solver_stats(per_doc=True)
+    th_g, th_o = g._get("theta"), o.theta
+    res = {"elbo_rel_err_vs_oracle": abs(g.elbo - o.elbo_value) / abs(o.elbo_value),
+           "theta_max_rel_err_vs_oracle": float(np.max(np.abs(th_g - th_o) / np.maximum(np.abs(th_o), 1e-300))),
+           "mma_evaluation_counts_equal_for_all_documents": bool(np.array_equal(st["per_doc_nu"], o.nev_nu[:400]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:400])),
+           "oracle": "order-matched variant (oracle/mmm_twin.c), 400 docs x 12 passes"}
+    g.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--docs", type=int, default=10000, help="documents per GPU")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps iterations each; the median is reported")
+    ap.add_argument("--docs", type=int, default=0, help="documents per GPU (weak) / in total (strong); default: the configuration's size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 50 if cfg["model"] == "lda" else 10
+    if args.warmup is None:
+        args.warmup = 5 if cfg["model"] == "lda" else 2
 
     import numpy as np
     import torch                       # first: the library then binds to the HIP runtime torch has loaded
     import torch.distributed as dist
     import mmm_pkg
+    import np_ref
     pkg = mmm_pkg.load()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,83 +214,155 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    K, V, alpha, eta, D = 10, 96, 0.1, 0.1, args.docs
-    seed = 20261003 + 1                                   # corpus seed = 20261003 + config index
-    X, lam0 = synth(D, V, K, seed + 1000 * rank)          # every rank its own shard; lambda0 identical
-    if world > 1:                                          # same lambda0 everywhere: take rank 0's
-        t = torch.from_numpy(np.ascontiguousarray(lam0)).cuda()
+    # ---- corpus: SURVEY section 8d generator, corpus seed = 20261003 + config index; weak: every rank its own corpus (seed + 1000 rank),
+    # strong: every rank generates the one corpus and keeps its nnz-balanced contiguous shard
+    Dcfg = args.docs or cfg["docs"]
+    seed = 20261003 + (1 if args.config == 2 else args.config)
+    K, V = cfg["K"], cfg["V"]
+    corpus_seed = seed + (1000 * rank if args.scaling == "weak" else 0)
+    if cfg["model"] == "lda":
+        X, init = np_ref.synth_lda(Dcfg, V, K, seed=corpus_seed)
+    else:
+        X, init = np_ref.synth_mm(Dcfg, V, K, seed=corpus_seed)
+        if cfg["model"] == "immctm":
+            GM = sum(K[i] * int(f.max(axis=0).sum()) for i, f in enumerate(snv3()))
+            init = np.random.default_rng(1).integers(1, 101, size=GM).astype(np.float64)
+    if args.scaling == "strong" and world > 1:
+        d0, d1 = pkg.shard_documents(X, world, rank)
+        X = X[d0:d1]
+    D = len(X)
+    if world > 1 and cfg["model"] == "lda":                  # same lambda0 everywhere: take rank 0's
+        t = torch.from_numpy(np.ascontiguousarray(init)).cuda()
         dist.broadcast(t, 0)
-        lam0 = t.cpu().numpy()
-    model = pkg.LDA(K, alpha, eta, V, X, λ0=lam0, ctx=ctx)
-    nnz = int(model._doc_ptr[-1])
+        init = t.cpu().numpy()
+    elif world > 1 and cfg["model"] == "mmctm":
+        t = torch.from_numpy(np.concatenate([g.ravel() for g in init])).cuda()
+        dist.broadcast(t, 0)
+        flat = t.cpu().numpy(); o = 0; new = []
+        for g in init:
+            new.append(flat[o:o + g.size].reshape(g.shape).copy()); o += g.size
+        init = new
     lib = pkg.lib()
+    if cfg["model"] == "lda":
+        alpha = eta = 0.1
+        model = pkg.LDA(K, alpha, eta, V, X, λ0=init, ctx=ctx)
+        nnz = int(model._doc_ptr[-1])
 
-    def steps(n):
-        pkg._lib.check(lib.mmm_lda_iterate(model._h, n), ctx.h, "mmm_lda_iterate")
+        def steps(n):
+            pkg._lib.check(lib.mmm_lda_iterate(model._h, n), ctx.h, "mmm_lda_iterate")
+    else:
+        alpha = [0.1] * len(K)
+        if cfg["model"] == "mmctm":
+            model = pkg.MMCTM(K, alpha, V, X, γ0=init, ctx=ctx)
+        else:
+            model = pkg.IMMCTM(K, alpha, snv3(), X, γ0=init, ctx=ctx)
+        nnz = int(sum(model._nnz))
+
+        def steps(n):
+            pkg._lib.check(lib.mmm_ctm_iterate(model._h, n, 1), ctx.h, "mmm_ctm_iterate")
 
     steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    # Dominant-kernel duration: the same K steps again with every k_lda_estep launch bracketed by a HIP event pair on the
-    # library's stream.  Kept out of the timed region above because each hipEventRecord opens a ~5.6 us bubble in the
-    # otherwise back-to-back kernel stream (rocprofv3 trace: profiles/), i.e. +25 % on ms_per_step.
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append(dt)
+    dt = float(np.median(regions))
+
+    # Dominant-kernel duration: the same K steps again with every launch of the dominant kernel bracketed by a HIP event pair on
+    # the library's stream.  Kept out of the timed regions above because each hipEventRecord opens a ~5.6 us bubble in the otherwise
+    # back-to-back kernel stream (rocprofv3 trace: profiles/), i.e. +25 % on config 2's ms_per_step.
     ctx.profile_begin()
     steps(args.steps)
     n_launch, k_ms = ctx.profile_end()
-    # ... and once more with the (idempotent) kernel launched twice inside every span: the difference of the two spans is the
-    # kernel's own duration, without the ~4 us an event pair adds around a single launch (what rocprofv3 reports)
-    ctx.profile_begin(repeat=2)
-    steps(args.steps)
-    n_launch2, k_ms2 = ctx.profile_end()
-    ctx.profile_begin(repeat=1); ctx.profile_end()
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ll = np.zeros(1); n = pkg._lib.C.c_int()
-    pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
-
-    if rank == 0:
-        docs_total = D * world * args.steps
-        # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch: 8 B per nonzero
-        # (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in registers, the
-        # topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
-        # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
-        algo_bytes = 8.0 * nnz + 24.0 * K * D
-        span1 = (k_ms / max(n_launch, 1)) * 1e-3
+    span1 = (k_ms / max(n_launch, 1)) * 1e-3
+    if cfg["model"] == "lda":
+        # ... and once more with the (idempotent) kernel launched twice inside every span: the difference of the two spans is the
+        # kernel's own duration, without the ~4 us an event pair adds around a single launch (what rocprofv3 reports)
+        ctx.profile_begin(repeat=2)
+        steps(args.steps)
+        n_launch2, k_ms2 = ctx.profile_end()
+        ctx.profile_begin(repeat=1); ctx.profile_end()
         span2 = (k_ms2 / max(n_launch2, 1)) * 1e-3
         avg_s = span2 - span1 if span2 > span1 > 0 else span1
-        achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    else:
+        span2 = None
+        avg_s = span1        # a millisecond kernel: the ~4 us of the event pair are < 0.5 %
+
+    if rank == 0:
+        docs_step = (D * world) if args.scaling == "weak" else Dcfg
+        Dtot = docs_step
         res = {
-            "metric": "E-step docs/sec", "value": docs_total / dt, "unit": "docs/s", "n_gpus": world,
+            "metric": "E-step docs/sec", "value": docs_step * args.steps / dt, "unit": "docs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "LDA K=10 alpha=eta=0.1, %d docs x 96 SNV terms per GPU (BASELINE configs[1]), "
-                                   "nnz/GPU=%d, one EM iteration per step" % (D, nnz),
-                       "docs_per_gpu": D, "terms": V, "topics": K, "sharding": "docs x%d" % world,
-                       "allreduce": ctx.transport},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_lda_estep<10,16,false,96,true>", "launches": n_launch, "avg_us": avg_s * 1e6,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "event_span_1_launch_us": span1 * 1e6, "event_span_2_launches_us": span2 * 1e6,
-                         "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
-                                   "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"},
-            "ll_last": float(ll[0]),
+            "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3, "repeats": len(regions),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (cfg["name"] % Dcfg) + (" per GPU" if args.scaling == "weak" and world > 1 else "") +
+                                   ", nnz(rank 0)=%d, one EM iteration per step" % nnz,
+                       "docs_rank0": D, "docs_total": Dtot, "terms": V, "topics": K,
+                       "sharding": "docs x%d (%s)" % (world, args.scaling), "allreduce": ctx.transport},
         }
-        tp = os.path.join(ROOT, "profiles", "r01_traffic_lda_estep.json")
-        if world == 1 and D == 10000 and os.path.exists(tp):
+        if cfg["model"] == "lda":
+            ll = np.zeros(1); n = pkg._lib.C.c_int()
+            pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
+            res["ll_last"] = float(ll[0])
+            # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch: 8 B per nonzero
+            # (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in registers, the
+            # topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
+            # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
+            algo_bytes = 8.0 * nnz + 24.0 * K * D
+            achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_lda_estep", "launches": n_launch, "avg_us": avg_s * 1e6,
+                               "algorithmic_bytes_per_launch": algo_bytes,
+                               "event_span_1_launch_us": span1 * 1e6, "event_span_2_launches_us": span2 * 1e6,
+                               "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
+                                         "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"}
+            tname = "lda_estep"
+        else:
+            st = model.solver_stats()
+            MK, M = sum(K), len(K)
+            # dominant kernel: the solve phase k_ctm_estep<L,1,..> (update_ν! + update_λ!, the two LD_MMA solves per document).
+            # Algorithmic bytes per document: lambda, nu, sumtheta read + lambda, nu written (5 MK doubles), zeta and N_dm read (2 M
+            # doubles), two evaluation counters.  Useful f64 work per document, from the evaluation counts the kernel reports:
+            # a lambda evaluation = invSigma mat-vec (2 MK^2) + objective/gradient/MMA step algebra (~35 MK), a nu evaluation ~35 MK.
+            algo_bytes = ((5 * MK + 2 * M) * 8.0 + 8.0) * D
+            flops = st["n_eval_lambda"] * (2.0 * MK * MK + 35.0 * MK) + st["n_eval_nu"] * 35.0 * MK
+            achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+            tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "k_ctm_estep<L,1,...> (solve phase: update_nu! + update_lambda!)", "launches": n_launch, "avg_us": avg_s * 1e6,
+                               "algorithmic_bytes_per_launch": algo_bytes,
+                               "f64_valu": {"achieved": tf, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
+                                            "flops_per_launch": flops,
+                                            "model": "n_eval_lambda x (2 MK^2 + 35 MK) + n_eval_nu x 35 MK, evaluation counts of the last pass",
+                                            "mma_evaluations_per_document": (st["n_eval_nu"] + st["n_eval_lambda"]) / max(D, 1)},
+                               "timing": "HIP events on the library's stream around the kernel, inside a repeat of the timed K steps"}
+            res["n_capped"] = st["n_capped"]
+            tname = "ctm_solve_cfg%d" % args.config
+        tp = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tname)
+        if not os.path.exists(tp):
+            tp = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % tname)
+        if world == 1 and D == cfg["docs"] and os.path.exists(tp):
             tr = json.load(open(tp))
             res["roofline"]["traffic"] = tr["hbm_bytes_per_launch_gfx950_corrected"]
-            res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/r01_traffic_lda_estep.json"
+            res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + os.path.basename(tp)
         if world == 1:
-            res.update(parity_probe(pkg, K, alpha, eta, V, seed + 7))
+            if cfg["model"] == "lda":
+                res.update(parity_probe_lda(pkg, K, 0.1, 0.1, V, seed + 7))
+            else:
+                res.update(parity_probe_ctm(pkg, cfg, seed + 7))
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(X, lam0, K, alpha, eta)
+                res["cpu_baseline"] = cpu_baseline_lda(X, init, K, 0.1, 0.1) if cfg["model"] == "lda" else cpu_baseline_ctm(cfg, X, init)
                 res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
     model.close()

@@ -1243,6 +1243,7 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
         if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
     }
     if (flags & (F_NU | F_LAMBDA)) {
+        ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
         if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
     }
     return MMM_OK;
@@ -1434,7 +1435,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     // keep lambda_{t-1} and the exp table of this pass: theta_t is rebuilt from them on demand
     if ((rc = copy2_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK(), m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
     // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
-    { ProfSpan span(ctx); rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p); }
+    rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p);
     if (rc) return rc;
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
     const size_t r0 = sc.rep0;
@@ -1492,7 +1493,7 @@ int frozen_pass(mmm_ctm* m, Scope sc, int flags)
     const double* table = (flags & MMM_INFER_UNSMOOTHED) ? m->phieff.p : m->expEeff.p;
     if ((rc = copy_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK()))) return rc;
     if ((rc = copy_rep(m, sc, m->expEeff_prev.p, table, (size_t)dm.GT))) return rc;
-    { ProfSpan span(ctx); rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA, m->lambda.p, m->lambda.p, table); }
+    rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA, m->lambda.p, m->lambda.p, table);
     if (rc) return rc;
     if (flags & MMM_INFER_FIT_GAUSSIAN) {
         const size_t r0 = sc.rep0;

@@ -14,6 +14,7 @@
 #include "mmm_oracle.h"
 
 int orc_omp_threads(void) { return omp_get_max_threads(); }
+void orc_omp_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 /* one pass of the body of fit! (LDA.jl:201-209); returns the log-likelihood */
 double orc_lda_pass_omp(int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr, const int32_t* term,

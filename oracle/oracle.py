@@ -137,6 +137,7 @@ def lib_omp():
         build()
         L = C.CDLL(os.path.join(_HERE, "build", "libmmm_oracle_omp.so"))
         L.orc_omp_threads.restype = C.c_int
+        L.orc_omp_set_threads.argtypes = [C.c_int]
         L.orc_lda_pass_omp.restype = C.c_double
         L.orc_lda_pass_omp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i64p, i32p, i32p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
         _LIB_OMP = L
