@@ -1716,6 +1716,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     if ((rc = run_estep(m, sc, F_ZETA, m->lambda.p, nullptr, nullptr))) { delete m; return rc; }
     MMM_HIP(ctx, hipStreamSynchronize(st));
     *out = m;
+    mmm_ctx_model_created(ctx);
     return MMM_OK;
 }
 
@@ -1753,7 +1754,9 @@ int mmm_ctm_destroy(mmm_ctm* m)
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->pin_flags) (void)hipHostFree(m->pin_flags);
+    mmm_ctx* ctx = m->ctx;
     delete m;
+    mmm_ctx_model_destroyed(ctx);
     return MMM_OK;
 }
 

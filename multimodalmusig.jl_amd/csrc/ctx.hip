@@ -43,11 +43,12 @@ int mmm_ctx_create(int device_id, mmm_ctx** out)
 int mmm_ctx_destroy(mmm_ctx* ctx)
 {
     if (!ctx) return MMM_OK;
+    if (ctx->live_models > 0) { ctx->destroy_pending = true; return MMM_OK; }      // released by the last model's destroy
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // nothing in flight may still touch the pinned block or the events
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pin_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     mmm_p2p_release(ctx);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
@@ -142,3 +143,9 @@ void mmm_solver_opts_default(mmm_solver_opts* o)
 }
 
 } // extern "C"
+
+void mmm_ctx_model_created(mmm_ctx* ctx) { ++ctx->live_models; }
+void mmm_ctx_model_destroyed(mmm_ctx* ctx)
+{
+    if (--ctx->live_models <= 0 && ctx->destroy_pending) { ctx->destroy_pending = false; (void)mmm_ctx_destroy(ctx); }
+}

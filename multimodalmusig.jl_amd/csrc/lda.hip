@@ -33,6 +33,7 @@
 // k_lda_mstep: one wave per topic (receives the peers' statistics in rank order when folded): lambda = eta + sums,
 //   Elnbeta, exp table, beta (LDA.jl:96-112); an extra block finishes ll_{t-1}, applies the convergence test of
 //   common.jl:53-56 (device-side stop flag: later launches exit at once) and advances t.  ILDA: k_ilda_mstep instead.
+#include <memory>
 #include "dev_math.h"
 #include "mmm_internal.h"
 
@@ -514,7 +515,10 @@ __device__ void lda_reduce_block(const ReduceArgs& r)
     const int e = blockIdx.x * 16 + tx;
     double acc = 0.0;
     if (e < r.VK) for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
-    if (stop) return;
+    if (stop) {      // a no-op pass still keeps the mailbox rendezvous of its sequence number (p2p.hip header): element 0, value unused
+        if (r.p2p && blockIdx.x == 0 && tx == 0 && ty == 0) p2p_send(r.px, r.p2p_seq, 0, 0.0);
+        return;
+    }
     sm[ty][tx] = acc;
     __syncthreads();
     if (ty < 8) {
@@ -616,7 +620,10 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     const int e = rb * 16 + tx;
     double acc = 0.0;
     for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
-    if (stop) return;
+    if (stop) {      // a no-op pass still keeps the mailbox rendezvous of its sequence number (p2p.hip header): element 0, value unused
+        if (P2P && rb == 0 && tid == 0) { p2p_send(r.px, r.p2p_seq, 0, 0.0); (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0); }
+        return;
+    }
     sm[ty][tx] = acc;
     __syncthreads();
     if (ty < 8) {
@@ -733,6 +740,7 @@ __global__ __launch_bounds__(128) void k_lda_mstep(ReduceArgs r, int V, double e
     double* sums = r.stats + (size_t)k * V;
     if (P2P && r.p2p) {             // all-reduce folded in: own statistics + the peers', summed in rank order, written back for the passes below
         if (!stop) for (int v = tid; v < V; v += 128) sums[v] = p2p_recv_sum(r.px, r.p2p_seq, k * V + v, sums[v]);
+        else if (k == 0 && tid == 0) (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0);      // no-op pass: the rendezvous of lda_reduce_block's dummy send
         __syncthreads();
     }
     // both waves form the column sum (same loads, same order: same bits, and no barrier); each then takes every other 64 entries
@@ -1333,6 +1341,7 @@ struct mmm_lda {
     bool ll_pending = false;    // the ll of pass t has not been recorded yet
     bool theta_valid = false;
     bool attr_e[2] = {false, false}, attr_m = false, attr_mm[3] = {false, false, false};
+    int cap_mm[3] = {-1, -1, -1}, cap_m = -1;      // blocks of the reduce / merged launches that can be resident together (residency_cap)
     DevBuf<unsigned long long> cells;   // k_lda_reduce_ll_mstep: [2 * (512 + 512)] exchange cells
     DevBuf<unsigned long long> fcells;  // ILDA: [2 * 512 * 16] fold cells
     unsigned int kseq = 0;              // sequence number of its launches
@@ -1386,6 +1395,19 @@ template <typename Kern>
 int set_lds(mmm_ctx* ctx, Kern kern, size_t lds)
 {
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return MMM_OK;
+}
+
+// How many blocks of a launch whose blocks WAIT for each other (cells) can be resident at once: occupancy x CUs.  Launches of
+// k_lda_reduce_ll_mstep / k_lda_reduce_ll never exceed it, so every block a waiting block waits for is on the chip -- the waits
+// cannot deadlock whatever order the dispatcher picks.  MMM_LDA_RESIDENT_CAP lowers the figure (tests).
+template <class Kern>
+int residency_cap(mmm_ctx* ctx, Kern kern, size_t lds, int* cap)
+{
+    int nb = 0;
+    MMM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 1024, lds));
+    *cap = nb * ctx->num_cu;
+    if (const char* e = getenv("MMM_LDA_RESIDENT_CAP")) *cap = std::min(*cap, std::max(0, atoi(e)));
     return MMM_OK;
 }
 
@@ -1584,13 +1606,43 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         // V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep), statistics
         // rows padded to a multiple of 16; MMM_LDA_MERGE=0 keeps the split kernels (A/B)
         static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
-        const bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
-                            (!m->ilda || (m->ids.SJ <= 16 && !mmm_comm_active(ctx)));
+        bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
+                      (!m->ilda || (m->ids.SJ <= 16 && !mmm_comm_active(ctx)));
+        const size_t lds_red = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+        int cap = 0;       // residency of the launch whose blocks wait for each other
+        if (merged) {
+            const int ai = m->ilda ? 2 : r.p2p;
+            if (m->cap_mm[ai] < 0) {
+                MMM_KP_SWITCH(m, {
+                    auto k = m->ilda ? k_lda_reduce_ll_mstep<KPV, false, true> : (r.p2p ? k_lda_reduce_ll_mstep<KPV, true, false> : k_lda_reduce_ll_mstep<KPV, false, false>);
+                    if (!m->attr_mm[ai]) { if ((rc = set_lds(ctx, k, lds_red))) return rc; m->attr_mm[ai] = true; }
+                    if ((rc = residency_cap(ctx, k, lds_red, &m->cap_mm[ai]))) return rc;
+                })
+            }
+            cap = m->cap_mm[ai];
+            // every reduce block waits for the blocks of its topic, wave 1 of block 0 for the ll blocks: all of them must fit
+            if (cap < (Vp * m->K + 15) / 16 + 1) merged = false;
+        }
         if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
         r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
+        if (!merged && via_cells && r.n_ll > 0) {      // RCCL transport: wave 1 of reduce block 0 waits for the ll blocks' cells
+            if (m->cap_m < 0) {
+                MMM_KP_SWITCH(m, {
+                    auto k = k_lda_reduce_ll<KPV>;
+                    if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds_red))) return rc; m->attr_m = true; }
+                    if ((rc = residency_cap(ctx, k, lds_red, &m->cap_m))) return rc;
+                })
+            }
+            cap = m->cap_m;
+        }
+        if (r.n_ll > 0 && (merged || via_cells)) {
+            const int nred_ = (r.VK + 15) / 16;
+            if (cap - nred_ < 1) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: the reduce launch cannot hold its %d reduce blocks and one ll block at once (%d resident)", nred_, cap);
+            r.n_ll = std::min(r.n_ll, cap - nred_);       // the ll blocks stride over the documents: fewer blocks, same sums per block id
+        }
         EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
@@ -1602,7 +1654,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (rc) return rc;
         const int nred = (r.VK + 15) / 16;
         if (merged) {
-            const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+            const size_t lds = lds_red;
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
             const int c3 = t % 3;
             IldaMerge im{};
@@ -1795,7 +1847,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const bool wide = lds_for(waves) > 160 * 1024 || (wide_env ? atoi(wide_env) != 0 : KP >= 32);
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
-    mmm_lda* m = new mmm_lda();
+    std::unique_ptr<mmm_lda> guard(new mmm_lda());      // every early return below (MMM_HIP, ...) destroys the model and its buffers
+    mmm_lda* m = guard.get();
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
     m->waves_e = waves; m->lds_e = wide ? 0 : lds_for(waves); m->lds_tab = tabB; m->wide = wide;
     if (const char* s = wide ? nullptr : getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
@@ -1809,7 +1862,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
-#define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); delete m; return rc; } } while (0)
+#define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); return rc; } } while (0)
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
     for (int i = 0; i < 3; ++i) { A(lambda[i], VK); A(Elnbeta[i], VK); A(expElnbeta[i], VK); A(beta[i], VK); A(gamma[i], KD); A(Elntheta[i], KD); }
     A(theta, KD); A(phi, (size_t)K * nnz);
@@ -1836,7 +1889,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         for (int d = 0; d < D; ++d)
             for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) tpost[(size_t)fill[(size_t)term[e]]++] = make_int2(d, count[e]);
         hipError_t e1 = m->term_ptr.alloc((size_t)V + 1), e2 = m->tpost.alloc((size_t)nnz), e3 = m->aexp.alloc((size_t)KP * D), e4 = m->tabT.alloc((size_t)2 * V * KP);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); delete m; return rc; }
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(postings): out of memory"); return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(m->term_ptr.p, tptr.data(), sizeof(int64_t) * ((size_t)V + 1), hipMemcpyHostToDevice, st));
         if (nnz) MMM_HIP(ctx, hipMemcpyAsync(m->tpost.p, tpost.data(), sizeof(int2) * (size_t)nnz, hipMemcpyHostToDevice, st));
         // waves per term block: segments of >= 128 postings on average, at most 8
@@ -1853,7 +1906,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
             for (int d = 0; d < D; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
             hipError_t e_ = m->tc_ell.alloc(ell.size());
-            if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(tc_ell): %s", hipGetErrorString(e_)); delete m; return rc; }
+            if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(tc_ell): %s", hipGetErrorString(e_)); return rc; }
             MMM_HIP(ctx, hipMemcpyAsync(m->tc_ell.p, ell.data(), sizeof(int2) * ell.size(), hipMemcpyHostToDevice, st));
         }
     }
@@ -1894,13 +1947,14 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if (mmm_comm_active(ctx)) {
         MMM_HIP(ctx, hipMemcpyAsync(ncount, hd, sizeof hd, hipMemcpyHostToDevice, st));
         int rc = mmm_allreduce_sum(ctx, ncount, 2);
-        if (rc) { delete m; return rc; }
+        if (rc) { return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(hd, ncount, sizeof hd, hipMemcpyDeviceToHost, st));
         MMM_HIP(ctx, hipStreamSynchronize(st));
     }
     m->Nglobal = hd[0]; m->Dglobal = hd[1];
     m->phi_valid = true; m->phi_from_prev = false; m->gnext_valid = false; m->ll_pending = false; m->theta_valid = false;
-    *out = m;
+    *out = guard.release();
+    mmm_ctx_model_created(ctx);
     return MMM_OK;
 }
 
@@ -1923,7 +1977,9 @@ int mmm_lda_destroy(mmm_lda* m)
     if (!m) return MMM_OK;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    mmm_ctx* ctx = m->ctx;
     delete m;
+    mmm_ctx_model_destroyed(ctx);
     return MMM_OK;
 }
 

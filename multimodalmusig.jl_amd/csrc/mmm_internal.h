@@ -36,7 +36,15 @@ struct mmm_ctx {
     // can look at chunk i's stop flag while chunk i+1 is already running (lazily created)
     void* pin_ctl = nullptr;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    // models created on this context and still alive.  mmm_ctx_destroy with live models only marks the context; the last
+    // mmm_*_destroy then releases it -- a garbage-collected host (Julia finalizers run in no particular order) may destroy
+    // the context before its models without a use-after-free.
+    int live_models = 0;
+    bool destroy_pending = false;
 };
+
+void mmm_ctx_model_created(mmm_ctx* ctx);
+void mmm_ctx_model_destroyed(mmm_ctx* ctx);      // may delete ctx
 
 // RAII span: records an event pair around a launch while profiling is on
 struct ProfSpan {

@@ -11,6 +11,10 @@
 // transactions of two 8-byte ones); should the fabric split it, the reader simply sees mismatching tags for a moment.  seq is a per-context call counter (identical on all ranks, which
 // issue the same calls in the same order); slot = seq & 1 suffices because a rank cannot start call s+2 before every rank
 // has finished reading call s (it needs their s+1 contributions, which they send after their call-s kernel has ended).
+// That argument needs EVERY sequence number to be a real exchange.  The LDA kernels that fold the exchange into their own
+// work skip it on the no-op passes after the device-side stopping rule has fired (the host has already counted those launches):
+// they still send and receive element 0 of that sequence number (value unused), so no rank can run ahead through skipped numbers
+// and overwrite a slot a lagging peer is still reading (lda.hip: lda_reduce_block, k_lda_mstep, k_lda_reduce_ll_mstep).
 // Every poll loop has a wall-clock exit (default 20 s): on expiry the kernel records the failure and ends, and the next
 // host synchronisation point reports it -- a lost peer cannot hang the GPU.
 //
@@ -230,35 +234,39 @@ int mmm_p2p_setup_over_rccl(mmm_ctx* ctx)
     if (ctx->nranks > kP2PMaxRanks || (ctx->nranks < 2 && !getenv("MMM_P2P_ONE_RANK"))) return MMM_OK;
     if (const char* s = getenv("MMM_P2P")) if (atoi(s) == 0) return MMM_OK;
     const int n = ctx->nranks;
-    char mine[MMM_P2P_HANDLE_BYTES];
-    int ok_local = 1;
-    int rc = mmm_p2p_local_handle(ctx, n, mine);
-    if (rc) ok_local = 0;
+    // Every rank goes through the SAME sequence of collectives (all-gather, min, min) whatever fails locally: a local failure
+    // only lowers ok_local.  The buffers of all three exist before the first collective, so an allocation failure cannot
+    // leave the peers inside RCCL alone -- it is the one error returned before anything communicates.
     DevBuf<char> send, recv;
-    MMM_HIP(ctx, send.alloc(MMM_P2P_HANDLE_BYTES)); MMM_HIP(ctx, recv.alloc((size_t)n * MMM_P2P_HANDLE_BYTES));
-    MMM_HIP(ctx, hipMemcpyAsync(send.p, mine, MMM_P2P_HANDLE_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    MMM_NCCL(ctx, ncclAllGather(send.p, recv.p, MMM_P2P_HANDLE_BYTES, ncclChar, ctx->comm, ctx->stream));
-    std::vector<char> all((size_t)n * MMM_P2P_HANDLE_BYTES);
-    MMM_HIP(ctx, hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, ctx->stream));
-    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ok_local && mmm_p2p_attach(ctx, n, ctx->rank, all.data()) != MMM_OK) ok_local = 0;
-    // unanimous decision no. 1: everybody attached?  (a rank that could not must not leave the others polling)
     DevBuf<double> flag;
-    MMM_HIP(ctx, flag.alloc(1));
+    MMM_HIP(ctx, send.alloc(MMM_P2P_HANDLE_BYTES)); MMM_HIP(ctx, recv.alloc((size_t)n * MMM_P2P_HANDLE_BYTES)); MMM_HIP(ctx, flag.alloc(1));
+    char mine[MMM_P2P_HANDLE_BYTES] = {0};
+    int ok_local = 1;
+    if (mmm_p2p_local_handle(ctx, n, mine) != MMM_OK) { ok_local = 0; memset(mine, 0, sizeof mine); }
+    std::vector<char> all((size_t)n * MMM_P2P_HANDLE_BYTES, 0);
+    if (hipMemcpyAsync(send.p, mine, MMM_P2P_HANDLE_BYTES, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ok_local = 0;
+    MMM_NCCL(ctx, ncclAllGather(send.p, recv.p, MMM_P2P_HANDLE_BYTES, ncclChar, ctx->comm, ctx->stream));
+    if (hipMemcpyAsync(all.data(), recv.p, all.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ok_local = 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) ok_local = 0;
+    if (ok_local && mmm_p2p_attach(ctx, n, ctx->rank, all.data()) != MMM_OK) ok_local = 0;
+    // unanimous decisions: the copies around the min-reduction may fail locally (-> vote 0 / read 0), the collective itself is
+    // always issued; an RCCL error is fatal for the communicator anyway and is the only early return
     auto agree = [&](int v, int* out) -> int {
         double d = v;
-        MMM_HIP(ctx, hipMemcpyAsync(flag.p, &d, sizeof d, hipMemcpyHostToDevice, ctx->stream));
+        if (hipMemcpyAsync(flag.p, &d, sizeof d, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) (void)hipMemsetAsync(flag.p, 0, sizeof d, ctx->stream);
         MMM_NCCL(ctx, ncclAllReduce(flag.p, flag.p, 1, ncclDouble, ncclMin, ctx->comm, ctx->stream));
-        MMM_HIP(ctx, hipMemcpyAsync(&d, flag.p, sizeof d, hipMemcpyDeviceToHost, ctx->stream));
-        MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        d = 0.0;
+        if (hipMemcpyAsync(&d, flag.p, sizeof d, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) d = 0.0;
         *out = d > 0.5 ? 1 : 0;
         return MMM_OK;
     };
-    int all_ok = 0;
+    int all_ok = 0, rc;
+    // no. 1: everybody attached?  (a rank that could not must not leave the others polling)
     if ((rc = agree(ok_local, &all_ok))) return rc;
     if (!all_ok) { mmm_p2p_release(ctx); ctx->err.clear(); return MMM_OK; }
+    // no. 2: everybody passed the rehearsal?
     bool good = false;
-    if ((rc = p2p_selftest(ctx, &good))) good = false;
+    if (p2p_selftest(ctx, &good) != MMM_OK) good = false;
     if ((rc = agree(good ? 1 : 0, &all_ok))) return rc;
     if (!all_ok) { ctx->p2p_on = false; ctx->err.clear(); }
     return MMM_OK;

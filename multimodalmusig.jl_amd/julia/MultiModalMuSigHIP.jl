@@ -16,7 +16,7 @@ module MultiModalMuSigHIP
 
 using DataFrames
 
-export IMMCTM, MMCTM, LDA, fit!, format_counts_lda, format_counts_ctm, format_counts_mmctm
+export IMMCTM, MMCTM, ILDA, LDA, fit!, format_counts_lda, format_counts_ctm, format_counts_mmctm
 
 const LIB = get(ENV, "MMM_LIB_PATH", joinpath(@__DIR__, "..", "lib", "libmmmusig_hip.so"))
 

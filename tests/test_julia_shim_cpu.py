@@ -1,0 +1,159 @@
+"""Static check of the Julia shim (multimodalmusig.jl_amd/julia/MultiModalMuSigHIP.jl) against include/mmmusig.h.
+
+Julia is absent from the build container and the GPU boxes, so the shim cannot be executed; what can be verified is that every
+`ccall((:mmm_..., LIB), Ret, (ArgTypes...), args...)` names a function the header declares, with the same number of
+arguments, the same C type for each (Cint <-> int, Cdouble <-> double, Csize_t <-> size_t, Ptr/Ref{T} <-> T*, Cstring <->
+const char*), the same return type, and as many values as types.  The reference side of the boundary these calls replace:
+MultiModalMuSig.jl:9 (exports), LDA.jl:198, MMCTM.jl:457-458, IMMCTM.jl:437 (fit!)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "multimodalmusig.jl_amd", "julia", "MultiModalMuSigHIP.jl")
+HDR = os.path.join(ROOT, "include", "mmmusig.h")
+
+
+def _split_top(s):
+    """split at top-level commas"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _balanced(text, i):
+    """text[i] == '(' -> index just past its matching ')'"""
+    depth = 0
+    for j in range(i, len(text)):
+        if text[j] == "(":
+            depth += 1
+        elif text[j] == ")":
+            depth -= 1
+            if depth == 0:
+                return j + 1
+    raise ValueError("unbalanced")
+
+
+def header_prototypes():
+    txt = open(HDR).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    protos = {}
+    for m in re.finditer(r"\b((?:const\s+)?[A-Za-z_][A-Za-z_0-9]*\s*\**)\s*\b(mmm_[a-z_A-Z0-9]+)\s*\(", txt):
+        ret, name = m.group(1).strip(), m.group(2)
+        end = _balanced(txt, m.end() - 1)
+        if not txt[end:].lstrip().startswith(";"):
+            continue
+        params = txt[m.end():end - 1].strip()
+        args = [] if params in ("", "void") else _split_top(params)
+        protos[name] = (ctype(ret), [ctype(a) for a in args])
+    return protos
+
+
+def ctype(decl):
+    """C declaration -> category"""
+    d = decl.strip()
+    if "*" in d or "[" in d:
+        base = re.sub(r"\bconst\b", "", d.split("*")[0].split("[")[0]).split()
+        base = base[0] if base else "void"
+        if d.count("*") >= 2:
+            return "ptr:ptr"
+        if "[" in d:                # `double terms[7]`, `char out[64]`, `int out[8]`
+            base = re.sub(r"\bconst\b", "", d.split("[")[0]).split()[0]
+        return "ptr:" + {"mmm_ctx": "void", "mmm_lda": "void", "mmm_ctm": "void", "void": "void", "char": "char", "double": "double", "int": "int",
+                         "int32_t": "int32", "int64_t": "int64", "mmm_solver_opts": "void", "size_t": "size_t"}.get(base, base)
+    toks = re.sub(r"\bconst\b", "", d).split()
+    t = toks[0]
+    return {"int": "int", "double": "double", "size_t": "size_t", "void": "void", "int64_t": "int64"}.get(t, t)
+
+
+def jtype(t):
+    t = t.strip()
+    simple = {"Cint": "int", "Cdouble": "double", "Csize_t": "size_t", "Cstring": "ptr:char", "Cvoid": "void", "Int32": "int32", "Int64": "int64"}
+    if t in simple:
+        return simple[t]
+    m = re.fullmatch(r"(Ptr|Ref)\{(.+)\}", t)
+    assert m, "unknown Julia C type %r" % t
+    inner = m.group(2).strip()
+    if inner.startswith(("Ptr{", "Ref{")):
+        return "ptr:ptr"
+    return "ptr:" + {"Cvoid": "void", "Cdouble": "double", "Cint": "int", "Int32": "int32", "Int64": "int64", "UInt8": "char", "Cchar": "char",
+                     "SolverOpts": "void"}.get(inner, inner)
+
+
+def shim_ccalls():
+    txt = open(SHIM).read()
+    txt = re.sub(r"#[^\n]*", "", txt)
+    calls = []
+    for m in re.finditer(r"ccall\s*\(", txt):
+        end = _balanced(txt, m.end() - 1)
+        parts = _split_top(txt[m.end():end - 1])
+        fm = re.fullmatch(r"\(\s*:(mmm_[a-z_A-Z0-9]+)\s*,\s*LIB\s*\)", parts[0])
+        assert fm, "ccall target not of the form (:mmm_x, LIB): %r" % parts[0]
+        name, ret = fm.group(1), jtype(parts[1])
+        tt = parts[2].strip()
+        assert tt.startswith("(") and tt.endswith(")")
+        types = [jtype(x) for x in _split_top(tt[1:-1]) if x.strip()]
+        calls.append((name, ret, types, len(parts) - 3, txt.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def _compatible(j, c):
+    if j == c:
+        return True
+    # handles are opaque on the Julia side; a char* handle buffer may be passed as bytes; void* accepts any pointer
+    if j.startswith("ptr:") and c.startswith("ptr:") and ("void" in (j[4:], c[4:])):
+        return True
+    return False
+
+
+def test_every_ccall_matches_its_prototype():
+    protos = header_prototypes()
+    assert len(protos) >= 60 and "mmm_ctm_fit" in protos and protos["mmm_lda_get"] == ("int", ["ptr:void", "int", "ptr:double", "size_t"])
+    calls = shim_ccalls()
+    assert len(calls) >= 25
+    bad = []
+    for name, ret, types, nvals, line in calls:
+        if name not in protos:
+            bad.append("line %d: %s is not declared in include/mmmusig.h" % (line, name)); continue
+        cret, cargs = protos[name]
+        if not _compatible(ret, cret):
+            bad.append("line %d: %s returns %s, the shim says %s" % (line, name, cret, ret))
+        if len(types) != len(cargs):
+            bad.append("line %d: %s takes %d arguments, the shim passes %d types" % (line, name, len(cargs), len(types))); continue
+        if nvals != len(types):
+            bad.append("line %d: %s: %d argument types but %d values" % (line, name, len(types), nvals))
+        for i, (j, c) in enumerate(zip(types, cargs)):
+            if not _compatible(j, c):
+                bad.append("line %d: %s argument %d is %s in the header, %s in the shim" % (line, name, i + 1, c, j))
+    assert not bad, "\n".join(bad)
+
+
+def test_shim_keeps_the_reference_api_surface():
+    """exports of MultiModalMuSig.jl:9 plus the fit! keyword arguments of LDA.jl:198, MMCTM.jl:457-458, IMMCTM.jl:437"""
+    txt = open(SHIM).read()
+    exp = re.search(r"^export\s+(.+)$", txt, flags=re.M)
+    assert exp
+    names = {n.strip() for n in exp.group(1).split(",")}
+    assert {"LDA", "MMCTM", "IMMCTM", "ILDA", "fit!"} <= names
+    assert re.search(r"function fit!\(model::LDA; maxiter=1000, tol=1e-4, verbose=true\)", txt)
+    assert re.search(r"function fit!\(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true\)", txt)
+    assert re.search(r"function fit!\(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false\)", txt)
+
+
+def test_python_binding_table_matches_the_header(mmm):
+    """the executable binding (multimodalmusig.jl_amd/_lib.py) declares the same arities as the header"""
+    protos = header_prototypes()
+    sigs = mmm._lib._SIGS
+    assert set(sigs) == set(protos)
+    for name, (ret, args) in sigs.items():
+        assert len(args) == len(protos[name][1]), "%s: _SIGS has %d arguments, the header %d" % (name, len(args), len(protos[name][1]))

@@ -207,3 +207,36 @@ def test_large_corpus_grid_stride_paths(mmm, oracle):
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
     np.testing.assert_allclose(g.λ, o.lam.reshape(96, 10, order="F"), rtol=1e-9)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+
+
+@pytest.mark.parametrize("cap", [61, 64, 100, 30])
+def test_merged_launch_never_exceeds_residency(mmm, oracle, cap, monkeypatch):
+    """The reduce + ll + M-step launch has blocks that wait for each other (16-byte cells).  The library launches it only with as
+    many blocks as can be resident at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs; here lowered through
+    MMM_LDA_RESIDENT_CAP): the ll blocks are cut to what fits (cap 61 / 64 / 100: 60 reduce blocks + 1 / 4 / 40 ll blocks for
+    20,000 documents, which would take 313), or the split kernels run (cap 30 < 60 reduce blocks).  Either way: the oracle's
+    results, no wait_timeout."""
+    monkeypatch.setenv("MMM_LDA_RESIDENT_CAP", str(cap))
+    X, g, o = _pair(mmm, oracle, 20000, 96, 10, seed=78, mean_n=120)
+    ll_g = mmm.fit(g, maxiter=14, tol=0.0, verbose=False)        # raises MmmError on a device-side wait time-out
+    ll_o = o.fit(maxiter=14, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(96, 10, order="F"), rtol=1e-9)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+
+
+def test_context_may_be_destroyed_before_its_models(mmm):
+    """A garbage-collected host runs finalizers in no particular order (the Julia shim registers one per object): destroying the
+    context first only marks it; the last model's destroy releases it."""
+    X, lam0 = np_ref.synth_lda(50, 96, 10, seed=3, mean_n=300)
+    ctx = mmm.Context(0)
+    a = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0, ctx=ctx)
+    b = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0, ctx=ctx)
+    L = mmm.lib()
+    assert L.mmm_ctx_destroy(ctx.h) == 0          # deferred: two models alive
+    ll = mmm.fit(a, maxiter=3, tol=0.0, verbose=False)   # the context still works
+    assert np.all(np.isfinite(ll))
+    ha, hb = a._h, b._h
+    a._h = mmm._lib.C.c_void_p(); b._h = mmm._lib.C.c_void_p(); ctx.h = mmm._lib.C.c_void_p()     # the Python objects must not destroy again
+    assert L.mmm_lda_destroy(ha) == 0
+    assert L.mmm_lda_destroy(hb) == 0             # releases the context
