@@ -172,8 +172,10 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
             inner_done = gval >= fcur;
             if (fcur < fbest) { fbest = fcur; x = xc; grad = gcur; }
             if (nev >= cap) { done = true; capped = true; inner_done = false; }
-            else if (!inner_done && fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval)));
         }
+        // rho grows only in a group whose approximation was not conservative; the division is skipped while no group of the wave needs it
+        const bool grow = !done && !inner_done && fcur > gval;
+        if (__any(grow)) { const double rn = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval))); rho = grow ? rn : rho; }
         // outer iteration finished in at least one group of this wave: NLopt's x-tolerance test on (xcur, xprev)
         if (__any(inner_done)) {
             const double ad = fabs(xcur - xprev);

@@ -145,9 +145,12 @@ __device__ __forceinline__ double wave_readlane(double v, int lane)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v)
 {
+    // bound_ctrl = 1 and no `old` operand: every control used here (quad_perm, row_half_mirror, row_mirror) has a source lane for
+    // every lane, and without an `old` value the compiler emits the bare v_mov_b32_dpp pair (with old = src it copies the
+    // register first: two extra VALU instructions per stage, 8 per 16-lane sum -- measured in the f64-VALU-bound solve kernel)
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
