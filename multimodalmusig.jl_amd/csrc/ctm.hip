@@ -77,17 +77,89 @@ __device__ __forceinline__ bool group_none(bool pred, int g)
     return (b & mask) == 0ull;
 }
 
+// ---- packed document groups (solve phase, sum K not a divisor of 64): LP = sum K lanes per document, floor(64 / LP) documents per
+// wave instead of 64 / 16 -- sum K = 10 (BASELINE config 5): 6 documents per wave instead of 4.  Groups straddle the 16-lane DPP
+// rows, so the group sum goes through the LDS crossbar (ds_bpermute, no VALU slot -- the solve phase is f64-VALU bound): a tree
+// that folds lane l+off onto lane l for off = 8, 4, 2, 1 and broadcasts lane 0's total.  Lanes without a partner read a spare lane
+// of the wave (64 % LP of them exist) whose value is 0 at every stage.
+struct PackCtx { int a[5]; };       // byte addresses (lane * 4) of the partner per stage [8, 4, 2, 1] and of the group's lane 0
+
+template <int LP>
+__device__ __forceinline__ PackCtx pack_ctx(int lane)
+{
+    constexpr int G = MMM_WAVE / LP;
+    static_assert(G * LP < MMM_WAVE, "packed groups need a spare lane");
+    const int g = lane / LP, l = lane % LP;
+    const bool in = g < G;
+    PackCtx c;
+    const int offs[4] = {8, 4, 2, 1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.a[q] = 4 * ((in && l < offs[q] && l + offs[q] < LP) ? lane + offs[q] : MMM_WAVE - 1);
+    c.a[4] = 4 * (in ? g * LP : MMM_WAVE - 1);
+    return c;
+}
+
+__device__ __forceinline__ double bperm_f64(int addr, double v)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// v must be 0 in the spare lanes
+template <int LP>
+__device__ __forceinline__ double packed_sum(const PackCtx& c, double v)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if ((8 >> q) < LP) v += bperm_f64(c.a[q], v);
+    return bperm_f64(c.a[4], v);
+}
+
+// two independent sums through the same stages: their LDS round trips overlap (the packed path is bound by that latency)
+template <int LP>
+__device__ __forceinline__ void packed_sum2(const PackCtx& c, double& v, double& w)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if ((8 >> q) < LP) { const double pv = bperm_f64(c.a[q], v), pw = bperm_f64(c.a[q], w); v += pv; w += pw; }
+    const double tv = bperm_f64(c.a[4], v), tw = bperm_f64(c.a[4], w);
+    v = tv; w = tw;
+}
+
+template <int L, int LP>
+__device__ __forceinline__ void gsum2(const PackCtx& c, double& v, double& w)
+{
+    if constexpr (LP > 0) packed_sum2<LP>(c, v, w);
+    else { v = group_sum<L>(v); w = group_sum<L>(w); }
+}
+
+// sum over the caller's document group: L-lane DPP rows (LP = 0) or packed LP-lane groups
+template <int L, int LP>
+__device__ __forceinline__ double gsum(const PackCtx& c, double v)
+{
+    if constexpr (LP > 0) return packed_sum<LP>(c, v);
+    else return group_sum<L>(v);
+}
+
+template <int L, int LP>
+__device__ __forceinline__ bool gnone(bool pred, int g)
+{
+    if constexpr (LP > 0) {
+        const unsigned long long b = __ballot(pred);
+        return (b & (((1ull << LP) - 1ull) << (g * LP))) == 0ull;
+    } else return group_none<L>(pred, g);
+}
+
 // ---- objectives in NLopt's minimisation form (common.jl:11-36 negated) ----------------------------------------------
 // nu: f = 1/2 sum nu_i S_ii + sum c_i exp(lambda_i + nu_i/2) - 1/2 sum log nu_i
 struct NuObj {
     double lam, c, Sll; bool act;
-    template <int L>
-    __device__ __forceinline__ double eval(double x, double& g) const
+    template <int L, int LP = 0>
+    __device__ __forceinline__ double eval(double x, double& g, const PackCtx& pc = PackCtx{}) const
     {
         const double E = ar_exp(lam + 0.5 * x);
         g = act ? 0.5 * Sll + 0.5 * c * E - dev_div(1.0, 2.0 * x) : 0.0;
         const double t = act ? 0.5 * x * Sll + c * E - 0.5 * ar_log(x) : 0.0;
-        return group_sum<L>(t);
+        return gsum<L, LP>(pc, t);
     }
 };
 
@@ -97,8 +169,8 @@ struct LamObj {
     double nu, c, sumth, mu; bool act; int l, MK;
     const double* sS;     // [j*MK + i], symmetric
     double* scr;          // group-private LDS, >= MK doubles
-    template <int L>
-    __device__ __forceinline__ double eval(double x, double& g) const
+    template <int L, int LP = 0>
+    __device__ __forceinline__ double eval(double x, double& g, const PackCtx& pc = PackCtx{}) const
     {
         const double diff = act ? x - mu : 0.0;
         lds_wave_sync();
@@ -129,19 +201,19 @@ struct LamObj {
         const double E = ar_exp(x + 0.5 * nu);
         g = act ? Sd - sumth + c * E : 0.0;
         const double t = act ? 0.5 * diff * Sd - x * sumth + c * E : 0.0;
-        return group_sum<L>(t);
+        return gsum<L, LP>(pc, t);
     }
 };
 
 // NLopt LD_MMA, zero constraints, for the L-lane group of the calling lane (lane l holds coordinate l).  All lanes of the
 // wave execute every trip; a finished group keeps its state through selects.  Returns the number of objective
 // evaluations (negative: the evaluation cap was hit).
-template <int L, class Obj>
-__device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb, double lb, const SolveOpts& o)
+template <int L, int LP, class Obj>
+__device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb, double lb, const SolveOpts& o, const PackCtx& pc)
 {
     double sigma = 1.0, rho = 1.0;
     double gcur, grad;
-    double fbest = obj.template eval<L>(x, grad);
+    double fbest = obj.template eval<L, LP>(x, grad, pc);
     double xcur = x, xprev = x, xprevprev = x;
     int k = 1, nev = 1;
     bool done = false, capped = false;
@@ -162,9 +234,10 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         const double denominv = dev_div(1.0, sigma2 - dx2);
         const double gl = act ? (grad * (sigma2 * dx) + (fabs(grad) * sigma + 0.5 * rho) * dx2) * denominv : 0.0;
         const double wl = act ? 0.5 * dx2 * denominv : 0.0;
-        const double gval = fbest + group_sum<L>(gl);
-        const double wval = group_sum<L>(wl);
-        const double fcur = obj.template eval<L>(xc, gcur);
+        double gsm = gl, wval = wl;
+        gsum2<L, LP>(pc, gsm, wval);
+        const double gval = fbest + gsm;
+        const double fcur = obj.template eval<L, LP>(xc, gcur, pc);
         bool inner_done = false;
         if (!done) {
             ++nev;
@@ -181,13 +254,14 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
             const double ad = fabs(xcur - xprev);
             bool stop;
             if (o.xtol_rule == 0) {
-                const double dn = group_sum<L>(act ? ad : 0.0), xn = group_sum<L>(act ? fabs(xcur) : 0.0);
-                stop = (dn < o.xtol_rel * xn) || group_none<L>(act && !(ad < o.xtol_abs), g);
+                double dn = act ? ad : 0.0, xn = act ? fabs(xcur) : 0.0;
+                gsum2<L, LP>(pc, dn, xn);
+                stop = (dn < o.xtol_rel * xn) || gnone<L, LP>(act && !(ad < o.xtol_abs), g);
             } else {
                 const bool ok = isinf(xprev) ? false
                                               : (ad < o.xtol_abs || ad < o.xtol_rel * (fabs(xcur) + fabs(xprev)) * 0.5 ||
                                                  (o.xtol_rel > 0 && xcur == xprev));
-                stop = group_none<L>(act && !ok, g);
+                stop = gnone<L, LP>(act && !ok, g);
             }
             if (inner_done) {
                 if (stop) done = true;
@@ -228,11 +302,15 @@ struct CtmEArgs {
 // WIDE (theta phase): topic tables too large for LDS (a 1536-term modality, ...): the table is read through L2, no slabs --
 // the gamma statistics come from k_ctm_stats_terms, a term-major sweep over posting lists that evaluates theta_kw again from
 // the exp(lambda - max) rows this phase leaves in `aexp` (the scheme of the LDA wide path, lda.hip)
-template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false>
+// PACK (solve phase, MKT = sum K with 64 % MKT != 0): MKT lanes per document instead of L (packed_sum above)
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false, bool PACK = false>
 __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int G = MMM_WAVE / L;
+    static_assert(!PACK || (PH == 1 && MKT > 0 && MMM_WAVE % MKT != 0), "packed groups: solve phase with compile-time sum K");
+    constexpr int LG = PACK ? MKT : L;          // lanes per document group
+    constexpr int LP = PACK ? MKT : 0;
+    constexpr int G = MMM_WAVE / LG;
     const CtmDims& dm = a.c.dm;
     const int MK = MKT ? MKT : dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
     // replica r = blockIdx.y of a batched launch works on the r-th copy of every per-model array.  The kernel arguments are
@@ -252,13 +330,17 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     int* p_nev_lam = a.nev_lam ? a.nev_lam + rep * D : nullptr;
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane / L, l = lane % L;
+    const int g = lane / LG, l = lane % LG;
+    const bool ingrp = g < G;                          // packed groups leave 64 % MKT spare lanes
+    PackCtx pc{};
+    if constexpr (PACK) pc = pack_ctx<MKT>(lane);
     const int flags = a.flags;
     // PH 1: [MK*MK invSigma | MK mu | scratch];  PH 0: [scratch | GT table | NW*GT slabs]
-    double* sScr = smem;                               // [NW][G][2L]
-    double* sS = sScr + (size_t)NW * G * 2 * L;        // [MK*MK]   (PH 1)
+    constexpr int SCRW = PACK ? (G + 1) * 2 * LG : 2 * MMM_WAVE;      // scratch doubles per wave: [G][2 LG] (+ one dummy group for the spare lanes)
+    double* sScr = smem;                               // [NW][SCRW]
+    double* sS = sScr + (size_t)NW * SCRW;             // [MK*MK]   (PH 1)
     double* sMu = sS + MK * MK;                        // [MK]      (PH 1)
-    double* sB = sScr + (size_t)NW * G * 2 * L;        // [GT]      (PH 0)
+    double* sB = sScr + (size_t)NW * SCRW;             // [GT]      (PH 0)
     double* sSlab = sB + GT;                           // [NW][GT]  (PH 0, F_SLAB)
     if (PH == 1) {
         for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = p_invSigma[i];
@@ -269,14 +351,14 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     }
     __syncthreads();
     double* slab = sSlab + (size_t)wid * GT;
-    double* scrA = sScr + ((size_t)wid * G + g) * 2 * L;   // a_k values
-    double* scrD = scrA + L;                               // lambda-objective differences
+    double* scrA = sScr + (size_t)wid * SCRW + (size_t)g * 2 * LG;   // a_k values (spare lanes of a packed wave: the dummy group g = G)
+    double* scrD = scrA + LG;                              // lambda-objective differences
     int mod_l = 0;
     for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) mod_l = m;
 
     for (int base = (blockIdx.x * NW + wid) * G; base < D; base += gridDim.x * NW * G) {
         const int d = base + g;
-        const bool valid = d < D;
+        const bool valid = ingrp && d < D;
         const bool act = valid && l < MK;
         double lam = act ? p_lam_in[(size_t)d * MK + l] : 0.0;
         double nu = act ? p_nu[(size_t)d * MK + l] : 1.0;
@@ -354,14 +436,14 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
         // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ ----------------
         if (flags & F_NU) {
             NuObj obj{lam, cl, act ? sS[l * MK + l] : 1.0, act};
-            const int nev = mma_group<L>(obj, act, g, nu, true, o.nu_lower, o);
+            const int nev = mma_group<L, LP>(obj, act, g, nu, true, o.nu_lower, o, pc);
             if (act) p_nu[(size_t)d * MK + l] = nu;
             if (p_nev_nu && valid && l == 0) p_nev_nu[d] = nev;
         }
         // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν ---------------------------------------------
         if (flags & F_LAMBDA) {
             LamObj<MKT> obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
-            const int nev = mma_group<L>(obj, act, g, lam, false, 0.0, o);
+            const int nev = mma_group<L, LP>(obj, act, g, lam, false, 0.0, o, pc);
             if (act) p_lam_out[(size_t)d * MK + l] = lam;
             if (p_nev_lam && valid && l == 0) p_nev_lam[d] = nev;
         }
@@ -1137,6 +1219,7 @@ struct mmm_ctm {
     bool immctm = false;
     int R = 1, sel = 0;
     int L = 64, GM = 0 /* model-layout gamma size */;
+    int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 10 / 12)
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
     double Dglobal = 0;
@@ -1177,11 +1260,11 @@ struct Scope { int rep0, nrep; const int* active; };
 inline Scope one(const mmm_ctm* m) { return Scope{m->sel, 1, nullptr}; }
 inline Scope all(const mmm_ctm* m) { return Scope{0, m->R, m->active.p}; }
 
-template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false>
+template <int L, int PH, int MKT = 0, int KMX = 16, int OCC = 4, bool WIDE = false, bool PACK = false>
 int launch_estep_L(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     mmm_ctx* ctx = m->ctx;
-    auto k = k_ctm_estep<L, PH, MKT, KMX, OCC, WIDE>;
+    auto k = k_ctm_estep<L, PH, MKT, KMX, OCC, WIDE, PACK>;
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
     MMM_LAUNCH_CHECK(ctx);
@@ -1199,8 +1282,8 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 
 size_t solve_lds(const mmm_ctm* m)
 {
-    const int G = MMM_WAVE / m->L;
-    return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * G * 2 * m->L);
+    const int scrw = m->Ls != m->L ? (MMM_WAVE / m->Ls + 1) * 2 * m->Ls : 2 * MMM_WAVE;
+    return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * scrw);
 }
 
 template <int PH>
@@ -1208,6 +1291,14 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
 {
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
         const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
+        if (m->Ls != m->L) {       // packed groups: sum K lanes per document
+            if (m->Ls == 6) return launch_estep_L<16, PH, 6, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
+            static const int pocc = getenv("MMM_CTM_PACK_OCC") ? atoi(getenv("MMM_CTM_PACK_OCC")) : 4;
+            if (m->Ls == 10 && pocc == 3) return launch_estep_L<16, PH, 10, 16, 3, false, true>(m, a, lds, grid, waves, nrep);
+            if (m->Ls == 10) return launch_estep_L<16, PH, 10, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
+            if (m->Ls == 12) return launch_estep_L<16, PH, 12, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
+            return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "no packed solve build for sum K = %d", m->Ls);
+        }
         if (m->L == 16 && m->dm.MK == 10) return small ? launch_estep_L<16, PH, 10, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
         if (m->L == 16 && m->dm.MK == 14) return small ? launch_estep_L<16, PH, 14, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
         if (m->L == 32 && m->dm.MK == 28) return launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
@@ -1623,7 +1714,15 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
     m->waves_s = 4;
-    m->grid_v = std::max(1, std::min((D + m->waves_s * G - 1) / (m->waves_s * G), ctx->num_cu * 8));
+    // solve phase: packed document groups (sum K lanes per document) for the shapes with a build; MMM_CTM_PACK=0: the 16-lane rows (A/B)
+    m->Ls = m->L;
+    {
+        const char* pe = getenv("MMM_CTM_PACK");
+        const bool allow = !pe || atoi(pe) != 0;
+        if (allow && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
+    }
+    const int Gs = MMM_WAVE / m->Ls;
+    m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     m->grid_m = std::max(1, std::min((D + 31) / 32, 1024));      // one 32-document tile per block while the reduce stays small
     if (const char* gm = getenv("MMM_CTM_GRID_M")) m->grid_m = std::max(1, atoi(gm));
@@ -2010,7 +2109,7 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = out[6] = out[7] = 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = out[7] = 0;
     return MMM_OK;
 }
 

@@ -32,6 +32,15 @@ static double tw_group_sum(const double* v, int L)
 {
     double t[64];
     memcpy(t, v, sizeof(double) * (size_t)L);
+    if (L & (L - 1)) {
+        /* packed groups (packed_sum<LP> of ctm.hip, L = sum K lanes per document): lane l+off is folded onto lane l for
+         * off = 8, 4, 2, 1 (lanes without a partner add a spare lane's 0), lane 0 holds the total */
+        for (int off = 8; off >= 1; off >>= 1) {
+            if (off >= L) continue;
+            for (int l = 0; l < off && l + off < L; ++l) t[l] += t[l + off];
+        }
+        return t[0];
+    }
     for (int n = L; n > 1; n >>= 1)
         for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
     return t[0];
@@ -370,7 +379,7 @@ void orc_twin_estep(orc_ctm* m, double* sG)
             for (int kk = 0; kk < m->K[mod]; ++kk) c[tw_koff(m, mod) + kk] = cl;
         }
         double* lam = m->lambda + (size_t)MK * d; double* nu = m->nu + (size_t)MK * d;
-        tw_obj o = { MK, L, lam, c, sumth + (size_t)d * MK, m->mu, m->invSigma };
+        tw_obj o = { MK, m->Ls > 0 ? m->Ls : L, lam, c, sumth + (size_t)d * MK, m->mu, m->invSigma };      /* Ls: lanes per document in the solve phase */
         memcpy(x, nu, sizeof(double) * (size_t)MK);
         int nev = tw_mma(&o, tw_nu_eval, x, 1, m->nu_lower, m->xtol_rel, m->xtol_abs, m->xtol_rule, m->max_eval);
         memcpy(nu, x, sizeof(double) * (size_t)MK);

@@ -59,6 +59,8 @@ if __name__ == "__main__":
     ok &= case("mm [7,7]", 560, [7, 7], [96, 48], [3000, 60], 7, npass=npass)
     ok &= case("mm [10,10,8]", 700, [10, 10, 8], [96, 38, 32], [2000, 150, 100], 8, npass=npass)
     ok &= case("imm [10]", 800, [10], [96], [2500], 9, feats=SNV3, npass=npass)
+    ok &= case("mm [3,3] packed 6", 500, [3, 3], [40, 24], [600, 80], 41, npass=npass)
+    ok &= case("mm [6,6] packed 12", 500, [6, 6], [40, 24], [600, 80], 42, npass=npass)
     ok &= case("mm [20,6]", 90, [20, 6], [96, 32], [2500, 120], 15, npass=npass)
     ok &= case("mm [24,17,23]", 40, [24, 17, 23], [30, 30, 30], [200, 200, 200], 91, npass=npass)
     print("ALL BIT-IDENTICAL" if ok else "DIFFERENCES FOUND")
