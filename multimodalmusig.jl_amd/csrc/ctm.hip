@@ -459,6 +459,272 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     }
 }
 
+// =====================================================================================================================
+// Solve phase, several coordinates per lane.  The solve phase is f64-VALU bound (PMC: the vector pipes are ~100 % busy), and with
+// one coordinate per lane most of a trip's instructions are not arithmetic on coordinates: five lane-butterfly sums, the scalars of
+// the LD_MMA state machine replicated in every lane, the padding lanes.  Here a document takes LPD lanes (2 or 4) with CPL = sum K /
+// LPD coordinates each: 16 or 32 documents per wave instead of 2-4, the per-document scalars are paid once per LPD lanes, a sum over
+// the document is CPL-1 local additions and log2(LPD) quad-permute stages.  Same algorithm, same formulas as mma_group; the sums
+// are associated as: each lane adds its coordinates in index order (from 0), the lanes' partial sums go through the quad butterfly.
+// Coordinate i of a document sits in lane i / CPL, slot i % CPL.
+template <int LPD>
+__device__ __forceinline__ double qsum(double v)
+{
+    v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]
+    if (LPD >= 4) v += dpp_mov_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int LPD>
+__device__ __forceinline__ bool qnone(bool pred, int lane)
+{
+    const unsigned long long b = __ballot(pred);
+    return ((b >> (lane & ~(LPD - 1))) & ((1ull << LPD) - 1ull)) == 0ull;
+}
+
+// invSigma in LDS for this layout: row j (the factor's index), the document's coordinates padded per lane to CPLP = CPL rounded up
+// to even, so that a lane reads its CPL entries of a row as 16-byte pairs: sS[j * (LPD * CPLP) + l * CPLP + c]
+template <int MKT, int LPD>
+struct CplGeom {
+    static constexpr int CPL = MKT / LPD, CPLP = (CPL + 1) & ~1, ROW = LPD * CPLP, G = MMM_WAVE / LPD;
+    static_assert(MKT % LPD == 0, "sum K must be a multiple of the lanes per document");
+};
+
+template <int MKT, int LPD, bool SB>
+struct NuObjC {
+    using Gm = CplGeom<MKT, LPD>;
+    double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
+    __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) {
+            const double E = ar_exp(lam[q] + 0.5 * x[q]);
+            g[q] = 0.5 * Sll[q] + 0.5 * c[q] * E - dev_div(1.0, 2.0 * x[q]);
+            s += 0.5 * x[q] * Sll[q] + c[q] * E - 0.5 * ar_log(x[q]);
+            if (SB) __builtin_amdgcn_sched_barrier(0);
+        }
+        return qsum<LPD>(s);
+    }
+};
+
+template <int MKT, int LPD, bool SB>
+struct LamObjC {
+    using Gm = CplGeom<MKT, LPD>;
+    double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL], mu[Gm::CPL];
+    int l;
+    const double* sS;     // padded layout above
+    double* scr;          // group-private LDS, MKT doubles (+1 pad): the differences x - mu of the whole document
+    __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
+    {
+        double diff[Gm::CPL];
+        lds_wave_sync();
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - mu[q]; scr[l * Gm::CPL + q] = diff[q]; }
+        lds_wave_sync();
+        // the rows of invSigma are read from LDS in every evaluation: without this the compiler hoists all CPL x sum K of them out of
+        // the solver loop into registers (392 VGPRs at sum K = 28) and spills
+        asm volatile("" ::: "memory");
+        // Sd_i = sum_j S_ij diff_j with four chains over j, combined pairwise (the association of LamObj::eval)
+        double s0[Gm::CPL], s1[Gm::CPL], s2[Gm::CPL], s3[Gm::CPL];
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) { s0[q] = 0.0; s1[q] = 0.0; s2[q] = 0.0; s3[q] = 0.0; }
+        const double* row = sS + l * Gm::CPLP;
+#pragma unroll
+        for (int j = 0; j + 3 < MKT; j += 4) {
+            const double d0 = scr[j], d1 = scr[j + 1], d2 = scr[j + 2], d3 = scr[j + 3];
+#pragma unroll
+            for (int q = 0; q < Gm::CPL; ++q) {
+                s0[q] = fma(row[j * Gm::ROW + q], d0, s0[q]); s1[q] = fma(row[(j + 1) * Gm::ROW + q], d1, s1[q]);
+                s2[q] = fma(row[(j + 2) * Gm::ROW + q], d2, s2[q]); s3[q] = fma(row[(j + 3) * Gm::ROW + q], d3, s3[q]);
+            }
+        }
+#pragma unroll
+        for (int j = MKT & ~3; j < MKT; ++j) {
+            const double dj = scr[j];
+#pragma unroll
+            for (int q = 0; q < Gm::CPL; ++q) s0[q] = fma(row[j * Gm::ROW + q], dj, s0[q]);
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) {
+            const double Sd = (s0[q] + s1[q]) + (s2[q] + s3[q]);
+            const double E = ar_exp(x[q] + 0.5 * nu[q]);
+            g[q] = Sd - sumth[q] + c[q] * E;
+            s += 0.5 * diff[q] * Sd - x[q] * sumth[q] + c[q] * E;
+            if (SB) __builtin_amdgcn_sched_barrier(0);
+        }
+        return qsum<LPD>(s);
+    }
+};
+
+// NLopt LD_MMA, zero constraints (the algorithm of mma_group, statement: oracle/mmm_oracle.c orc_mma_minimize), LPD lanes per document
+template <int MKT, int LPD, bool SB, class Obj>
+__device__ __forceinline__ int mma_cpl(const Obj& obj, bool valid, int lane, double (&x)[CplGeom<MKT, LPD>::CPL], bool has_lb, double lb, const SolveOpts& o)
+{
+    constexpr int CPL = CplGeom<MKT, LPD>::CPL;
+    // xcur doubles as the candidate point: a finished document never looks at it again, so it needs no select-based commit
+    double sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL], xprevprev[CPL];
+    double rho = 1.0;
+    double fbest = obj.eval(x, grad);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
+    int k = 1, nev = 1;
+    bool done = !valid, capped = false;
+    const int cap = o.max_eval > 0 ? o.max_eval : 2000;
+    while (!__all(done)) {
+        double gls = 0.0, wls = 0.0;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const double sigma2 = sigma[q] * sigma[q];
+            const double u = grad[q] * sigma2;
+            const double v = fabs(grad[q]) * sigma[q] + 0.5 * rho;
+            const double qq = dev_div(u, v * sigma[q]);
+            double dx = dev_div(dev_div(u, v), -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
+            double c = x[q] + dx;
+            c = (has_lb && c < lb) ? lb : c;
+            const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
+            c = c > hi ? hi : (c < lo ? lo : c);
+            xcur[q] = c;
+            dx = c - x[q];
+            const double dx2 = dx * dx;
+            const double denominv = dev_div(1.0, sigma2 - dx2);
+            gls += (grad[q] * (sigma2 * dx) + (fabs(grad[q]) * sigma[q] + 0.5 * rho) * dx2) * denominv;
+            wls += 0.5 * dx2 * denominv;
+            if (SB) __builtin_amdgcn_sched_barrier(0);       // one coordinate at a time (the interleaved chains of all coordinates need more registers)
+        }
+        const double gval = fbest + qsum<LPD>(gls);
+        const double wval = qsum<LPD>(wls);
+        const double fcur = obj.eval(xcur, gcur);
+        const bool live = !done;
+        bool inner_done = live && gval >= fcur;
+        const bool better = live && fcur < fbest;                 // accepted before the cap is looked at, as in mma_group
+        nev += live ? 1 : 0;
+        if (live && nev >= cap) { done = true; capped = true; inner_done = false; }
+        fbest = better ? fcur : fbest;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) { x[q] = better ? xcur[q] : x[q]; grad[q] = better ? gcur[q] : grad[q]; }
+        const bool grow = !done && !inner_done && fcur > gval;
+        if (__any(grow)) { const double rn = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval))); rho = grow ? rn : rho; }
+        // outer iteration finished in at least one document of this wave: NLopt's x-tolerance test on (xcur, xprev)
+        if (__any(inner_done)) {
+            bool stop;
+            if (o.xtol_rule == 0) {
+                double dn = 0.0, xn = 0.0;
+                bool big = false;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { const double ad = fabs(xcur[q] - xprev[q]); dn += ad; xn += fabs(xcur[q]); big = big || !(ad < o.xtol_abs); }
+                dn = qsum<LPD>(dn); xn = qsum<LPD>(xn);
+                stop = (dn < o.xtol_rel * xn) || qnone<LPD>(big, lane);
+            } else {
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const double ad = fabs(xcur[q] - xprev[q]);
+                    const bool ok = isinf(xprev[q]) ? false
+                                                    : (ad < o.xtol_abs || ad < o.xtol_rel * (fabs(xcur[q]) + fabs(xprev[q])) * 0.5 ||
+                                                       (o.xtol_rel > 0 && xcur[q] == xprev[q]));
+                    bad = bad || !ok;
+                }
+                stop = qnone<LPD>(bad, lane);
+            }
+            done = done || (inner_done && stop);
+            const bool next = inner_done && !stop;           // this document starts another outer iteration
+            rho = next ? fmax(0.1 * rho, 1e-5) : rho;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const double sgn = (xcur[q] - xprev[q]) * (xprev[q] - xprevprev[q]);
+                const double fac = (k > 1) ? (sgn < 0 ? 0.7 : (sgn > 0 ? 1.2 : 1.0)) : 1.0;
+                sigma[q] = next ? sigma[q] * fac : sigma[q];
+                xprevprev[q] = next ? xprev[q] : xprevprev[q];
+                xprev[q] = next ? xcur[q] : xprev[q];
+            }
+            k += next ? 1 : 0;
+        }
+    }
+    return capped ? -nev : nev;
+}
+
+template <int MKT, int LPD, int OCC, bool SB>
+__global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    using Gm = CplGeom<MKT, LPD>;
+    constexpr int CPL = Gm::CPL, G = Gm::G, MK = MKT;
+    const CtmDims& dm = a.c.dm;
+    const int M = dm.M, D = dm.D;
+    const size_t rep = blockIdx.y;
+    if (a.active && !a.active[rep]) return;
+    const double* __restrict__ p_invSigma = a.invSigma + rep * MK * MK;
+    const double* __restrict__ p_mu = a.mu + rep * MK;
+    const double* p_lam_in = a.lam_in + rep * D * MK;
+    double* p_lam_out = a.lam_out + rep * D * MK;
+    double* p_nu = a.nu + rep * D * MK;
+    const double* p_zeta = a.zeta + rep * D * M;
+    const double* p_sumth = a.sumth + rep * D * MK;
+    int* p_nev_nu = a.nev_nu ? a.nev_nu + rep * D : nullptr;
+    int* p_nev_lam = a.nev_lam ? a.nev_lam + rep * D : nullptr;
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / LPD, l = lane % LPD;
+    // LDS: [MK rows][ROW] invSigma (padded) | [NW][G][MK + 2] difference vectors
+    double* sS = smem;
+    double* sScr = sS + MK * Gm::ROW;
+    for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
+        const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
+        sS[e] = (q < CPL) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
+    }
+    __syncthreads();
+    double* scr = sScr + ((size_t)wid * G + g) * (MK + 2);
+    int mod_q[CPL];
+    double mu_q[CPL], Sll_q[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int i = l * CPL + q;
+        int mm = 0;
+        for (int m = 0; m < M; ++m) if (i >= dm.koff[m] && i < dm.koff[m + 1]) mm = m;
+        mod_q[q] = mm; mu_q[q] = p_mu[i]; Sll_q[q] = p_invSigma[(size_t)i * MK + i];
+    }
+    const SolveOpts o = a.opt;
+    for (int base = (blockIdx.x * NW + wid) * G; base < D; base += gridDim.x * NW * G) {
+        const int d = base + g;
+        const bool valid = d < D;
+        const size_t row = (size_t)(valid ? d : 0) * MK + l * CPL;
+        double lam[CPL], nu[CPL], sumth[CPL], cl[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            lam[q] = valid ? p_lam_in[row + q] : 0.0; nu[q] = valid ? p_nu[row + q] : 1.0; sumth[q] = valid ? p_sumth[row + q] : 0.0;
+            const double Nl = valid ? a.c.Ndm[(size_t)d * M + mod_q[q]] : 0.0, zl = valid ? p_zeta[(size_t)d * M + mod_q[q]] : 1.0;
+            cl[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
+        }
+        // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ
+        if (a.flags & F_NU) {
+            NuObjC<MKT, LPD, SB> obj;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { obj.lam[q] = lam[q]; obj.c[q] = cl[q]; obj.Sll[q] = Sll_q[q]; }
+            const int nev = mma_cpl<MKT, LPD, SB>(obj, valid, lane, nu, true, o.nu_lower, o);
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) p_nu[row + q] = nu[q];
+                if (p_nev_nu && l == 0) p_nev_nu[d] = nev;
+            }
+        }
+        // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
+        if (a.flags & F_LAMBDA) {
+            LamObjC<MKT, LPD, SB> obj;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { obj.nu[q] = nu[q]; obj.c[q] = cl[q]; obj.sumth[q] = sumth[q]; obj.mu[q] = mu_q[q]; }
+            obj.l = l; obj.sS = sS; obj.scr = scr;
+            const int nev = mma_cpl<MKT, LPD, SB>(obj, valid, lane, lam, false, 0.0, o);
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) p_lam_out[row + q] = lam[q];
+                if (p_nev_lam && l == 0) p_nev_lam[d] = nev;
+            }
+        }
+    }
+}
+
 // objective values / gradients of one document at its stored (lambda, nu), in the reference's MAXIMISATION form
 // (common.jl:11-36), evaluated by the same device functors the solvers use.  One wave.
 __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const double* invSigma, const double* mu, const double* lam,
@@ -1219,7 +1485,8 @@ struct mmm_ctm {
     bool immctm = false;
     int R = 1, sel = 0;
     int L = 64, GM = 0 /* model-layout gamma size */;
-    int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 10 / 12)
+    int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 12), or 2 / 4 (cpl > 1)
+    int cpl = 1;                   // coordinates per lane in the solve phase (k_ctm_solve_cpl: sum K = 10, 14, 28)
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
     double Dglobal = 0;
@@ -1282,6 +1549,10 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 
 size_t solve_lds(const mmm_ctm* m)
 {
+    if (m->cpl > 1) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
+        const int cplp = (m->cpl + 1) & ~1;
+        return sizeof(double) * ((size_t)m->dm.MK * m->Ls * cplp + (size_t)m->waves_s * (MMM_WAVE / m->Ls) * (m->dm.MK + 2));
+    }
     const int scrw = m->Ls != m->L ? (MMM_WAVE / m->Ls + 1) * 2 * m->Ls : 2 * MMM_WAVE;
     return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * scrw);
 }
@@ -1291,6 +1562,21 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
 {
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
         const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
+        if (m->cpl > 1) {          // several coordinates per lane
+            mmm_ctx* ctx = m->ctx;
+            auto go = [&](auto kern) -> int {
+                if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(grid, nrep), dim3(waves * MMM_WAVE), lds, ctx->stream, a);
+                MMM_LAUNCH_CHECK(ctx);
+                return MMM_OK;
+            };
+            // builds: 2 waves per SIMD, chains of the coordinates interleaved by the scheduler (sum K = 10: 245 VGPRs, no scratch; 263 us at
+            // config 5 against 323 us for the 3-wave build with one coordinate at a time); sum K = 14 / 28: the 2-wave builds with scheduling barriers
+            if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
+            if (m->dm.MK == 28 && m->Ls == 4) return go(k_ctm_solve_cpl<28, 4, 2, true>);
+            if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
+            return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
+        }
         if (m->Ls != m->L) {       // packed groups: sum K lanes per document
             if (m->Ls == 6) return launch_estep_L<16, PH, 6, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
             static const int pocc = getenv("MMM_CTM_PACK_OCC") ? atoi(getenv("MMM_CTM_PACK_OCC")) : 4;
@@ -1720,6 +2006,17 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         const char* pe = getenv("MMM_CTM_PACK");
         const bool allow = !pe || atoi(pe) != 0;
         if (allow && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
+        // several coordinates per lane (k_ctm_solve_cpl): sum K = 10 -> 2 lanes x 5 coordinates (32 documents per wave; BASELINE config 5:
+        // solve phase 334 -> 263 us).  Builds for sum K = 14 (2 x 7) and 28 (4 x 7) exist but lose to one coordinate per lane there
+        // (config 4: 1105-1235 vs 729 us -- 1-2 waves per SIMD cannot hide the chains of 7 coordinates); MMM_CTM_CPL=2 selects them
+        // (tests, A/B), MMM_CTM_CPL=0 switches the path off.
+        const char* ce = getenv("MMM_CTM_CPL");
+        const int cmode = ce ? atoi(ce) : 1;
+        if (cmode != 0) {
+            if (dm.MK == 10) { m->Ls = 2; m->cpl = 5; }
+            else if (cmode == 2 && dm.MK == 28) { m->Ls = 4; m->cpl = 7; }
+            else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
+        }
     }
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
@@ -2109,7 +2406,7 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = out[7] = 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = m->cpl; out[7] = 0;
     return MMM_OK;
 }
 

@@ -40,14 +40,14 @@ static inline double ar_from_bits_(unsigned long long u) { double x; memcpy(&x, 
 #define AR_RINT(x) rint(x)
 #endif
 
-/* exp(x), any finite x; NaN -> NaN */
+/* exp(x), any x; NaN -> NaN.  Branch-free: the argument is clamped into the range where k = rint(x / ln 2) fits the two-step
+ * scaling, the out-of-range results are selected at the end (kernels evaluate it for several coordinates per lane in straight-line
+ * code; early returns would turn into divergent branches). */
 AR_FN double ar_exp(double x)
 {
-    if (x != x) return x;
-    if (x > 7.09782712893383973096e+02) return AR_FROM_BITS(0x7ff0000000000000ull);     /* overflow */
-    if (x < -7.45133219101941108420e+02) return 0.0;                                     /* below the smallest subnormal */
-    const double kd = AR_RINT(x * 1.44269504088896338700e+00);
-    const double hi = AR_FMA(-kd, 6.93147180369123816490e-01, x);      /* exact: ln2HI has 21 trailing zero bits */
+    const double xc = x > 7.1e+02 ? 7.1e+02 : (x < -7.5e+02 ? -7.5e+02 : x);           /* NaN stays NaN (both comparisons false) */
+    const double kd = AR_RINT(xc * 1.44269504088896338700e+00);
+    const double hi = AR_FMA(-kd, 6.93147180369123816490e-01, xc);     /* exact: ln2HI has 21 trailing zero bits */
     const double lo = kd * 1.90821492927058770002e-10;
     const double r = hi - lo;
     const double t = r * r;
@@ -58,12 +58,14 @@ AR_FN double ar_exp(double x)
     p = AR_FMA(p, t, 1.66666666666666019037e-01);
     const double c = AR_FMA(-t, p, r);                                  /* r - t*P(t) */
     const double y = 1.0 - ((lo - AR_DIV(r * c, 2.0 - c)) - hi);
-    /* y * 2^k in two exact-or-once-rounded steps (k in [-1075, 1024]) */
-    const int k = (int)kd;
+    /* y * 2^k in two exact-or-once-rounded steps (k in [-1083, 1025]) */
+    const int k = (x != x) ? 0 : (int)kd;
     const int k1 = k / 2, k2 = k - k1;
     const double s1 = AR_FROM_BITS((unsigned long long)(1023 + k1) << 52);
     const double s2 = AR_FROM_BITS((unsigned long long)(1023 + k2) << 52);
-    return (y * s1) * s2;
+    const double res = (y * s1) * s2;
+    return x > 7.09782712893383973096e+02 ? AR_FROM_BITS(0x7ff0000000000000ull)       /* overflow */
+         : (x < -7.45133219101941108420e+02 ? 0.0 : res);                            /* below the smallest subnormal; NaN falls through as NaN */
 }
 
 /* log(x), finite x > 0 (subnormals are scaled up first) */

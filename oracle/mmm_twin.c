@@ -99,11 +99,29 @@ static double tw_digamma(double x)
 /* ---- objectives in NLopt's minimisation form, lane layout (common.jl:11-36 negated) -------------------------------- */
 typedef struct {
     int n, L;
+    int cpl;                  /* > 1: k_ctm_solve_cpl -- n / cpl lanes per document, cpl coordinates per lane (L = n) */
     const double *other;      /* nu: lambda ; lambda: nu */
     const double *c;          /* Ndivzeta per coordinate */
     const double *sumth;      /* lambda objective */
     const double *mu, *invSigma;
 } tw_obj;
+
+/* sum over a document's coordinates as the solve kernel in use associates it: the lane butterfly over one coordinate per lane
+ * (mma_group), or (mma_cpl) every lane adds its cpl coordinates in index order from 0 and the lanes' sums go through the butterfly */
+static double tw_sum(const tw_obj* o, const double* t)
+{
+    if (o->cpl > 1) {
+        double part[64];
+        const int lpd = o->n / o->cpl;
+        for (int l = 0; l < lpd; ++l) {
+            double s = 0.0;
+            for (int q = 0; q < o->cpl; ++q) s += t[l * o->cpl + q];
+            part[l] = s;
+        }
+        return tw_group_sum(part, lpd);
+    }
+    return tw_group_sum(t, o->L);
+}
 
 /* nu: f = 1/2 sum nu_i S_ii + sum c_i exp(lambda_i + nu_i/2) - 1/2 sum log nu_i   (NuObj::eval) */
 static double tw_nu_eval(const tw_obj* o, const double* x, double* g)
@@ -117,7 +135,7 @@ static double tw_nu_eval(const tw_obj* o, const double* x, double* g)
         g[l] = 0.5 * Sll + 0.5 * c * E - 1.0 / (2.0 * x[l]);
         t[l] = 0.5 * x[l] * Sll + c * E - 0.5 * ar_log(x[l]);
     }
-    return tw_group_sum(t, o->L);
+    return tw_sum(o, t);
 }
 
 /* lambda: f = 1/2 (x-mu)' S (x-mu) - x . sumtheta + sum c_i exp(x_i + nu_i/2)   (LamObj::eval) */
@@ -143,7 +161,7 @@ static double tw_lam_eval(const tw_obj* o, const double* x, double* g)
         g[l] = Sd - sumth + c * E;
         t[l] = 0.5 * diff[l] * Sd - x[l] * sumth + c * E;
     }
-    return tw_group_sum(t, o->L);
+    return tw_sum(o, t);
 }
 
 typedef double (*tw_eval_fn)(const tw_obj*, const double*, double*);
@@ -179,8 +197,8 @@ static int tw_mma(const tw_obj* o, tw_eval_fn eval, double* x, int has_lb, doubl
             gl[l] = (grad[l] * (sigma2 * dx) + (fabs(grad[l]) * sigma[l] + 0.5 * rho) * dx2) * denominv;
             wl[l] = 0.5 * dx2 * denominv;
         }
-        const double gval = fbest + tw_group_sum(gl, L);
-        const double wval = tw_group_sum(wl, L);
+        const double gval = fbest + tw_sum(o, gl);
+        const double wval = tw_sum(o, wl);
         const double fcur = eval(o, xc, gcur);
         ++nev;
         memcpy(xcur, xc, sizeof(double) * (size_t)L);
@@ -195,7 +213,7 @@ static int tw_mma(const tw_obj* o, tw_eval_fn eval, double* x, int has_lb, doubl
         int stop;
         if (xtol_rule == 0) {
             for (int l = 0; l < L; ++l) { tmp[l] = l < n ? fabs(xcur[l] - xprev[l]) : 0.0; tmp2[l] = l < n ? fabs(xcur[l]) : 0.0; }
-            const double dn = tw_group_sum(tmp, L), xn = tw_group_sum(tmp2, L);
+            const double dn = tw_sum(o, tmp), xn = tw_sum(o, tmp2);
             int all_abs = 1;
             for (int l = 0; l < n; ++l) if (!(tmp[l] < xtol_abs)) all_abs = 0;
             stop = (dn < xtol_rel * xn) || all_abs;
@@ -379,7 +397,8 @@ void orc_twin_estep(orc_ctm* m, double* sG)
             for (int kk = 0; kk < m->K[mod]; ++kk) c[tw_koff(m, mod) + kk] = cl;
         }
         double* lam = m->lambda + (size_t)MK * d; double* nu = m->nu + (size_t)MK * d;
-        tw_obj o = { MK, m->Ls > 0 ? m->Ls : L, lam, c, sumth + (size_t)d * MK, m->mu, m->invSigma };      /* Ls: lanes per document in the solve phase */
+        /* Ls: lanes per document in the solve phase; cpl: coordinates per lane (k_ctm_solve_cpl: Ls * cpl = sum K) */
+        tw_obj o = { MK, m->cpl > 1 ? MK : (m->Ls > 0 ? m->Ls : L), m->cpl, lam, c, sumth + (size_t)d * MK, m->mu, m->invSigma };
         memcpy(x, nu, sizeof(double) * (size_t)MK);
         int nev = tw_mma(&o, tw_nu_eval, x, 1, m->nu_lower, m->xtol_rel, m->xtol_abs, m->xtol_rule, m->max_eval);
         memcpy(nu, x, sizeof(double) * (size_t)MK);
@@ -500,7 +519,7 @@ void orc_twin_objectives(int n, const double* lambda, const double* nu, const do
 {
     const int L = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
     double g[64];
-    tw_obj o = { n, L, nu, Ndivzeta, sumtheta, mu, invSigma };
+    tw_obj o = { n, L, 1, nu, Ndivzeta, sumtheta, mu, invSigma };
     vals[0] = -tw_lam_eval(&o, lambda, g);
     for (int i = 0; i < n; ++i) grad_lambda[i] = -g[i];
     o.other = lambda;

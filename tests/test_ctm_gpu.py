@@ -352,6 +352,36 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
     print("%s: %d documents x 12 passes, evaluations per pass nu %d lambda %d -- all equal" % (case, D, st["n_eval_nu"], st["n_eval_lambda"]))
 
 
+@pytest.mark.parametrize("env,case,expect", [({"MMM_CTM_CPL": "0", "MMM_CTM_PACK": "0"}, "imm10", (16, 1)), ({"MMM_CTM_CPL": "0"}, "imm10", (10, 1)),
+                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (4, 7)),
+                                             ({}, "mm33", (6, 1)), ({}, "mm66", (12, 1))])
+def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, env, case, expect):
+    """The solve phase has three lane layouts: one coordinate per lane in 16/32/64-lane DPP rows (mma_group), packed groups of sum K
+    lanes (6 / 10 / 12; ds_bpermute tree), and several coordinates per lane (k_ctm_solve_cpl; sum K = 10 by default, 14 and 28 on
+    request).  Each associates the sums over a document differently; the oracle mirrors the layout the handle reports
+    (geometry Ls / cpl) and the fit must stay bit-identical in all of them."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if case == "imm10":
+        kw = dict(D=300, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
+    elif case == "mm33":
+        kw = dict(D=200, K=[3, 3], V=[40, 24], seed=62, means=[600, 80])
+    elif case == "mm66":
+        kw = dict(D=200, K=[6, 6], V=[40, 24], seed=63, means=[600, 80])
+    else:
+        kw = dict(_fit_case(case)); kw["D"] = 300
+    D, MK = kw["D"], sum(kw["K"])
+    X, g, o = _pair(mmm, oracle, order="device", **kw)
+    geo = g.geometry()
+    assert (geo["Ls"], geo["cpl"]) == expect, geo
+    for it in range(6):
+        mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        assert o.twin_pass(True) == 0
+        st = g.solver_stats(per_doc=True)
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+        _same_state(g, o, D, MK)
+
+
 @pytest.mark.parametrize("case", ["mm", "mm_k20"])
 def test_fit_against_index_order_oracle(mmm, oracle, case):
     """The same fits against the index-order variant (libm exp, sequential sums).  The two CPU variants themselves drift apart by
