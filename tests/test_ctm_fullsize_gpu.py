@@ -106,7 +106,7 @@ def test_full_size_properties_and_slice(mmm, oracle, cfg, D):
     n = 200
     d0 = D // 3
     o = oracle.CtmOracle(K, [0.1] * M, X[d0:d0 + n], V=V if feats is None else None, features=feats, gamma0=gam_S,
-                         geometry=dict(L=g.geometry()["L"], Ls=g.geometry()["Ls"], grid_e=1, waves_e=1, grid_m=1))
+                         geometry=dict(g.geometry(), grid_e=1, waves_e=1, grid_m=1))
     oracle.lib().orc_twin_topics(oracle.C.byref(o.s), None)          # Elnphi / exp table from the device's gamma
     o.mu[:] = mu_S; o.invSigma[:] = iS_S
     o.lam[:] = lam_S[d0:d0 + n].ravel(); o.nu[:] = nu_S[d0:d0 + n].ravel()
