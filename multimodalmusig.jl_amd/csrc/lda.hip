@@ -234,10 +234,19 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     }
     MMM_STAMP(1);
 
+    // Grid-stride build: a two-deep software pipeline over the wave's steps.  The CSR offsets of step i+2 and the (term,count)
+    // pairs + gamma row of step i+1 are requested while step i computes, so that no step starts with the two dependent memory
+    // round trips doc_ptr -> tc (at 160k-640k documents they were ~70 % of a step: the SIMDs ran at 30 % VALU utilisation).
+    int d1 = 0; bool valid1 = false; int64_t start1 = 0; int W1 = 0;
+    if (!SINGLE) {
+        d1 = base + stride + g; valid1 = (base + stride < D) && d1 < D;
+        start1 = valid1 ? a.c.doc_ptr[d1] : 0;
+        W1 = valid1 ? (int)(a.c.doc_ptr[d1 + 1] - start1) : 0;
+    }
+    int2 tcp[PRE];                           // (term,count) of the first PRE chunks of the current step
     bool first = true;
     for (;;) {
-        // ---- the document's (term,count) pairs are fetched one chunk ahead; groups start at rotated chunks so that
-        //      the G documents of a wave instruction touch different term ranges of the slab --------------------
+        // ---- groups start at rotated chunks so that the G documents of a wave instruction touch different term ranges of the slab
         const int nch = (W + L - 1) / L;
         const int rot = nch > 0 ? g % nch : 0;
         const int2* __restrict__ tcd = a.c.tc + start;
@@ -245,12 +254,13 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         if (G >= 2) nchmax = max(nchmax, __shfl_xor(nchmax, 32, MMM_WAVE));
         if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
         nchmax = __builtin_amdgcn_readfirstlane(nchmax);
-        int2 tcp[PRE];                       // (term,count) of the first PRE chunks: loads issued before the prologue math
+        if (SINGLE || first) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
 #pragma unroll
-        for (int j = 0; j < PRE; ++j) {
-            int c = j + rot; if (c >= nch) c -= nch;
-            const int w = c * L + l;
-            tcp[j] = ((j < nch) && (w < W)) ? tcd[w] : make_int2(-1, 0);
+            for (int j = 0; j < PRE; ++j) {
+                int c = j + rot; if (c >= nch) c -= nch;
+                const int w = c * L + l;
+                tcp[j] = ((j < nch) && (w < W)) ? tcd[w] : make_int2(-1, 0);
+            }
         }
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k), theta_{t-1} (LDA.jl:92-94) ------------------------------
         const double S = group_sum<L>(gk);
@@ -274,6 +284,27 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         } else lds_wave_sync();
         if (valid && l < K) Eln[(size_t)d * K + l] = el;
         MMM_STAMP(3);
+        // ---- requests of the next two steps (grid-stride build) ---------------------------------------------------------
+        int2 tcn[PRE];
+        double gkn = 0.0, gpn = 0.0;
+        int d2 = 0; bool valid2 = false; int64_t start2 = 0; int W2 = 0;
+        const bool more = !SINGLE && base + stride < D;
+        if (more) {
+            const int nch1 = (W1 + L - 1) / L;
+            const int rot1 = nch1 > 0 ? g % nch1 : 0;
+            const int2* __restrict__ tcd1 = a.c.tc + start1;
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                int c = j + rot1; if (c >= nch1) c -= nch1;
+                const int w = c * L + l;
+                tcn[j] = ((j < nch1) && (w < W1)) ? tcd1[w] : make_int2(-1, 0);
+            }
+            gkn = (valid1 && l < K) ? gam[(size_t)d1 * K + l] : (l < K ? 1.0 : 0.0);
+            gpn = (LL && valid1 && l < K) ? gprev[(size_t)d1 * K + l] : (l < K ? 1.0 : 0.0);
+            d2 = base + 2 * stride + g; valid2 = (base + 2 * stride < D) && d2 < D;
+            start2 = valid2 ? a.c.doc_ptr[d2] : 0;
+            W2 = valid2 ? (int)(a.c.doc_ptr[d2 + 1] - start2) : 0;
+        }
         {
             double av[KP], acc[KP];
 #pragma unroll
@@ -303,12 +334,11 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         if (SINGLE) break;
         base += stride;
         if (base >= D) break;
-        // ---- loads of the next step ------------------------------------------------------------------------------
-        d = base + g; valid = d < D;
-        gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-        gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-        start = valid ? a.c.doc_ptr[d] : 0;
-        W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+        // ---- the next step's operands were requested above ------------------------------------------------------------
+        d = d1; valid = valid1; gk = gkn; gp = gpn; start = start1; W = W1;
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) tcp[j] = tcn[j];
+        d1 = d2; valid1 = valid2; start1 = start2; W1 = W2;
         lds_wave_sync();
     }
     MMM_STAMP(6);
