@@ -1079,12 +1079,23 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
     } else {
         const int mg = tp.mgoff[m], SJ = tp.SJ[m], nf = tp.nfeat[m], ao = tp.aoff[m];
         const int* feat = tp.features + tp.foff[m];
-        // gamma[m][k][i][j] = alpha[m][i] + sum_{v: f_vi = j} S[m][k][v]   (IMMCTM.jl:199-221)
+        // gamma[m][k][i][j] = alpha[m][i] + sum_{v: f_vi = j} S[m][k][v]   (IMMCTM.jl:199-221).  The topic's statistics row and the feature
+        // table are staged in LDS first (coalesced): the sum(J) threads that fold them walk all V terms each, in term order
+        constexpr int kStage = 1024;
+        __shared__ double sh_row[kStage];
+        __shared__ int sh_feat[4 * kStage];
+        const bool staged = a.gamma_from_stats && Vm <= kStage && nf * Vm <= 4 * kStage;
+        if (staged) {
+            for (int v = tid; v < Vm; v += nt) sh_row[v] = sG[go + k * Vm + v];
+            for (int e = tid; e < nf * Vm; e += nt) sh_feat[e] = feat[e];
+            __syncthreads();
+        }
         if (a.gamma_from_stats) for (int e = tid; e < SJ; e += nt) {
             int jj = e, i = 0;
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
             double s = q.alpha[ao + i];
-            for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
+            if (staged) { for (int v = 0; v < Vm; ++v) if (sh_feat[i * Vm + v] == jj) s += sh_row[v]; }
+            else for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
             q.gamma[mg + k * SJ + e] = s;
         }
         __syncthreads();
@@ -1220,12 +1231,13 @@ __global__ __launch_bounds__(256) void k_ctm_tables_from_Elnphi(CtmDims dm, CtmT
 // llpart[block][M]
 // gauss != 0: the launch carries one extra block (the last) that runs update_μ!/update_Σ! of the same pass -- the ll needs
 // only lambda and phi, the next E-step needs mu / Sigma^-1, so the 50 us single-block inversion hides behind the document sweep
-template <bool TAB_LDS>
+template <bool TAB_LDS, int L>
 __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
                                                         int compute_ll, const int* active, MstepArgs ga, int gauss)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double shw[kWavesS][kMaxM];
+    constexpr int G = MMM_WAVE / L;           // documents per wave: L >= sum K lanes each (coordinates for the softmax, terms for the sweep)
     const CtmDims& dm = c.dm;
     const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
     if (active && !active[blockIdx.y]) return;
@@ -1239,48 +1251,51 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * ndoc_blocks * M;
     if (props) props += (size_t)blockIdx.y * D * MK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
     const double* sP = TAB_LDS ? smem : phieff;                   // [GT]: staged, or (wide tables) read through L2
-    double* sPr = smem + (TAB_LDS ? GT : 0) + wid * 64;           // per-wave props
+    double* sPr = smem + (TAB_LDS ? GT : 0) + wid * 64 + g * L;   // the group's props
     if (TAB_LDS && compute_ll) { for (int i = tid; i < GT; i += kBlockS) smem[i] = phieff[i]; }
     __syncthreads();
     int mod_l = 0;
-    for (int m = 0; m < M; ++m) if (lane >= dm.koff[m] && lane < dm.koff[m + 1]) mod_l = m;
+    for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) mod_l = m;
+    // per-lane partial sums over the lane's terms of all its documents; reduced over the wave once, at the end
     double acc[kMaxM];
     for (int m = 0; m < kMaxM; ++m) acc[m] = 0.0;
-    for (int d = bx * kWavesS + wid; d < D; d += ndoc_blocks * kWavesS) {
-        const bool act = lane < MK;
-        const double x = act ? lam[(size_t)d * MK + lane] : 0.0;
+    for (int base = (bx * kWavesS + wid) * G; base < D; base += ndoc_blocks * kWavesS * G) {
+        const int d = base + g;
+        const bool valid = d < D, act = valid && l < MK;
+        const double x = act ? lam[(size_t)d * MK + l] : 0.0;
         double pr = 0.0;
         for (int m = 0; m < M; ++m) {
             const bool in = act && mod_l == m;
-            const double mx = wave_max(in ? x : -1e300);
+            const double mx = group_max<L>(in ? x : -1e300);
             const double e = in ? exp(x - mx) : 0.0;
-            const double s = wave_sum(e);
+            const double s = group_sum<L>(e);
             if (in) pr = e / s;
         }
-        if (act && props) props[(size_t)d * MK + lane] = pr;
+        if (act && props) props[(size_t)d * MK + l] = pr;
         if (!compute_ll) continue;
         lds_wave_sync();
-        sPr[lane] = pr;
+        sPr[l] = pr;
         lds_wave_sync();
         for (int m = 0; m < M; ++m) {
             const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
             const double* tb = sP + dm.goff[m];
             const int64_t* dp = c.doc_ptr + (size_t)m * (D + 1);
-            const int64_t start = dp[d];
-            const int W = (int)(dp[d + 1] - start);
+            const int64_t start = valid ? dp[d] : 0;
+            const int W = valid ? (int)(dp[d + 1] - start) : 0;
             double a = 0.0;
-            for (int w = lane; w < W; w += MMM_WAVE) {
+            for (int w = l; w < W; w += L) {
                 const int2 t = c.tc[start + w];
                 double p = 0.0;
                 for (int k = 0; k < Km; ++k) p = fma(sPr[off + k], tb[k * Vm + t.x], p);
                 a += (double)t.y * dev_log_pos(p);
             }
-            acc[m] += wave_sum(a);
+            acc[m] += a;
         }
     }
     if (compute_ll) {
-        if (lane == 0) for (int m = 0; m < M; ++m) shw[wid][m] = acc[m];
+        for (int m = 0; m < M; ++m) { const double tot = wave_sum(acc[m]); if (lane == 0) shw[wid][m] = tot; }
         __syncthreads();
         if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)bx * M + tid] = s; }
     }
@@ -1599,6 +1614,12 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             return launch_estep_L<64, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
         }
         if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32>(m, a, lds, grid, waves, nrep);
+        // the topic loops are unrolled to KMX: builds with KMX = 10 / 8 for the BASELINE shapes (K = [10,10,8], [10], [7,7]) instead of 16 --
+        // the padded topics cost instructions (a product, two sums, a select and an exec-masked atomic each), not results
+        static const bool kfit = getenv("MMM_CTM_KMX16") == nullptr;
+        if (kfit && kmax <= 8 && m->L == 16) return launch_estep_L<16, PH, 0, 8>(m, a, lds, grid, waves, nrep);
+        if (kfit && kmax <= 10 && m->L == 16) return launch_estep_L<16, PH, 0, 10>(m, a, lds, grid, waves, nrep);
+        if (kfit && kmax <= 10 && m->L == 32) return launch_estep_L<32, PH, 0, 10>(m, a, lds, grid, waves, nrep);
     }
     if (m->L == 16) return launch_estep_L<16, PH>(m, a, lds, grid, waves, nrep);
     if (m->L == 32) return launch_estep_L<32, PH>(m, a, lds, grid, waves, nrep);
@@ -1722,7 +1743,8 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     const size_t r0 = sc.rep0;
     const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
     const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
-    auto kll = m->wide ? k_ctm_loglik<false> : k_ctm_loglik<true>;
+    auto kll = m->wide ? (m->L == 16 ? k_ctm_loglik<false, 16> : (m->L == 32 ? k_ctm_loglik<false, 32> : k_ctm_loglik<false, 64>))
+                       : (m->L == 16 ? k_ctm_loglik<true, 16> : (m->L == 32 ? k_ctm_loglik<true, 32> : k_ctm_loglik<true, 64>));
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kll, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
                        m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
