@@ -490,10 +490,35 @@ struct CplGeom {
     static_assert(MKT % LPD == 0, "sum K must be a multiple of the lanes per document");
 };
 
+// per-document inputs of a solve (pointers of the launch's replica)
+struct CplDocs {
+    const double* lam_in; double* lam_out; double* nu; const double* zeta; const double* sumth; const double* Ndm;
+    int M;
+};
+
 template <int MKT, int LPD, bool SB>
 struct NuObjC {
     using Gm = CplGeom<MKT, LPD>;
     double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
+    int mod[Gm::CPL], l;
+    // start point and constants of document d (d < 0: an empty slot, harmless values)
+    __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
+    {
+        const size_t row = (size_t)(d < 0 ? 0 : d) * MKT + l * Gm::CPL;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) {
+            x[q] = d < 0 ? 1.0 : dc.nu[row + q];
+            lam[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
+            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + mod[q]], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + mod[q]];
+            c[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
+        }
+    }
+    __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
+    {
+        const size_t row = (size_t)d * MKT + l * Gm::CPL;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) dc.nu[row + q] = x[q];
+    }
     __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
     {
         double s = 0.0;
@@ -512,9 +537,27 @@ template <int MKT, int LPD, bool SB>
 struct LamObjC {
     using Gm = CplGeom<MKT, LPD>;
     double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL], mu[Gm::CPL];
-    int l;
+    int mod[Gm::CPL], l;
     const double* sS;     // padded layout above
-    double* scr;          // group-private LDS, MKT doubles (+1 pad): the differences x - mu of the whole document
+    double* scr;          // group-private LDS, MKT doubles (+ pad): the differences x - mu of the whole document
+    __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
+    {
+        const size_t row = (size_t)(d < 0 ? 0 : d) * MKT + l * Gm::CPL;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) {
+            x[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
+            nu[q] = d < 0 ? 1.0 : dc.nu[row + q];
+            sumth[q] = d < 0 ? 0.0 : dc.sumth[row + q];
+            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + mod[q]], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + mod[q]];
+            c[q] = Nl / zl;
+        }
+    }
+    __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
+    {
+        const size_t row = (size_t)d * MKT + l * Gm::CPL;
+#pragma unroll
+        for (int q = 0; q < Gm::CPL; ++q) dc.lam_out[row + q] = x[q];
+    }
     __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
     {
         double diff[Gm::CPL];
@@ -522,9 +565,6 @@ struct LamObjC {
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - mu[q]; scr[l * Gm::CPL + q] = diff[q]; }
         lds_wave_sync();
-        // the rows of invSigma are read from LDS in every evaluation: without this the compiler hoists all CPL x sum K of them out of
-        // the solver loop into registers (392 VGPRs at sum K = 28) and spills
-        asm volatile("" ::: "memory");
         // Sd_i = sum_j S_ij diff_j with four chains over j, combined pairwise (the association of LamObj::eval)
         double s0[Gm::CPL], s1[Gm::CPL], s2[Gm::CPL], s3[Gm::CPL];
 #pragma unroll
@@ -558,21 +598,27 @@ struct LamObjC {
     }
 };
 
-// NLopt LD_MMA, zero constraints (the algorithm of mma_group, statement: oracle/mmm_oracle.c orc_mma_minimize), LPD lanes per document
+// NLopt LD_MMA, zero constraints (the algorithm of mma_group; statement: oracle/mmm_oracle.c orc_mma_minimize) for the documents
+// [r0, r1) of the calling wave, LPD lanes per document, 64 / LPD document SLOTS.  A slot whose solve stops takes the next
+// document of the range at once (documents finish after very different numbers of evaluations: in lock step a wave would run
+// to its slowest document with the other slots idle -- 1.3-2x the mean at 32 slots); a new document's first evaluation f(x0)
+// rides in the common trip with the candidate point = x0.  Every document goes through exactly the operations of mma_group,
+// whatever its slot and its neighbours.
 template <int MKT, int LPD, bool SB, class Obj>
-__device__ __forceinline__ int mma_cpl(const Obj& obj, bool valid, int lane, double (&x)[CplGeom<MKT, LPD>::CPL], bool has_lb, double lb, const SolveOpts& o)
+__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out)
 {
-    constexpr int CPL = CplGeom<MKT, LPD>::CPL;
-    // xcur doubles as the candidate point: a finished document never looks at it again, so it needs no select-based commit
-    double sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL], xprevprev[CPL];
-    double rho = 1.0;
-    double fbest = obj.eval(x, grad);
+    constexpr int CPL = CplGeom<MKT, LPD>::CPL, G = MMM_WAVE / LPD;
+    const int g = lane / LPD, l = lane % LPD;
+    int d = r0 + g, next = r0 + G;
+    bool have = d < r1, fresh = true;
+    double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL], xprevprev[CPL];
+    double rho = 1.0, fbest = 0.0;
+    int k = 1, nev = 0;
+    obj.load(dc, have ? d : -1, x);
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
-    int k = 1, nev = 1;
-    bool done = !valid, capped = false;
+    for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
-    while (!__all(done)) {
+    while (__any(have)) {
         double gls = 0.0, wls = 0.0;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
@@ -585,6 +631,7 @@ __device__ __forceinline__ int mma_cpl(const Obj& obj, bool valid, int lane, dou
             c = (has_lb && c < lb) ? lb : c;
             const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
             c = c > hi ? hi : (c < lo ? lo : c);
+            c = fresh ? x[q] : c;                   // a new document: evaluate its start point
             xcur[q] = c;
             dx = c - x[q];
             const double dx2 = dx * dx;
@@ -596,16 +643,19 @@ __device__ __forceinline__ int mma_cpl(const Obj& obj, bool valid, int lane, dou
         const double gval = fbest + qsum<LPD>(gls);
         const double wval = qsum<LPD>(wls);
         const double fcur = obj.eval(xcur, gcur);
-        const bool live = !done;
+        const bool live = have && !fresh;
         bool inner_done = live && gval >= fcur;
-        const bool better = live && fcur < fbest;                 // accepted before the cap is looked at, as in mma_group
-        nev += live ? 1 : 0;
-        if (live && nev >= cap) { done = true; capped = true; inner_done = false; }
-        fbest = better ? fcur : fbest;
+        const bool take = fresh || (live && fcur < fbest);        // accepted before the cap is looked at, as in mma_group
+        fbest = take ? fcur : fbest;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { x[q] = better ? xcur[q] : x[q]; grad[q] = better ? gcur[q] : grad[q]; }
-        const bool grow = !done && !inner_done && fcur > gval;
+        for (int q = 0; q < CPL; ++q) { x[q] = take ? xcur[q] : x[q]; grad[q] = take ? gcur[q] : grad[q]; }
+        nev = fresh ? 1 : nev + (live ? 1 : 0);
+        const bool capped = live && nev >= cap;
+        inner_done = inner_done && !capped;
+        fresh = false;
+        const bool grow = live && !capped && !inner_done && fcur > gval;
         if (__any(grow)) { const double rn = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval))); rho = grow ? rn : rho; }
+        bool stopped = false;
         // outer iteration finished in at least one document of this wave: NLopt's x-tolerance test on (xcur, xprev)
         if (__any(inner_done)) {
             bool stop;
@@ -628,21 +678,38 @@ __device__ __forceinline__ int mma_cpl(const Obj& obj, bool valid, int lane, dou
                 }
                 stop = qnone<LPD>(bad, lane);
             }
-            done = done || (inner_done && stop);
-            const bool next = inner_done && !stop;           // this document starts another outer iteration
-            rho = next ? fmax(0.1 * rho, 1e-5) : rho;
+            stopped = inner_done && stop;
+            const bool nxt = inner_done && !stop;           // this document starts another outer iteration
+            rho = nxt ? fmax(0.1 * rho, 1e-5) : rho;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 const double sgn = (xcur[q] - xprev[q]) * (xprev[q] - xprevprev[q]);
-                const double fac = (k > 1) ? (sgn < 0 ? 0.7 : (sgn > 0 ? 1.2 : 1.0)) : 1.0;
-                sigma[q] = next ? sigma[q] * fac : sigma[q];
-                xprevprev[q] = next ? xprev[q] : xprevprev[q];
-                xprev[q] = next ? xcur[q] : xprev[q];
+                const double fac = (nxt && k > 1) ? (sgn < 0 ? 0.7 : (sgn > 0 ? 1.2 : 1.0)) : 1.0;
+                sigma[q] *= fac;
+                xprevprev[q] = nxt ? xprev[q] : xprevprev[q];
+                xprev[q] = nxt ? xcur[q] : xprev[q];
             }
-            k += next ? 1 : 0;
+            k += nxt ? 1 : 0;
+        }
+        const bool finished = have && (stopped || capped);
+        if (__any(finished)) {
+            if (finished) {
+                obj.store(dc, d, x);
+                if (nev_out && l == 0) nev_out[d] = capped ? -nev : nev;
+            }
+            // the finished slots take the next documents of the range, in slot order
+            const unsigned long long fm = __ballot(finished && l == 0);
+            const int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
+            next += __popcll(fm);
+            if (finished) {
+                d = nd; have = nd < r1;
+                obj.load(dc, have ? d : -1, x);
+                rho = 1.0; k = 1; nev = 0; fresh = true;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
+            }
         }
     }
-    return capped ? -nev : nev;
 }
 
 template <int MKT, int LPD, int OCC, bool SB>
@@ -657,11 +724,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     if (a.active && !a.active[rep]) return;
     const double* __restrict__ p_invSigma = a.invSigma + rep * MK * MK;
     const double* __restrict__ p_mu = a.mu + rep * MK;
-    const double* p_lam_in = a.lam_in + rep * D * MK;
-    double* p_lam_out = a.lam_out + rep * D * MK;
-    double* p_nu = a.nu + rep * D * MK;
-    const double* p_zeta = a.zeta + rep * D * M;
-    const double* p_sumth = a.sumth + rep * D * MK;
+    const CplDocs dc{a.lam_in + rep * D * MK, a.lam_out + rep * D * MK, a.nu + rep * D * MK, a.zeta + rep * D * M, a.sumth + rep * D * MK, a.c.Ndm, M};
     int* p_nev_nu = a.nev_nu ? a.nev_nu + rep * D : nullptr;
     int* p_nev_lam = a.nev_lam ? a.nev_lam + rep * D : nullptr;
     const int NW = blockDim.x >> 6;
@@ -675,53 +738,37 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         sS[e] = (q < CPL) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
     }
     __syncthreads();
-    double* scr = sScr + ((size_t)wid * G + g) * (MK + 2);
+    // the wave's documents: a contiguous range
+    const int nwaves = gridDim.x * NW, w = blockIdx.x * NW + wid;
+    const int per = (D + nwaves - 1) / nwaves;
+    const int r0 = min(D, w * per), r1 = min(D, r0 + per);
     int mod_q[CPL];
-    double mu_q[CPL], Sll_q[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         const int i = l * CPL + q;
         int mm = 0;
         for (int m = 0; m < M; ++m) if (i >= dm.koff[m] && i < dm.koff[m + 1]) mm = m;
-        mod_q[q] = mm; mu_q[q] = p_mu[i]; Sll_q[q] = p_invSigma[(size_t)i * MK + i];
+        mod_q[q] = mm;
     }
     const SolveOpts o = a.opt;
-    for (int base = (blockIdx.x * NW + wid) * G; base < D; base += gridDim.x * NW * G) {
-        const int d = base + g;
-        const bool valid = d < D;
-        const size_t row = (size_t)(valid ? d : 0) * MK + l * CPL;
-        double lam[CPL], nu[CPL], sumth[CPL], cl[CPL];
+    // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ -- for every document of the range
+    if (a.flags & F_NU) {
+        NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            lam[q] = valid ? p_lam_in[row + q] : 0.0; nu[q] = valid ? p_nu[row + q] : 1.0; sumth[q] = valid ? p_sumth[row + q] : 0.0;
-            const double Nl = valid ? a.c.Ndm[(size_t)d * M + mod_q[q]] : 0.0, zl = valid ? p_zeta[(size_t)d * M + mod_q[q]] : 1.0;
-            cl[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
-        }
-        // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ
-        if (a.flags & F_NU) {
-            NuObjC<MKT, LPD, SB> obj;
+        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.Sll[q] = p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q]; }
+        obj.l = l;
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu);
+    }
+    // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
+    if (a.flags & F_LAMBDA) {
+        LamObjC<MKT, LPD, SB> obj;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) { obj.lam[q] = lam[q]; obj.c[q] = cl[q]; obj.Sll[q] = Sll_q[q]; }
-            const int nev = mma_cpl<MKT, LPD, SB>(obj, valid, lane, nu, true, o.nu_lower, o);
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) p_nu[row + q] = nu[q];
-                if (p_nev_nu && l == 0) p_nev_nu[d] = nev;
-            }
-        }
-        // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
-        if (a.flags & F_LAMBDA) {
-            LamObjC<MKT, LPD, SB> obj;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) { obj.nu[q] = nu[q]; obj.c[q] = cl[q]; obj.sumth[q] = sumth[q]; obj.mu[q] = mu_q[q]; }
-            obj.l = l; obj.sS = sS; obj.scr = scr;
-            const int nev = mma_cpl<MKT, LPD, SB>(obj, valid, lane, lam, false, 0.0, o);
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) p_lam_out[row + q] = lam[q];
-                if (p_nev_lam && l == 0) p_nev_lam[d] = nev;
-            }
-        }
+        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.mu[q] = p_mu[l * CPL + q]; }
+        obj.l = l; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam);
     }
 }
 
@@ -2042,6 +2089,9 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     }
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
+    // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
+    // slots work through (a finished slot takes the range's next document)
+    if (m->cpl > 1) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 2));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     m->grid_m = std::max(1, std::min((D + 31) / 32, 1024));      // one 32-document tile per block while the reduce stays small
     if (const char* gm = getenv("MMM_CTM_GRID_M")) m->grid_m = std::max(1, atoi(gm));

@@ -71,10 +71,10 @@ AR_FN double ar_exp(double x)
 /* log(x), finite x > 0 (subnormals are scaled up first) */
 AR_FN double ar_log(double x)
 {
-    int eadj = 0;
-    if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; eadj = -54; }          /* 2^54 */
+    const int sub = x < 2.2250738585072014e-308;                                         /* selects, not a branch (see ar_exp) */
+    x = sub ? x * 18014398509481984.0 : x;                                               /* 2^54 */
     const unsigned long long u = AR_BITS(x);
-    int e = (int)((u >> 52) & 0x7ff) - 1022 + eadj;                                      /* x = m 2^e, m in [0.5, 1) */
+    int e = (int)((u >> 52) & 0x7ff) - 1022 + (sub ? -54 : 0);                           /* x = m 2^e, m in [0.5, 1) */
     double m = AR_FROM_BITS((u & 0x000fffffffffffffull) | 0x3fe0000000000000ull);
     const int lo = m < 0.70710678118654752440;
     m = lo ? m + m : m;                                                                  /* m in [sqrt(1/2), sqrt(2)) */
