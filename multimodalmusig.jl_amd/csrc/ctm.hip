@@ -472,6 +472,7 @@ __device__ __forceinline__ double qsum(double v)
 {
     v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]
     if (LPD >= 4) v += dpp_mov_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (LPD >= 8) v += dpp_mov_f64<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half row
     return v;
 }
 
@@ -484,10 +485,11 @@ __device__ __forceinline__ bool qnone(bool pred, int lane)
 
 // invSigma in LDS for this layout: row j (the factor's index), the document's coordinates padded per lane to CPLP = CPL rounded up
 // to even, so that a lane reads its CPL entries of a row as 16-byte pairs: sS[j * (LPD * CPLP) + l * CPLP + c]
+// LPD lanes per document of which ACT = sum K / CPL hold coordinates (sum K = 28: 8 lanes, 7 of them with 4 coordinates each)
 template <int MKT, int LPD>
 struct CplGeom {
-    static constexpr int CPL = MKT / LPD, CPLP = (CPL + 1) & ~1, ROW = LPD * CPLP, G = MMM_WAVE / LPD;
-    static_assert(MKT % LPD == 0, "sum K must be a multiple of the lanes per document");
+    static constexpr int CPL = (MKT + LPD - 1) / LPD, ACT = MKT / CPL, CPLP = (CPL + 1) & ~1, ROW = LPD * CPLP, G = MMM_WAVE / LPD;
+    static_assert(MKT % CPL == 0 && ACT <= LPD, "sum K must be a whole number of lanes of CPL coordinates");
 };
 
 // per-document inputs of a solve (pointers of the launch's replica)
@@ -501,13 +503,16 @@ struct NuObjC {
     using Gm = CplGeom<MKT, LPD>;
     double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
     int mod[Gm::CPL], l;
-    // start point and constants of document d (d < 0: an empty slot, harmless values)
+    bool lane_on, on;      // lane_on: the lane holds coordinates (l < ACT); on: ... of a document
+    // start point and constants of document d (d < 0: an empty slot).  Lanes that are not `on` keep x = 0 and contribute exact zeros.
     __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
     {
+        if (!lane_on) d = -1;
+        on = d >= 0;
         const size_t row = (size_t)(d < 0 ? 0 : d) * MKT + l * Gm::CPL;
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) {
-            x[q] = d < 0 ? 1.0 : dc.nu[row + q];
+            x[q] = d < 0 ? 0.0 : dc.nu[row + q];
             lam[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
             const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + mod[q]], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + mod[q]];
             c[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
@@ -516,8 +521,10 @@ struct NuObjC {
     __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
     {
         const size_t row = (size_t)d * MKT + l * Gm::CPL;
+        if (lane_on) {
 #pragma unroll
-        for (int q = 0; q < Gm::CPL; ++q) dc.nu[row + q] = x[q];
+            for (int q = 0; q < Gm::CPL; ++q) dc.nu[row + q] = x[q];
+        }
     }
     __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
     {
@@ -525,8 +532,11 @@ struct NuObjC {
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) {
             const double E = ar_exp(lam[q] + 0.5 * x[q]);
-            g[q] = 0.5 * Sll[q] + 0.5 * c[q] * E - dev_div(1.0, 2.0 * x[q]);
-            s += 0.5 * x[q] * Sll[q] + c[q] * E - 0.5 * ar_log(x[q]);
+            const bool msk = (Gm::ACT < LPD) ? on : true;        // only layouts with idle lanes need the mask
+            const double gq = 0.5 * Sll[q] + 0.5 * c[q] * E - dev_div(1.0, 2.0 * x[q]);
+            const double tq = 0.5 * x[q] * Sll[q] + c[q] * E - 0.5 * ar_log(x[q]);
+            g[q] = msk ? gq : 0.0;
+            s += msk ? tq : 0.0;
             if (SB) __builtin_amdgcn_sched_barrier(0);
         }
         return qsum<LPD>(s);
@@ -538,10 +548,13 @@ struct LamObjC {
     using Gm = CplGeom<MKT, LPD>;
     double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL], mu[Gm::CPL];
     int mod[Gm::CPL], l;
+    bool lane_on, on;
     const double* sS;     // padded layout above
     double* scr;          // group-private LDS, MKT doubles (+ pad): the differences x - mu of the whole document
     __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
     {
+        if (!lane_on) d = -1;
+        on = d >= 0;
         const size_t row = (size_t)(d < 0 ? 0 : d) * MKT + l * Gm::CPL;
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) {
@@ -555,15 +568,17 @@ struct LamObjC {
     __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
     {
         const size_t row = (size_t)d * MKT + l * Gm::CPL;
+        if (lane_on) {
 #pragma unroll
-        for (int q = 0; q < Gm::CPL; ++q) dc.lam_out[row + q] = x[q];
+            for (int q = 0; q < Gm::CPL; ++q) dc.lam_out[row + q] = x[q];
+        }
     }
     __device__ __forceinline__ double eval(const double (&x)[Gm::CPL], double (&g)[Gm::CPL]) const
     {
         double diff[Gm::CPL];
         lds_wave_sync();
 #pragma unroll
-        for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - mu[q]; scr[l * Gm::CPL + q] = diff[q]; }
+        for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - mu[q]; if (lane_on) scr[l * Gm::CPL + q] = diff[q]; }
         lds_wave_sync();
         // Sd_i = sum_j S_ij diff_j with four chains over j, combined pairwise (the association of LamObj::eval)
         double s0[Gm::CPL], s1[Gm::CPL], s2[Gm::CPL], s3[Gm::CPL];
@@ -590,8 +605,11 @@ struct LamObjC {
         for (int q = 0; q < Gm::CPL; ++q) {
             const double Sd = (s0[q] + s1[q]) + (s2[q] + s3[q]);
             const double E = ar_exp(x[q] + 0.5 * nu[q]);
-            g[q] = Sd - sumth[q] + c[q] * E;
-            s += 0.5 * diff[q] * Sd - x[q] * sumth[q] + c[q] * E;
+            const bool msk = (Gm::ACT < LPD) ? on : true;
+            const double gq = Sd - sumth[q] + c[q] * E;
+            const double tq = 0.5 * diff[q] * Sd - x[q] * sumth[q] + c[q] * E;
+            g[q] = msk ? gq : 0.0;
+            s += msk ? tq : 0.0;
             if (SB) __builtin_amdgcn_sched_barrier(0);
         }
         return qsum<LPD>(s);
@@ -631,7 +649,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
             c = (has_lb && c < lb) ? lb : c;
             const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
             c = c > hi ? hi : (c < lo ? lo : c);
-            c = fresh ? x[q] : c;                   // a new document: evaluate its start point
+            c = (fresh || ((CplGeom<MKT, LPD>::ACT < LPD) && !obj.on)) ? x[q] : c;      // a new document: evaluate its start point; a lane without coordinates stays at 0
             xcur[q] = c;
             dx = c - x[q];
             const double dx2 = dx * dx;
@@ -730,12 +748,13 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / LPD, l = lane % LPD;
+    const bool lane_on = (Gm::ACT == LPD) ? true : l < Gm::ACT;
     // LDS: [MK rows][ROW] invSigma (padded) | [NW][G][MK + 2] difference vectors
     double* sS = smem;
     double* sScr = sS + MK * Gm::ROW;
     for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
         const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
-        sS[e] = (q < CPL) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
+        sS[e] = (q < CPL && ll < Gm::ACT) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
     }
     __syncthreads();
     // the wave's documents: a contiguous range
@@ -755,8 +774,8 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     if (a.flags & F_NU) {
         NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.Sll[q] = p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q]; }
-        obj.l = l;
+        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0; }
+        obj.l = l; obj.lane_on = lane_on;
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu);
     }
     // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
@@ -766,8 +785,8 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.mu[q] = p_mu[l * CPL + q]; }
-        obj.l = l; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
+        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.mu[q] = lane_on ? p_mu[l * CPL + q] : 0.0; }
+        obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam);
     }
 }
@@ -1635,7 +1654,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             // builds: 2 waves per SIMD, chains of the coordinates interleaved by the scheduler (sum K = 10: 245 VGPRs, no scratch; 263 us at
             // config 5 against 323 us for the 3-wave build with one coordinate at a time); sum K = 14 / 28: the 2-wave builds with scheduling barriers
             if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
-            if (m->dm.MK == 28 && m->Ls == 4) return go(k_ctm_solve_cpl<28, 4, 2, true>);
+            if (m->dm.MK == 28 && m->Ls == 8) return go(k_ctm_solve_cpl<28, 8, 2, false>);
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
             return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
         }
@@ -2075,15 +2094,15 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         const char* pe = getenv("MMM_CTM_PACK");
         const bool allow = !pe || atoi(pe) != 0;
         if (allow && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
-        // several coordinates per lane (k_ctm_solve_cpl): sum K = 10 -> 2 lanes x 5 coordinates (32 documents per wave; BASELINE config 5:
-        // solve phase 334 -> 263 us).  Builds for sum K = 14 (2 x 7) and 28 (4 x 7) exist but lose to one coordinate per lane there
-        // (config 4: 1105-1235 vs 729 us -- 1-2 waves per SIMD cannot hide the chains of 7 coordinates); MMM_CTM_CPL=2 selects them
-        // (tests, A/B), MMM_CTM_CPL=0 switches the path off.
+        // several coordinates per lane (k_ctm_solve_cpl): sum K = 10 -> 2 lanes x 5 coordinates (32 document slots per wave; BASELINE config 5:
+        // solve phase 334 -> 263 us).  Builds for sum K = 14 (2 x 7) and 28 (8 lanes, 7 of them x 4) exist but do not beat one coordinate per
+        // lane there (config 4: 762 vs 726 us; a 4 x 7 build: 1105 us -- two waves per SIMD do not hide the chains of 4-7 coordinates as
+        // four waves with one coordinate each do); MMM_CTM_CPL=2 selects them (tests, A/B), MMM_CTM_CPL=0 switches the path off.
         const char* ce = getenv("MMM_CTM_CPL");
         const int cmode = ce ? atoi(ce) : 1;
         if (cmode != 0) {
             if (dm.MK == 10) { m->Ls = 2; m->cpl = 5; }
-            else if (cmode == 2 && dm.MK == 28) { m->Ls = 4; m->cpl = 7; }
+            else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
         }
     }

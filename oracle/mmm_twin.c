@@ -112,10 +112,12 @@ static double tw_sum(const tw_obj* o, const double* t)
 {
     if (o->cpl > 1) {
         double part[64];
-        const int lpd = o->n / o->cpl;
+        const int act = o->n / o->cpl;          /* lanes that hold coordinates; the document's remaining lanes contribute 0 */
+        int lpd = 1;
+        while (lpd < act) lpd <<= 1;
         for (int l = 0; l < lpd; ++l) {
             double s = 0.0;
-            for (int q = 0; q < o->cpl; ++q) s += t[l * o->cpl + q];
+            if (l < act) for (int q = 0; q < o->cpl; ++q) s += t[l * o->cpl + q];
             part[l] = s;
         }
         return tw_group_sum(part, lpd);
