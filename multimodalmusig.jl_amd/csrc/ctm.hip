@@ -616,7 +616,7 @@ struct LamObjC {
     }
 };
 
-// NLopt LD_MMA, zero constraints (the algorithm of mma_group; statement: oracle/mmm_oracle.c orc_mma_minimize) for the documents
+// NLopt LD_MMA, zero constraints (the algorithm of mma_group; statement: DESIGN.md "MMA" and SURVEY.md section 7) for the documents
 // [r0, r1) of the calling wave, LPD lanes per document, 64 / LPD document SLOTS.  A slot whose solve stops takes the next
 // document of the range at once (documents finish after very different numbers of evaluations: in lock step a wave would run
 // to its slowest document with the other slots idle -- 1.3-2x the mean at 32 slots); a new document's first evaluation f(x0)
