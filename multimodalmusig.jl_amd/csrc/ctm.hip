@@ -1668,7 +1668,8 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
         }
         if (m->L == 16 && m->dm.MK == 10) return small ? launch_estep_L<16, PH, 10, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
         if (m->L == 16 && m->dm.MK == 14) return small ? launch_estep_L<16, PH, 14, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
-        if (m->L == 32 && m->dm.MK == 28) return launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
+        static const bool occ3 = getenv("MMM_CTM_OCC3") != nullptr;
+        if (m->L == 32 && m->dm.MK == 28) return (small || occ3) ? launch_estep_L<32, PH, 28, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
     }
     if constexpr (PH == 0) {      // theta phase: a modality with more than 16 topics takes the build unrolled to 32
         int kmax = 0;
