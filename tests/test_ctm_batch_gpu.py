@@ -31,10 +31,14 @@ def _make(mmm, K, V, X, g0, feats, restarts=None, **kw):
 FIELDS = ["mu", "Sigma", "invSigma", "gamma", "Elnphi", "lambda", "nu", "zeta", "props", "theta"]
 
 
-@pytest.mark.parametrize("case", ["mm", "imm"])
+@pytest.mark.parametrize("case", ["mm", "imm", "imm10", "mm66"])
 def test_batched_fit_is_bitwise_the_single_model_fit(mmm, case):
     if case == "mm":
         D, K, V, means, feats = 70, [5, 4], [40, 24], [600, 80], None
+    elif case == "imm10":       # sum K = 10: the several-coordinates-per-lane solve kernel (persistent waves, slot refill) with replicas on grid.y
+        D, K, V, means, feats = 150, [10], [96], [1500], SNV3
+    elif case == "mm66":        # sum K = 12: the packed solve groups
+        D, K, V, means, feats = 70, [6, 6], [40, 24], [600, 80], None
     else:
         D, K, V, means, feats = 50, [6], [96], [1500], SNV3
     R = 4
