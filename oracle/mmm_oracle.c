@@ -1222,13 +1222,18 @@ int orc_ctm_infer(orc_ctm* m, int flags, int maxiter, double tol, double* ll_his
 {
     *converged = 0; int it = 0;
     for (int iter = 1; iter <= maxiter; ++iter) {
-        for (int d = 0; d < m->D; ++d) {
-            orc_ctm_update_zeta(m, d);
-            if (flags & 1) orc_ctm_unsmoothed_update_theta(m, d); else orc_ctm_update_theta(m, d);
-            orc_ctm_update_nu(m, d);
-            orc_ctm_update_lambda(m, d);
+        if (m->arith) {                                   /* the same steps in device order (mmm_twin.c) */
+            if (iter == 1) orc_twin_tables_from_Elnphi(m);
+            orc_twin_infer_pass(m, flags);
+        } else {
+            for (int d = 0; d < m->D; ++d) {
+                orc_ctm_update_zeta(m, d);
+                if (flags & 1) orc_ctm_unsmoothed_update_theta(m, d); else orc_ctm_update_theta(m, d);
+                orc_ctm_update_nu(m, d);
+                orc_ctm_update_lambda(m, d);
+            }
+            if (flags & 2) { orc_ctm_update_mu(m); orc_ctm_update_Sigma(m); }
         }
-        if (flags & 2) { orc_ctm_update_mu(m); orc_ctm_update_Sigma(m); }
         if (!m->n_feat) orc_ctm_update_props(m);
         orc_ctm_loglik(m, ll_hist + (size_t)m->M * it); ++it;
         if (it > 10) {

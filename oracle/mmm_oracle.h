@@ -153,6 +153,8 @@ void orc_twin_estep(orc_ctm* m, double* sG);
 void orc_twin_moments(const orc_ctm* m, double* mom);
 int  orc_twin_gauss(orc_ctm* m, const double* mom, int do_sigma);
 int  orc_twin_pass(orc_ctm* m, int update_sigma);
+void orc_twin_tables_from_Elnphi(orc_ctm* m);
+int  orc_twin_infer_pass(orc_ctm* m, int flags);
 void orc_twin_objectives(int n, const double* lambda, const double* nu, const double* Ndivzeta, const double* sumtheta,
                          const double* mu, const double* invSigma, double* vals, double* grad_lambda, double* grad_nu);
 void orc_ar_exp_vec(int n, const double* x, double* out);

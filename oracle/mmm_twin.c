@@ -500,6 +500,45 @@ int orc_twin_gauss(orc_ctm* m, const double* mom, int do_sigma)
     return singular ? -2 : 0;
 }
 
+/* exp table of the theta phase from UPLOADED Elnphi (fit_heldout copies gamma and Elnphi, MMCTM.jl:561-562): k_ctm_tables_from_Elnphi */
+void orc_twin_tables_from_Elnphi(orc_ctm* m)
+{
+    for (int mod = 0; mod < m->M; ++mod) {
+        const int Km = m->K[mod], Vm = m->V[mod], go = tw_goff(m, mod);
+        for (int k = 0; k < Km; ++k) {
+            if (!m->n_feat) {
+                for (int v = 0; v < Vm; ++v) m->expE[go + k * Vm + v] = ar_exp(m->Elnphi[go + (size_t)k * Vm + v]);
+            } else {
+                const int SJ = tw_SJ(m, mod), nf = m->n_feat[mod], ao = tw_aoff(m, mod);
+                const size_t mg = tw_mgoff(m, mod);
+                const int32_t* feat = m->features + tw_foff(m, mod);
+                for (int v = 0; v < Vm; ++v) {
+                    double se = 0.0; int jo = 0;
+                    for (int i = 0; i < nf; ++i) { se += m->Elnphi[mg + (size_t)k * SJ + jo + feat[(size_t)i * Vm + v]]; jo += m->J[ao + i]; }
+                    m->expE[go + k * Vm + v] = ar_exp(se);
+                }
+            }
+        }
+    }
+}
+
+/* one frozen-topic pass in device order: the document loop of transform (flags & 1: theta from phi instead of exp(Elnphi),
+ * MMCTM.jl:496-509, 521-528) or of fit_heldout / predict_modality_eta (MMCTM.jl:565-569), optionally update_mu! / update_Sigma!
+ * (flags & 2, :530-533).  The exp table must be current (orc_twin_tables_from_Elnphi). */
+int orc_twin_infer_pass(orc_ctm* m, int flags)
+{
+    const int GT = tw_GT(m), n = m->MK;
+    double* sG = (double*)malloc(sizeof(double) * ((size_t)GT + 2 * n + (size_t)n * n));
+    double* keep = m->expE;
+    if (flags & 1) m->expE = m->phi;                    /* MMCTM: phi has the effective [m][k][v] layout */
+    orc_twin_estep(m, sG);
+    m->expE = keep;
+    int rc = 0;
+    if (flags & 2) { orc_twin_moments(m, sG + GT); rc = orc_twin_gauss(m, sG + GT, 1); }
+    free(sG);
+    return rc;
+}
+
 /* one pass of fit! up to and including update_γ!/Elnϕ! (MMCTM.jl:462-471), device order */
 int orc_twin_pass(orc_ctm* m, int update_sigma)
 {

@@ -120,6 +120,8 @@ def lib():
     L.orc_twin_moments.argtypes = [P, f64p]
     L.orc_twin_gauss.argtypes = [P, f64p, C.c_int]; L.orc_twin_gauss.restype = C.c_int
     L.orc_twin_pass.argtypes = [P, C.c_int]; L.orc_twin_pass.restype = C.c_int
+    L.orc_twin_tables_from_Elnphi.argtypes = [P]
+    L.orc_twin_infer_pass.argtypes = [P, C.c_int]; L.orc_twin_infer_pass.restype = C.c_int
     L.orc_twin_objectives.argtypes = [C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
     for name in ("exp", "log", "digamma"):
         getattr(L, "orc_ar_%s_vec" % name).argtypes = [C.c_int, f64p, f64p]

@@ -104,12 +104,28 @@ def _ctm_trained(mmm, oracle, feats=None, seed=21):
     return g, o, Xn, K, V, alpha
 
 
-def _fresh_oracle(oracle, o, Xn, K, V, alpha, feats=None, mods=None):
+def _fresh_oracle(oracle, o, Xn, K, V, alpha, feats=None, mods=None, geometry=None):
+    """geometry (of the device handle that ran the same inference): the order-matched variant, which the device must equal bit for bit"""
     mods = list(range(len(K))) if mods is None else mods
     Km = [K[m] for m in mods]
     if feats is None:
-        return oracle.CtmOracle(Km, [alpha[m] for m in mods], Xn, V=[V[m] for m in mods], seed=5)
-    return oracle.CtmOracle(Km, [alpha[m] for m in mods], Xn, features=[feats[m] for m in mods], seed=5)
+        return oracle.CtmOracle(Km, [alpha[m] for m in mods], Xn, V=[V[m] for m in mods], seed=5, geometry=geometry)
+    return oracle.CtmOracle(Km, [alpha[m] for m in mods], Xn, features=[feats[m] for m in mods], seed=5, geometry=geometry)
+
+
+def _same_bits(a, b, what):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel(); b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    n = int((a.view(np.int64) != b.view(np.int64)).sum())
+    assert n == 0, "%s: %d of %d values differ in their bits" % (what, n, a.size)
+
+
+def _cmp_docs_exact(gn, on):
+    """against the order-matched oracle: the documents' state in every bit, evaluation counts of the last pass equal"""
+    D = on.D
+    _same_bits(gn.lam_matrix(), on.lam, "lambda"); _same_bits(gn.nu_matrix(), on.nu, "nu"); _same_bits(gn._get("zeta"), on.zeta, "zeta")
+    np.testing.assert_allclose(gn._get("theta"), on.theta, rtol=1e-12, atol=1e-300)
+    st = gn.solver_stats(per_doc=True)
+    assert np.array_equal(st["per_doc_nu"], on.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], on.nev_lambda[:D])
 
 
 def _cmp_docs(gn, on, first_pass):
@@ -147,6 +163,16 @@ def test_mmctm_transform(mmm, oracle, fit_gaussian):
         _cmp_docs(gn, on, first)
         if first:
             np.testing.assert_allclose(gn._get("props"), on.props, rtol=1e-6, atol=1e-9)
+        # the same inference by the order-matched oracle: bit-identical
+        ot = _fresh_oracle(oracle, o, Xn, K, V, alpha, geometry=gn.geometry())
+        ot.phi[:] = o.phi; ot.Elnphi[:] = o.Elnphi
+        if not fit_gaussian:
+            ot.mu[:] = o.mu; ot.Sigma[:] = o.Sigma
+        ll_t = ot.infer(flags, maxiter, 1e-9)
+        np.testing.assert_allclose(gn.ll_history, ll_t, rtol=1e-10)
+        _cmp_docs_exact(gn, ot)
+        if fit_gaussian:
+            _same_bits(gn.μ, ot.mu, "mu"); _same_bits(np.asarray(gn.invΣ).ravel(order="F"), ot.invSigma, "invSigma")
         MK = sum(K)
         if fit_gaussian:
             # 60 documents: one document whose MMA solve stopped an iteration apart (|Δλ| < 2e-3, test_ctm_gpu.py docstring)
@@ -179,6 +205,15 @@ def test_fit_heldout_ctm(mmm, oracle, case):
         assert gn.converged == on.converged and gn.ll_history.shape == ll_o.shape
         np.testing.assert_allclose(gn.ll_history, ll_o, rtol=1e-6 if first else 1e-5)   # after an MMA solve: x-tolerance level, not round-off
         _cmp_docs(gn, on, first)
+        # the same inference by the order-matched oracle: bit-identical
+        ot = _fresh_oracle(oracle, o, Xn, K, V, alpha, feats=feats, geometry=gn.geometry())
+        ot.mu[:] = o.mu; ot.Sigma[:] = o.Sigma; ot.invSigma[:] = o.invSigma; ot.gamma[:] = o.gamma; ot.Elnphi[:] = o.Elnphi
+        if feats is None:
+            ot.phi[:] = o.phi
+        ll_t = ot.infer(0, maxiter, 1e-4)
+        assert gn.converged == ot.converged and gn.ll_history.shape == ll_t.shape
+        np.testing.assert_allclose(gn.ll_history, ll_t, rtol=1e-10)
+        _cmp_docs_exact(gn, ot)
         gn.close()
 
 
