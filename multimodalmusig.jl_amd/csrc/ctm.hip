@@ -389,21 +389,35 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
                     double av[KMX], acc[KMX];
 #pragma unroll
                     for (int k = 0; k < KMX; ++k) { av[k] = (k < Km) ? scr[off + k] : 0.0; acc[k] = 0.0; }
-                    for (int w0 = 0; __any(w0 < W); w0 += L) {
+                    // the document's (term,count) pairs of this modality: the first PRE chunks are requested together, before the
+                    // first chunk computes (one memory latency per document and modality instead of one per chunk)
+                    // (32-lane groups: three chunks cover a 96-term document -- cfg 4 theta phase 138 -> 131 us; with 16-lane groups the six
+                    // chunk registers cost the fourth wave per SIMD and the phase got slower, 64 -> 83 us at cfg 5: one chunk there)
+                    constexpr int PRE = L >= 32 ? (96 / L > 0 ? 96 / L : 1) : 1;
+                    int2 tcp[PRE];
+#pragma unroll
+                    for (int j = 0; j < PRE; ++j) { const int w = j * L + l; tcp[j] = (w < W) ? a.c.tc[start + w] : make_int2(-1, 0); }
+                    int j = 0;
+                    for (int w0 = 0; __any(w0 < W); w0 += L, ++j) {
                         const int w = w0 + l;
-                        const bool aw = w < W;
-                        const int2 tcv = aw ? a.c.tc[start + w] : make_int2(0, 0);
+                        int2 tcv = tcp[0];
+#pragma unroll
+                        for (int q = 1; q < PRE; ++q) tcv = (j == q) ? tcp[q] : tcv;
+                        if (j >= PRE) tcv = (w < W) ? a.c.tc[start + w] : make_int2(-1, 0);
+                        const bool aw = tcv.x >= 0;
+                        tcv.x = aw ? tcv.x : 0;
                         const double n = (double)tcv.y;
                         double e[KMX], s = 0.0;
 #pragma unroll
                         for (int k = 0; k < KMX; ++k) { e[k] = (k < Km) ? av[k] * tb[k * Vm + tcv.x] : 0.0; s += e[k]; }
                         const double inv = aw ? 1.0 / s : 0.0;
                         const double r = n * inv;
+                        double pn[KMX];
 #pragma unroll
-                        for (int k = 0; k < KMX; ++k) {
-                            const double pn = e[k] * r;
-                            acc[k] += pn;
-                            if (aw && k < Km) unsafeAtomicAdd(&myslab[k * Vm + tcv.x], pn);
+                        for (int k = 0; k < KMX; ++k) { pn[k] = e[k] * r; acc[k] += pn[k]; }
+                        if (aw) {
+#pragma unroll
+                            for (int k = 0; k < KMX; ++k) if (k < Km) unsafeAtomicAdd(&myslab[k * Vm + tcv.x], pn[k]);
                         }
                     }
                     double st = 0.0;
