@@ -410,7 +410,9 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
                         double e[KMX], s = 0.0;
 #pragma unroll
                         for (int k = 0; k < KMX; ++k) { e[k] = (k < Km) ? av[k] * tb[k * Vm + tcv.x] : 0.0; s += e[k]; }
-                        const double inv = aw ? 1.0 / s : 0.0;
+                        // s = sum_k a_k exp(Elnphi_kv): one a_k is 1 and Elnphi >= psi(alpha) - psi(sum gamma), so s is far inside the normal
+                        // range, where dev_div is the correctly rounded quotient (8 instructions instead of the ~25 of the general sequence)
+                        const double inv = aw ? dev_div(1.0, s) : 0.0;
                         const double r = n * inv;
                         double pn[KMX];
 #pragma unroll
@@ -994,15 +996,16 @@ __global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double
     // up to 4 output entries per thread (n <= 2*64 + 64*64 needs more: loop)
     for (int e0 = 0; e0 < n; e0 += 4 * blockDim.x) {
         double acc[4] = {0, 0, 0, 0};
-        // what each of this thread's entries reads: two LDS columns (a, b); kind 0: sum a (lambda or nu tile), 1: sum a*b
-        const double* pa[4]; const double* pb[4]; int kind[4];
+        // what each of this thread's entries reads: two LDS columns (a, b) as OFFSETS into smem (pointers picked from sL / sN at run time
+        // lose their address space: the loop's reads became flat loads through the vector-memory path, 473 per wave); kind 0: sum a, 1: sum a*b
+        int oa[4], ob[4], kind[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = e0 + q * blockDim.x + threadIdx.x;
-            kind[q] = -1; pa[q] = sL; pb[q] = sL;
-            if (e < MK) { kind[q] = 0; pa[q] = sL + e; }
-            else if (e < 2 * MK) { kind[q] = 0; pa[q] = sN + (e - MK); }
-            else if (e < n) { kind[q] = 1; pa[q] = sL + (e - 2 * MK) % MK; pb[q] = sL + (e - 2 * MK) / MK; }
+            kind[q] = -1; oa[q] = 0; ob[q] = 0;
+            if (e < MK) { kind[q] = 0; oa[q] = e; }
+            else if (e < 2 * MK) { kind[q] = 0; oa[q] = T * MK + (e - MK); }
+            else if (e < n) { kind[q] = 1; oa[q] = (e - 2 * MK) % MK; ob[q] = (e - 2 * MK) / MK; }
         }
         for (int t0 = d0; t0 < d1; t0 += T) {
             const int nt = min(T, d1 - t0);
@@ -1017,15 +1020,15 @@ __global__ __launch_bounds__(256) void k_ctm_moments(int D, int MK, const double
             for (int q = 0; q < 4; ++q) {
                 if (kind[q] < 0) continue;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // independent chains: the LDS reads pipeline
-                const double* A = pa[q]; const double* B = pb[q];
+                const int A = oa[q], B = ob[q];
                 if (kind[q] == 0) {
 #pragma unroll 2
-                    for (int d = 0; d < T; d += 4) { s0 += A[d * MK]; s1 += A[(d + 1) * MK]; s2 += A[(d + 2) * MK]; s3 += A[(d + 3) * MK]; }
+                    for (int d = 0; d < T; d += 4) { s0 += smem[A + d * MK]; s1 += smem[A + (d + 1) * MK]; s2 += smem[A + (d + 2) * MK]; s3 += smem[A + (d + 3) * MK]; }
                 } else {
 #pragma unroll 2
                     for (int d = 0; d < T; d += 4) {
-                        s0 = fma(A[d * MK], B[d * MK], s0); s1 = fma(A[(d + 1) * MK], B[(d + 1) * MK], s1);
-                        s2 = fma(A[(d + 2) * MK], B[(d + 2) * MK], s2); s3 = fma(A[(d + 3) * MK], B[(d + 3) * MK], s3);
+                        s0 = fma(smem[A + d * MK], smem[B + d * MK], s0); s1 = fma(smem[A + (d + 1) * MK], smem[B + (d + 1) * MK], s1);
+                        s2 = fma(smem[A + (d + 2) * MK], smem[B + (d + 2) * MK], s2); s3 = fma(smem[A + (d + 3) * MK], smem[B + (d + 3) * MK], s3);
                     }
                 }
                 acc[q] += (s0 + s1) + (s2 + s3);
@@ -2194,7 +2197,11 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     // slots work through (a finished slot takes the range's next document)
     if (m->cpl > 1) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 2));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
-    m->grid_m = std::max(1, std::min((D + 31) / 32, 1024));      // one 32-document tile per block while the reduce stays small
+    // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks
+    {
+        const int tiles_per_block = std::max(1, (D + 32 * 1024 - 1) / (32 * 1024));
+        m->grid_m = std::max(1, (D + 32 * tiles_per_block - 1) / (32 * tiles_per_block));
+    }
     if (const char* gm = getenv("MMM_CTM_GRID_M")) m->grid_m = std::max(1, atoi(gm));
     const size_t MK = dm.MK, DMK = (size_t)D * MK, Rz = (size_t)R;
     m->nmom = 2 * dm.MK + dm.MK * dm.MK; m->nalpha = nalpha;
