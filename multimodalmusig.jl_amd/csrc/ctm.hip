@@ -293,6 +293,9 @@ struct CtmEArgs {
     SolveOpts opt;
     int flags;
     const int* active;      // batched launches (grid.y = replicas): per-replica activity flags, may be NULL
+    // fused pass (F_SLAB): the theta phase also keeps lambda_{t-1} and the exp table of this pass (theta_t is rebuilt from them on
+    // demand) -- it reads both anyway, which saves the copy launch.  Base of replica 0, may be NULL.
+    double* lam_keep; double* expE_keep;
 };
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
             double* scr = sScr + ((size_t)wid * G + g) * 2 * L;      // a_k of the group's document
             int ml = 0;
             for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) ml = m;
+            if (a.expE_keep && blockIdx.x == 0) for (int i = tid; i < GT; i += blockDim.x) a.expE_keep[rep * GT + i] = sB[i];
             for (int m = 0; m < M; ++m) {
                 const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
                 for (int i = lane; i < Km * Vm; i += MMM_WAVE) myslab[i] = 0.0;
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
                     const bool valid = d < D;
                     const bool act = valid && l < MK, mine = act && ml == m;
                     const double lam = act ? p_lam_in[(size_t)d * MK + l] : 0.0;
+                    if (m == 0 && a.lam_keep && act) a.lam_keep[(rep * D + d) * MK + l] = lam;
                     if (m == 0 && (flags & F_ZETA)) {       // update_ζ! (MMCTM.jl:172-181), once per document
                         const double nu = act ? p_nu[(size_t)d * MK + l] : 1.0;
                         const double E = act ? ar_exp(lam + 0.5 * nu) : 0.0;
@@ -1778,7 +1783,8 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
 }
 
 // lam_in / expE: per-replica arrays (base of replica 0); lam_out likewise (may alias lam_in: in-place update)
-int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam_out, const double* expE)
+int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam_out, const double* expE, double* lam_keep = nullptr,
+              double* expE_keep = nullptr)
 {
     const CtmDims& dm = m->dm;
     const size_t r0 = sc.rep0, DMK = m->sDMK(), MK = dm.MK;
@@ -1786,7 +1792,8 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
                lam_out ? lam_out + r0 * DMK : nullptr, m->nu.p + r0 * DMK, m->zeta.p + r0 * dm.D * dm.M,
                (flags & (F_THETA_STORED | F_THETA_STORE)) ? m->theta.p : nullptr, m->sumth.p + r0 * DMK,
                m->wide ? nullptr : m->partial.p + r0 * m->grid_e * dm.GT, m->wide ? m->aexp.p + r0 * dm.D * MK : nullptr,
-               m->nev_nu.p + r0 * dm.D, m->nev_lam.p + r0 * dm.D, m->opt, flags, sc.active};
+               m->nev_nu.p + r0 * dm.D, m->nev_lam.p + r0 * dm.D, m->opt, flags, sc.active,
+               lam_keep ? lam_keep + r0 * DMK : nullptr, expE_keep ? expE_keep + r0 * dm.GT : nullptr};
     int rc;
     if (flags & (F_ZETA | F_THETA_COMPUTE | F_THETA_STORED | F_SLAB)) {
         const size_t lds = estep_lds(m, flags);
@@ -1984,10 +1991,12 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     mmm_ctx* ctx = m->ctx;
     const CtmDims& dm = m->dm;
     int rc;
-    // keep lambda_{t-1} and the exp table of this pass: theta_t is rebuilt from them on demand
-    if ((rc = copy2_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK(), m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
+    // keep lambda_{t-1} and the exp table of this pass (theta_t is rebuilt from them on demand): the theta phase writes them beside its
+    // own reads; the wide-table path has no such hook and copies
+    if (m->wide && (rc = copy2_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK(), m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
     // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
-    rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p);
+    rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p,
+                   m->wide ? nullptr : m->lambda_prev.p, m->wide ? nullptr : m->expEeff_prev.p);
     if (rc) return rc;
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
     const size_t r0 = sc.rep0;
