@@ -141,6 +141,11 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7]);   /* calculate_elbo
  * to an internal device history; read it with mmm_lda_ll_history. */
 int mmm_lda_iterate(mmm_lda* m, int n_iter);
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n);
+/* Which E-step build the handle uses and its launch geometry (diagnostics, tests): out[0] = lanes per document, [1] = blocks,
+ * [2] = waves per block, [3] = 1 for the single-step build (small corpora: the grid covers every document at once), [4] = 1 for
+ * the wide-table path (tables beyond LDS), [5] = 1 for the dense-row build (dense corpus over <= 128 terms: rows of counts,
+ * statistics accumulated in registers), [6] = its term slots per lane, [7] = topics padded to. */
+int mmm_lda_geometry(const mmm_lda* m, int out[8]);
 /* fit!(model; maxiter, tol) -- LDA.jl:198-224: iterate until |dll|/|ll| < tol after > 10 passes, then ELBO. */
 int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged,
                 double* elbo);

@@ -559,6 +559,8 @@ __device__ __forceinline__ double qsum(double v)
     v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]
     if (LPD >= 4) v += dpp_mov_f64<0x4E>(v);        // quad_perm [2,3,0,1]
     if (LPD >= 8) v += dpp_mov_f64<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half row
+    if (LPD >= 16) v += dpp_mov_f64<0x140>(v);      // row_mirror
+    if (LPD >= 32) v += __shfl_xor(v, 16, MMM_WAVE);
     return v;
 }
 
@@ -566,7 +568,7 @@ template <int LPD>
 __device__ __forceinline__ bool qnone(bool pred, int lane)
 {
     const unsigned long long b = __ballot(pred);
-    return ((b >> (lane & ~(LPD - 1))) & ((1ull << LPD) - 1ull)) == 0ull;
+    return ((b >> (lane & ~(LPD - 1))) & ((LPD >= 64 ? 0ull : (1ull << (LPD & 63))) - 1ull)) == 0ull;
 }
 
 // invSigma in LDS for this layout: row j (the factor's index), the document's coordinates padded per lane to CPLP = CPL rounded up
@@ -574,7 +576,7 @@ __device__ __forceinline__ bool qnone(bool pred, int lane)
 // LPD lanes per document of which ACT = sum K / CPL hold coordinates (sum K = 28: 8 lanes, 7 of them with 4 coordinates each)
 template <int MKT, int LPD>
 struct CplGeom {
-    static constexpr int CPL = (MKT + LPD - 1) / LPD, ACT = MKT / CPL, CPLP = (CPL + 1) & ~1, ROW = LPD * CPLP, G = MMM_WAVE / LPD;
+    static constexpr int CPL = (MKT + LPD - 1) / LPD, ACT = MKT / CPL, CPLP = CPL == 1 ? 1 : (CPL + 1) & ~1, ROW = LPD * CPLP, G = MMM_WAVE / LPD;
     static_assert(MKT % CPL == 0 && ACT <= LPD, "sum K must be a whole number of lanes of CPL coordinates");
 };
 
@@ -1655,6 +1657,7 @@ struct mmm_ctm {
     int L = 64, GM = 0 /* model-layout gamma size */;
     int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 12), or 2 / 4 (cpl > 1)
     int cpl = 1;                   // coordinates per lane in the solve phase (k_ctm_solve_cpl: sum K = 10, 14, 28)
+    bool persist = false;          // solve phase by k_ctm_solve_cpl (persistent waves, document slots refilled): cpl > 1, or cpl = 1 with Ls = L
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
     double Dglobal = 0;
@@ -1719,8 +1722,8 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 
 size_t solve_lds(const mmm_ctm* m)
 {
-    if (m->cpl > 1) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
-        const int cplp = (m->cpl + 1) & ~1;
+    if (m->persist) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
+        const int cplp = m->cpl == 1 ? 1 : (m->cpl + 1) & ~1;
         return sizeof(double) * ((size_t)m->dm.MK * m->Ls * cplp + (size_t)m->waves_s * (MMM_WAVE / m->Ls) * (m->dm.MK + 2));
     }
     const int scrw = m->Ls != m->L ? (MMM_WAVE / m->Ls + 1) * 2 * m->Ls : 2 * MMM_WAVE;
@@ -1732,7 +1735,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
 {
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
         const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
-        if (m->cpl > 1) {          // several coordinates per lane
+        if (m->persist) {          // persistent waves with refilled document slots (several coordinates per lane, or one)
             mmm_ctx* ctx = m->ctx;
             auto go = [&](auto kern) -> int {
                 if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1745,6 +1748,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
             if (m->dm.MK == 28 && m->Ls == 8) return go(k_ctm_solve_cpl<28, 8, 2, false>);
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
+            if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
             return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
         }
         if (m->Ls != m->L) {       // packed groups: sum K lanes per document
@@ -2198,13 +2202,15 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             if (dm.MK == 10) { m->Ls = 2; m->cpl = 5; }
             else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
+            else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
+            if (m->cpl > 1) m->persist = true;
         }
     }
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
     // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
     // slots work through (a finished slot takes the range's next document)
-    if (m->cpl > 1) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 2));
+    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * (m->cpl > 1 ? 2 : 4)));
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks
     {

@@ -50,6 +50,8 @@ struct LdaDev {
     double alpha, eta;
     const int2* ell;      // [D][V] rows padded with (-1, 0), or NULL: lets the ll blocks fetch a document's terms without first
                           // waiting for doc_ptr (built when V <= 128 and no document lists a term twice)
+    const int* dense;     // [D][Vp] rows of counts (the dense-row E-step's corpus), or NULL; the ll blocks then read these instead of ell
+    int Vp;
 };
 
 struct LdaCtl {
@@ -367,6 +369,148 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     MMM_STAMP(7);
 }
 
+
+// ---- dense-row E-step (large corpora over a small vocabulary) ---------------------------------------------------------------------
+// The corpora this model is used on are dense: mutation catalogues over the 96 SNV channels list nearly every channel in every sample
+// (data/brca-eu_snv_counts.tsv: 53,559 of 53,760 entries).  For such a corpus the CSR sweep of k_lda_estep spends its time in LDS: per
+// nonzero an 80-byte table column read and an 80-byte read-modify-write of the wave's slab (PMC: LDS pipe, not VALU, bounds the chunk
+// loop).  Here a document is a row of Vp = 16 SL counts (zeros where a term is absent); lane l of a 16-lane document group owns the terms
+// l, 16 + l, ..., the same ones in every document it meets, so the statistics sum_d phi_kv n_dv of its terms stay in REGISTERS for the
+// whole launch (SL * KP doubles per lane) and reach the slab once, at the end.  Per term slot: a conflict-free 16-byte-per-lane read
+// of the term-major table and 2 KP + 16 f64 instructions; no atomics in the loop.  HBM per document: 4 Vp bytes of counts instead of
+// 8 bytes per nonzero.  Same formulas as k_lda_estep (LDA.jl:69-108); the sums are associated per lane, then lanes, waves, blocks.
+template <int KP, int SL>
+__global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int L = 16, G = MMM_WAVE / L, Vp = L * SL;
+    const int t = a.t;
+    const int stop = a.ctl->stop;
+    const double* __restrict__ gam = a.gamma.s[t % 3];
+    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
+    double* __restrict__ Eln = a.Elntheta.s[t % 3];
+    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
+    const int K = a.c.K, D = a.c.D, V = a.c.V;
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
+    double* sT = smem;                                   // [Vp][KP] exp(Elnbeta_{t-1}), term-major; rows v >= V hold 1 (their counts are 0)
+    double* sSlab = sT + (size_t)Vp * KP;                // [NW][K][V]
+    double* sA = sSlab + (size_t)NW * K * V;             // [NW][G][KP]
+    double* sR = sA + (size_t)NW * G * KP;               // [NW][64][KP] gamma sums, lane-major
+    double* slab = sSlab + (size_t)wid * K * V;
+    double* myA = sA + ((size_t)wid * G + g) * KP;
+    double* myR = sR + (size_t)wid * MMM_WAVE * KP;
+    const int stride = gridDim.x * NW * G;
+    int base = (blockIdx.x * NW + wid) * G;
+
+    int d = base + g;
+    bool valid = d < D;
+    double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+    int c[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) c[q] = valid ? cnt[(size_t)d * Vp + q * L + l] : 0;
+    for (int i = tid; i < Vp * KP; i += blockDim.x) {
+        const int v = i / KP, k = i % KP;
+        sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
+    }
+    for (int i = tid; i < NW * K * V; i += blockDim.x) sSlab[i] = 0.0;
+    double st[SL][KP];
+#pragma unroll
+    for (int q = 0; q < SL; ++q)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) st[q][k] = 0.0;
+    bool first = true;
+    for (;;) {
+        // ---- the next step's gamma row and counts are requested before this step computes
+        const int dn = d + stride;
+        const bool more = base + stride < D, validn = more && dn < D;
+        double gkn = l < K ? 1.0 : 0.0;
+        int cn[SL];
+        if (validn && l < K) gkn = gam[(size_t)dn * K + l];
+#pragma unroll
+        for (int q = 0; q < SL; ++q) cn[q] = validn ? cnt[(size_t)dn * Vp + q * L + l] : 0;
+        // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k)
+        const double S = group_sum<L>(gk);
+        const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
+        const double psS = __shfl(ps, g * L + K, MMM_WAVE);
+        const double el = ps - psS;
+        if (l < KP) myA[l] = (l < K) ? exp(el) : 0.0;
+        if (first) {
+            if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
+            __syncthreads();
+            first = false;
+        } else lds_wave_sync();
+        if (valid && l < K) Eln[(size_t)d * K + l] = el;
+        double acc[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] = 0.0;
+        // ---- phi_kv n_v (LDA.jl:92-106) for the lane's SL terms.  (Tried at K = 10, V = 96, 640k documents: a_k re-read from LDS in every slot,
+        // no spilled register instead of 12: 330 vs 307 us; the next slot's table row requested a slot ahead, 62 spilled: 509 us.)
+        double av[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) av[k] = myA[k];
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const double* tb = sT + (size_t)(q * L + l) * KP;
+            double b[KP], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) b[k] = av[k] * tb[k];
+#pragma unroll
+            for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
+            if (KP & 1) s0 += b[KP - 1];
+            const double r = (double)c[q] * dev_rcp(s0 + s1);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
+            // one slot at a time, its statistics updated here (left alone the compiler sinks the SL KP updates to the end of the step and keeps
+            // every slot's products alive until then: 190 spilled registers)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(st[q][k]));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- gamma_{t+1} = alpha + sum_v phi_kv n_v: the lanes' sums meet in LDS, lane k of the group adds its column
+#pragma unroll
+        for (int k = 0; k < KP; ++k) myR[(size_t)lane * KP + k] = acc[k];
+        lds_wave_sync();
+        if (l < K) {
+            const double* col = myR + (size_t)(g * L) * KP + l;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; j += 4) { r0 += col[j * KP]; r1 += col[(j + 1) * KP]; r2 += col[(j + 2) * KP]; r3 += col[(j + 3) * KP]; }
+            if (valid) gnext[(size_t)d * K + l] = a.c.alpha + ((r0 + r1) + (r2 + r3));
+        }
+        base += stride;
+        if (base >= D) break;
+        d = dn; valid = validn; gk = gkn;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) c[q] = cn[q];
+        lds_wave_sync();
+    }
+    // ---- the lane's statistics reach the wave's slab, one document group at a time (a fixed order: groups 0..G-1)
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+        if (g == gg) {
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                const int v = q * L + l;
+                if (v < V) {
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] += st[q][k];
+                }
+            }
+        }
+        lds_wave_sync();
+    }
+    __syncthreads();
+    double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
+    for (int i = tid; i < K * V; i += blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * K * V + i];
+        out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = s;
+    }
+}
+
 // ---- slab reduction + log-likelihood / stopping rule ------------------------------------------------------------
 struct ReduceArgs {
     const double* partial; const double* llpart; int nslab; int VK;
@@ -449,9 +593,14 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     bool valid = d < D;
     double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     constexpr int PRE = 128 / L;          // padded rows: every chunk of the document is requested up front, no doc_ptr needed
-    const bool ell = c.ell != nullptr;
+    const bool dense = L == 16 && c.dense != nullptr;       // rows of counts: term = slot index, 4 bytes per slot, table columns read in lane order
+    const bool ell = dense || c.ell != nullptr;
     int2 pre[PRE];
-    if (ell) {
+    if (dense) {
+        const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
+#pragma unroll
+        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, row[j * L + l]) : make_int2(-1, 0);
+    } else if (ell) {
         const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
         for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? row[j * L + l] : make_int2(-1, 0);
@@ -467,9 +616,15 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
             if (base != wslot * G) {
                 d = base + g; valid = d < D;
                 gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-                const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
+                if (dense) {
+                    const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
-                for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? row[j * L + l] : make_int2(-1, 0);
+                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, row[j * L + l]) : make_int2(-1, 0);
+                } else {
+                    const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
+#pragma unroll
+                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? row[j * L + l] : make_int2(-1, 0);
+                }
             }
             const double Sp = group_sum<L>(gp);
             lds_wave_sync();
@@ -1357,6 +1512,8 @@ struct mmm_lda {
     double alpha = 0, eta = 0;
     double Nglobal = 0, Dglobal = 0;
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
+    DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
+    bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
     DevBuf<double> partial, stats[2], scratch, llpart, llpart2, elbopart, ll_hist;
@@ -1392,7 +1549,7 @@ struct mmm_lda {
     IldaDesc ids{};
     DevBuf<int> features;
     DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
-    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p}; }
+    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, dense ? cnt_dense.p : nullptr, 16 * SL}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
@@ -1466,10 +1623,40 @@ int go_estep(mmm_lda* m, const EstepArgs& a)
     return go_estep2<KPV, LV, LLV, 0>(m, a);
 }
 
+template <int KPV, int SLV>
+int go_dense(mmm_lda* m, const EstepArgs& a)
+{
+    if constexpr (KPV * SLV <= 64) {
+        mmm_ctx* ctx = m->ctx;
+        auto k = k_lda_estep_dense<KPV, SLV>;
+        if (!m->attr_d) { int rc = set_lds(ctx, k, m->lds_d); if (rc) return rc; m->attr_d = true; }
+        hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p);
+        return MMM_OK;
+    } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no dense-row build for KP=%d SL=%d", KPV, SLV);
+}
+
+// term slots per lane of the dense-row build that covers V terms (0: none)
+int dense_slots(int V) { return V <= 32 ? 2 : (V <= 48 ? 3 : (V <= 96 ? 6 : (V <= 128 ? 8 : 0))); }
+
 int launch_estep(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
     int rc = MMM_OK;
+    if (m->dense && !a.do_ll) {
+        MMM_KP_SWITCH(m, {
+            if constexpr (KPV >= 4 && KPV <= 16) {
+                switch (m->SL) {
+                    case 2: rc = go_dense<KPV, 2>(m, a); break;
+                    case 3: rc = go_dense<KPV, 3>(m, a); break;
+                    case 6: rc = go_dense<KPV, 6>(m, a); break;
+                    default: rc = go_dense<KPV, 8>(m, a); break;
+                }
+            }
+        })
+        if (rc) return rc;
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     if (m->wide) {
         const size_t n = (size_t)m->V * m->KP;
         const int slot = (a.t + 2) % 3;
@@ -1862,7 +2049,25 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const size_t tabB = (size_t)KP * V * sizeof(double);
     // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
     // single-step build (3 waves per SIMD).  Larger corpora: 8-wave blocks, one per CU, grid-stride steps (2 waves per SIMD).
-    const bool small = (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
+    // dense-row E-step (k_lda_estep_dense): a dense corpus (at least half of the D x V entries present, no term listed twice in a
+    // document) of at least 192 documents per CU, topics and vocabulary within the register budget of a lane (SL KP <= 64
+    // doubles).  MMM_LDA_DENSE=1 takes it for any corpus that has the shape (tests), 0 never.
+    bool dense = false;
+    const int SL = dense_slots(V);
+    {
+        const char* de = getenv("MMM_LDA_DENSE");
+        const int dmode = de ? atoi(de) : -1;
+        const bool shape = SL > 0 && L == 16 && KP >= 4 && KP * SL <= 64 && D > 0 && !getenv("MMM_LDA_WIDE");
+        bool dup = false;
+        if (shape && dmode != 0) {
+            std::vector<int> seen((size_t)V, -1);
+            for (int d = 0; d < D && !dup; ++d)
+                for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) { if (seen[(size_t)term[e]] == d) { dup = true; break; } seen[(size_t)term[e]] = d; }
+        }
+        const bool big = D >= 192 * ctx->num_cu;      // measured on MI355X (K = 10, V = 96): 40k documents 59.1 vs 58.3 us per iteration for the CSR sweep, 80k 85.6 vs 98.4
+        dense = shape && !dup && dmode != 0 && (dmode > 0 || (big && 2 * nnz >= (int64_t)D * V));
+    }
+    const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
                        !getenv("MMM_LDA_WAVES");
     // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
     // per SIMD = shorter step); MMM_LDA_SWAVES overrides for experiments
@@ -1881,6 +2086,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     mmm_lda* m = guard.get();
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
     m->waves_e = waves; m->lds_e = wide ? 0 : lds_for(waves); m->lds_tab = tabB; m->wide = wide;
+    m->dense = dense && !wide; m->SL = SL;
     if (const char* s = wide ? nullptr : getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
@@ -1890,6 +2096,9 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if (wide) m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * blocks_per_cu));     // wave per document
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
+    if (m->dense)      // [16 SL][KP] table | [waves][K][V] slabs | [waves][G][KP] a_k | [waves][64][KP] gamma sums
+        m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * K * V + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
+    if (m->dense && m->lds_d > 160 * 1024) m->dense = false;
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); return rc; } } while (0)
@@ -1927,11 +2136,21 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         m->stats_waves = 1;
         while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
     }
+    if (m->dense) {
+        const int Vp = 16 * SL;
+        std::vector<int> rows((size_t)D * Vp, 0);
+        for (int d = 0; d < D; ++d)
+            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + term[e]] = count[e];
+        hipError_t e_ = m->cnt_dense.alloc(rows.size());
+        if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(cnt_dense): %s", hipGetErrorString(e_)); return rc; }
+        MMM_HIP(ctx, hipMemcpyAsync(m->cnt_dense.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
+        MMM_HIP(ctx, hipStreamSynchronize(st));
+    }
     std::vector<int2> ell;
     {   // padded rows for the ll blocks (V <= 128 slots, no duplicate terms: then a document always fits its row)
         int64_t maxW = 0;
         for (int d = 0; d < D; ++d) maxW = std::max<int64_t>(maxW, doc_ptr[d + 1] - doc_ptr[d]);
-        if (V <= 128 && maxW <= V && D > 0 && !wide) {
+        if (V <= 128 && maxW <= V && D > 0 && !wide && !m->dense) {
             ell.assign((size_t)D * V, make_int2(-1, 0));
             for (int d = 0; d < D; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
@@ -2171,6 +2390,14 @@ int mmm_lda_iterate(mmm_lda* m, int n_iter)
         m->stop_seen = false;
     }
     return fused_passes(m, n_iter, -1.0, 0);
+}
+
+int mmm_lda_geometry(const mmm_lda* m, int out[8])
+{
+    if (!m || !out) return MMM_ERR_ARG;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->single_step ? 1 : 0; out[4] = m->wide ? 1 : 0;
+    out[5] = m->dense ? 1 : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
+    return MMM_OK;
 }
 
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)

@@ -129,6 +129,12 @@ class LDA:
         """ϕ as one [nnz, K] array (document blocks concatenated)."""
         return self._get("phi").reshape(-1, self.K)
 
+    def geometry(self):
+        """E-step build and launch geometry of the handle (mmm_lda_geometry)."""
+        g = (C.c_int * 8)()
+        check(lib().mmm_lda_geometry(self._h, g), self.ctx.h, "geometry")
+        return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "single_step": g[3], "wide": g[4], "dense": g[5], "SL": g[6], "KP": g[7]}
+
     def close(self):
         if self._h:
             lib().mmm_lda_destroy(self._h)

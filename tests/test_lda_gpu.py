@@ -198,10 +198,53 @@ def test_degenerate_shapes(mmm, oracle):
         g.close()
 
 
-def test_large_corpus_grid_stride_paths(mmm, oracle):
-    """40,000 documents: the grid-stride E-step build (several steps per wave) and the ll blocks' loop (more document groups than
-    ll blocks) against the oracle."""
-    X, g, o = _pair(mmm, oracle, 40000, 96, 10, seed=77, mean_n=150, empty=(0, 39999))
+@pytest.mark.parametrize("D,V,K,mean_n", [(500, 96, 10, 500), (300, 40, 7, 200), (260, 128, 4, 900), (70, 20, 12, 100), (333, 90, 5, 60),
+                                           (200, 33, 15, 300)])
+def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_n):
+    """The dense-row E-step build (rows of counts, statistics in registers; taken by default for dense corpora too large for the single-step
+    build) forced on small corpora of every slot count it has builds for, sparse rows and empty documents included."""
+    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
+    geo = g.geometry()
+    assert geo["dense"] == 1 and geo["SL"] * 16 >= V and geo["single_step"] == 0
+    ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=12, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    _cmp_state(g, o, 1e-8)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+    # several steps per wave and bitwise run-to-run
+    monkeypatch.setenv("MMM_LDA_GRID", "2")
+    _, g2, _ = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
+    _, g3, _ = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
+    ll_2 = mmm.fit(g2, maxiter=12, tol=0.0, verbose=False)
+    ll_3 = mmm.fit(g3, maxiter=12, tol=0.0, verbose=False)
+    np.testing.assert_allclose(ll_2, ll_o, rtol=1e-9)
+    assert np.array_equal(np.asarray(ll_2), np.asarray(ll_3)) and np.array_equal(g2.λ, g3.λ) and np.array_equal(g2.γ, g3.γ)
+    _cmp_state(g2, o, 1e-8)
+
+
+def test_dense_row_build_is_not_taken_for_sparse_or_duplicated_rows(mmm, oracle, monkeypatch):
+    """Documents that list a term twice (the reference treats the rows separately) or a sparse corpus keep the CSR sweep."""
+    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    X, lam0 = np_ref.synth_lda(40, 24, 5, seed=5, mean_n=100)
+    X[7] = np.vstack([X[7], X[7][:1]])
+    g = mmm.LDA(5, 0.1, 0.1, 24, X, λ0=lam0)
+    assert g.geometry()["dense"] == 0
+    o = oracle.LdaOracle(5, 0.1, 0.1, X, V=24, lambda0=lam0)
+    np.testing.assert_allclose(mmm.fit(g, maxiter=5, tol=0.0, verbose=False), o.fit(maxiter=5, tol=0.0), rtol=1e-9)
+    monkeypatch.delenv("MMM_LDA_DENSE")
+    X, g, o = _pair(mmm, oracle, 200, 96, 10, seed=3, mean_n=3000)
+    assert g.geometry()["dense"] == 0 and g.geometry()["single_step"] == 1       # small corpora: the single-step build
+
+
+@pytest.mark.parametrize("dense", ["0", None])
+def test_large_corpus_grid_stride_paths(mmm, oracle, monkeypatch, dense):
+    """50,000 documents: the grid-stride E-step builds (several steps per wave; the CSR sweep and, by default for this dense corpus, the
+    dense-row build) and the ll blocks' loop (more document groups than ll blocks) against the oracle."""
+    if dense is not None:
+        monkeypatch.setenv("MMM_LDA_DENSE", dense)
+    X, g, o = _pair(mmm, oracle, 50000, 96, 10, seed=77, mean_n=150, empty=(0, 49999))
+    assert g.geometry()["dense"] == (0 if dense == "0" else 1)
     ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=4, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
