@@ -779,6 +779,9 @@ struct MergeArgs {
     unsigned long long* cells;      // [nred] column-sum cells, then [512] ll cells
     unsigned int seq;               // never reused (a discarded pass must not leave valid-looking cells behind)
     int nred;
+    int ll_join;                    // large corpora (the ll blocks loop over their documents): the reduce blocks 1.. take a share of the ll sweep
+                                    // once their 16 entries are done -- the launch holds only as many blocks as are resident at once (61 of the
+                                    // 256 at K = 10, V = 96 are reduce blocks, busy for ~6 us of a ~200 us sweep at 640k documents)
 };
 
 // P2P: several GPUs with the mailboxes up -- a reduce block sends its 16 sums to the peers and adds theirs (rank order) before the
@@ -796,8 +799,8 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     if ((int)blockIdx.x >= ms.nred) {        // ---- ll block: numerator of pass t-1 into its cell
         if (stop) return;
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
-        const int lb = (int)blockIdx.x - ms.nred;
-        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, (int)gridDim.x - ms.nred, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        const int lb = (int)blockIdx.x - ms.nred, n_ll = (int)gridDim.x - ms.nred;
+        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nred - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
         return;
     }
     // ---- reduce block: 16 entries of the statistics (as lda_reduce_block)
@@ -881,8 +884,14 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         if (real) { ms.lambda.s[slot][o] = lam; ms.Elnbeta.s[slot][o] = el; ms.expElnbeta.s[slot][o] = exp(el); ms.beta.s[slot][o] = lam / cs; }
         }
     }
+    if (ms.ll_join && rb > 0) {              // (uniform per block; block 0 keeps the pass tail)
+        constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
+        const int n_ll = (int)gridDim.x - ms.nred, lb = n_ll + rb - 1;
+        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + ms.nred - 1, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        return;
+    }
     if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
-        const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred;
+        const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred + (ms.ll_join ? ms.nred - 1 : 0);
         // what the tail needs from memory is fetched before the wait, not after it (lda_pass_tail's dependent loads)
         const int n = r.ctl->n_hist;
         const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
@@ -1872,7 +1881,9 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         const int nred = (r.VK + 15) / 16;
         if (merged) {
             const size_t lds = lds_red;
-            MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred};
+            MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred, 0};
+            static const bool join_env = getenv("MMM_LDA_LL_JOIN") == nullptr || atoi(getenv("MMM_LDA_LL_JOIN")) != 0;
+            ms.ll_join = (join_env && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + nred - 1 <= 512) ? 1 : 0;
             const int c3 = t % 3;
             IldaMerge im{};
             if (m->ilda) im = IldaMerge{m->ids, m->ilam[c3].p, m->iEln[c3].p, m->ibeta[c3].p, m->fcells.p};
