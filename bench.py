@@ -318,10 +318,14 @@ def main():
             # topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
             # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
             algo_bytes = 8.0 * nnz + 24.0 * K * D
+            geo = model.geometry()
+            kname = ("k_lda_estep_dense<%d,%d> (rows of counts, 4 B per term slot: the kernel moves %d B per document where the CSR figure "
+                     "counts 8 B per nonzero)" % (geo["KP"], geo["SL"], 4 * 16 * geo["SL"] + 24 * K)) if geo["dense"] else \
+                    ("k_lda_estep<%d,%d,..,%s>" % (geo["KP"], geo["L"], "single step" if geo["single_step"] else "grid stride"))
             achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "k_lda_estep", "launches": n_launch, "avg_us": avg_s * 1e6,
+                               "kernel": kname, "launches": n_launch, "avg_us": avg_s * 1e6,
                                "algorithmic_bytes_per_launch": algo_bytes,
                                "event_span_1_launch_us": span1 * 1e6, "event_span_2_launches_us": span2 * 1e6,
                                "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "

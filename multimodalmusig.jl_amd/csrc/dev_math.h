@@ -22,20 +22,10 @@ __device__ __forceinline__ double dev_digamma_series(double x)   // x >= 7
     return psi - t * p;
 }
 
-// x > 0 (every argument on the hot path is a Dirichlet parameter).  Branch-free form of the same recurrence:
-// psi(x) = psi(x+7) - sum_{v=0}^{6} 1/(x+v), with the sum evaluated as Q'(x)/Q(x), Q = prod (x+v): one division
-// instead of up to seven, no data-dependent trip count (lanes of a wave hold very different x).
-__device__ __forceinline__ double dev_digamma_pos(double x)
-{
-    double q = x, dq = 1.0;
-#pragma unroll
-    for (int v = 1; v < 7; ++v) {
-        const double f = x + (double)v;
-        dq = fma(dq, f, q);
-        q *= f;
-    }
-    return dev_digamma_series(x + 7.0) - dq / q;
-}
+// x > 0 (every argument on the hot path is a Dirichlet parameter): csrc/mmm_arith.h's ar_digamma_pos -- psi(x) = psi(x+7) - Q'(x)/Q(x),
+// Q = prod_{v<7} (x+v) (one division instead of up to seven, no data-dependent trip count), with the 8-instruction division and the
+// fdlibm-style log of that header: ~110 instructions where the ocml log and two IEEE division sequences took ~220.  Defined below.
+__device__ __forceinline__ double dev_digamma_pos(double x);
 
 __device__ __forceinline__ double dev_digamma(double x)
 {
@@ -87,6 +77,7 @@ __device__ __forceinline__ double dev_sqrt(double x)
 
 // exp / log / digamma whose bits the parity tests' order-matched CPU restatement reproduces (one source for both sides)
 #include "mmm_arith.h"
+__device__ __forceinline__ double dev_digamma_pos(double x) { return ar_digamma_pos(x); }
 __device__ __forceinline__ double dev_digamma_ar(double x) { return (x > 0.0 && x < 1e40) ? ar_digamma_pos(x) : dev_digamma(x); }
 
 // natural log for finite x > 0 (normal or subnormal-free inputs: probabilities and Dirichlet parameters), fdlibm-style:

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
         const double psS = __shfl(ps, g * L + K, MMM_WAVE);
         const double el = ps - psS;
-        if (l < KP) myA[l] = (l < K) ? exp(el) : 0.0;
+        if (l < KP) myA[l] = (l < K) ? ar_exp(el) : 0.0;
         if (LL) {
             const double Sp = group_sum<L>(gp);
             if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
         const double psS = __shfl(ps, g * L + K, MMM_WAVE);
         const double el = ps - psS;
-        if (l < KP) myA[l] = (l < K) ? exp(el) : 0.0;
+        if (l < KP) myA[l] = (l < K) ? ar_exp(el) : 0.0;
         if (first) {
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
             __syncthreads();
