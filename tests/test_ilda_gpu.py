@@ -111,6 +111,21 @@ def test_fit_matches_oracle(mmm, oracle, K):
     assert g.ll == pytest.approx(ll_o[-1], rel=1e-9)
 
 
+def test_fit_on_the_dense_row_estep_build(mmm, oracle, monkeypatch):
+    """ILDA shares the LDA E-step: the dense-row build (forced here; default for dense corpora of >= 192 documents per CU) and the reduce
+    blocks joining the ll sweep (residency lowered so that the ll blocks loop) against the oracle."""
+    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    monkeypatch.setenv("MMM_LDA_RESIDENT_CAP", "64")
+    X, g, o = _pair(mmm, oracle, 400, 10, seed=29)
+    assert g.geometry()["dense"] == 1
+    ll_g = mmm.fit(g, maxiter=30, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=30, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    for i in range(3):
+        np.testing.assert_allclose(g.λ[i], o.mat(o.lam, i), rtol=1e-7)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+
+
 def test_fit_heldout_and_transform(mmm, oracle):
     X, g, o = _pair(mmm, oracle, 120, 5, seed=31)
     mmm.fit(g, maxiter=20, tol=0.0, verbose=False); o.fit(maxiter=20, tol=0.0)

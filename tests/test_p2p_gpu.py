@@ -47,6 +47,14 @@ def _worker(rank, world, port, q):
         g = pkg.LDA(10, 0.1, 0.1, 96, X[d0:d1], λ0=lam0, ctx=ctx)
         ll = pkg.fit(g, maxiter=40, tol=1e-4, verbose=False)
         res.update(lda_ll=ll.tolist(), lda_elbo=g.elbo, lda_beta=g.β.tolist(), lda_conv=g.converged, shard=(d0, d1))
+        # ---- the same LDA fit through the dense-row E-step build, with the reduce blocks joining the ll sweep (residency lowered so that
+        #      the ll blocks loop over their documents) -- the folded exchange rides in that launch too
+        os.environ["MMM_LDA_DENSE"] = "1"; os.environ["MMM_LDA_RESIDENT_CAP"] = "64"
+        gd = pkg.LDA(10, 0.1, 0.1, 96, X[d0:d1], λ0=lam0, ctx=ctx)
+        assert gd.geometry()["dense"] == 1
+        lld = pkg.fit(gd, maxiter=40, tol=1e-4, verbose=False)
+        res.update(ldad_ll=lld.tolist(), ldad_beta=gd.β.tolist())
+        del os.environ["MMM_LDA_DENSE"]; del os.environ["MMM_LDA_RESIDENT_CAP"]
         # ---- MMCTM: moments + gamma sums (1 x 7 x ... doubles) and M-double ll
         Xm, g0 = np_ref.synth_mm(240, [40, 24], [5, 4], seed=4, means=[600, 80], empty_frac=0.1)
         e0, e1 = pkg.shard_documents(Xm, world, rank)
@@ -95,6 +103,7 @@ def test_three_ranks_on_one_card_p2p_allreduce():
         # rank-order summation: every rank holds the same bits
         assert r["lda_ll"] == r0["lda_ll"] and r["lda_beta"] == r0["lda_beta"] and r["lda_conv"] == r0["lda_conv"]
         assert r["ctm_ll"] == r0["ctm_ll"] and r["ctm_mu"] == r0["ctm_mu"] and r["ctm_gamma"] == r0["ctm_gamma"]
+        assert r["ldad_ll"] == r0["ldad_ll"] and r["ldad_beta"] == r0["ldad_beta"]
     assert sum(b - a for a, b in (r["shard"] for r in res)) == 600
     # sharded == unsharded up to the order of the sums
     assert len(r0["lda_ll"]) == len(r0["ref_lda_ll"])
@@ -102,6 +111,9 @@ def test_three_ranks_on_one_card_p2p_allreduce():
     np.testing.assert_allclose(r0["lda_beta"], r0["ref_lda_beta"], rtol=1e-9)
     np.testing.assert_allclose(sum(r["lda_elbo"] for r in res) / WORLD, r0["lda_elbo"], rtol=1e-13)     # the ELBO is a global sum
     np.testing.assert_allclose(r0["lda_elbo"], r0["ref_lda_elbo"], rtol=1e-10)
+    assert len(r0["ldad_ll"]) == len(r0["ref_lda_ll"])
+    np.testing.assert_allclose(r0["ldad_ll"], r0["ref_lda_ll"], rtol=1e-11)
+    np.testing.assert_allclose(r0["ldad_beta"], r0["ref_lda_beta"], rtol=1e-9)
     np.testing.assert_allclose(r0["ctm_ll"], r0["ref_ctm_ll"], rtol=1e-5)
     np.testing.assert_allclose(r0["ctm_elbo"], r0["ref_ctm_elbo"], rtol=1e-5)
     np.testing.assert_allclose(r0["ctm_mu"], r0["ref_ctm_mu"], rtol=1e-3, atol=1e-5)
