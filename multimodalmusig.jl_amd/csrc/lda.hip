@@ -35,6 +35,7 @@
 //   common.jl:53-56 (device-side stop flag: later launches exit at once) and advances t.  ILDA: k_ilda_mstep instead.
 #include <memory>
 #include "dev_math.h"
+#include "mmm_logtab.h"
 #include "mmm_internal.h"
 
 namespace {
@@ -87,6 +88,41 @@ __device__ __forceinline__ double cell_wait(const unsigned long long* c, unsigne
     }
     ctl->wait_timeout = 1;
     return 0.0;
+}
+
+// sum of the cells c[2 (lane + 64 j)], j = 0.. while lane + 64 j < n (n <= 512), added in that order: every polling round asks for ALL the
+// cells the lane still misses at once, so the lane is done one memory round trip after its last cell arrives (waiting for them one
+// after the other costs a round trip per cell: 157 ll blocks = 3 cells per lane)
+__device__ __forceinline__ double cells_wait_sum(const unsigned long long* c, int n, int lane, unsigned int seq, LdaCtl* ctl)
+{
+    constexpr int MAXJ = 8;
+    double val[MAXJ];
+    unsigned pending = 0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) { val[j] = 0.0; if (lane + 64 * j < n) pending |= 1u << j; }
+    for (int it = 0; it < (1 << 22) && pending; ++it) {
+        unsigned long long w0[MAXJ], w1[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (pending & (1u << j)) {
+                w0[j] = __hip_atomic_load(c + 2 * (lane + 64 * j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1[j] = __hip_atomic_load(c + 2 * (lane + 64 * j) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if ((pending & (1u << j)) && (unsigned int)(w0[j] >> 32) == seq && (unsigned int)(w1[j] >> 32) == seq) {
+                val[j] = __longlong_as_double((long long)((w0[j] & 0xffffffffull) | (w1[j] << 32)));
+                pending &= ~(1u << j);
+            }
+        }
+        if (pending) __builtin_amdgcn_s_sleep(1);
+    }
+    if (pending) ctl->wait_timeout = 1;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) v += val[j];
+    return v;
 }
 
 constexpr int kIldaMaxI = 8, kIldaMaxSJ = 512;
@@ -584,6 +620,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     const int K = c.K, V = c.V, D = c.D;
     double* sBeta = smem;
     double* myT = smem + (size_t)KP * V + ((size_t)wid * G + g) * KP;
+    double* sLog = smem + (size_t)KP * V + (size_t)64 * KP;         // [256] the log table (dev_log_tab)
     // the first step's document loads go out before the table is staged (as in the E-step kernel).  (Splitting a document
     // group's chunks over 2 or 4 waves -- more, lighter blocks on the CUs the reduction leaves idle -- was slower: 29.7 / 33.6
     // vs 26.6 us per iteration; the launch is bound by block dispatch and table staging, not by the sweep's arithmetic.)
@@ -608,6 +645,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     int64_t start = (!ell && valid) ? c.doc_ptr[d] : 0;
     int W = (!ell && valid) ? (int)(c.doc_ptr[d + 1] - start) : 0;
     for (int i = tid; i < KP * V; i += 1024) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
+    if (tid < MMM_LOGTAB_N) sLog[tid] = g_mmm_logtab[tid];
     __syncthreads();
     double acc = 0.0;
     if (ell) {
@@ -644,7 +682,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
                 for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
                 if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
                 const double p = act ? p0 + p1 : 1.0;
-                acc = fma((double)t.y, dev_log_pos(p), acc);
+                acc = fma((double)t.y, dev_log_tab(p, sLog), acc);
             }
         }
     } else
@@ -677,7 +715,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
             for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
             if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
             const double p = act ? p0 + p1 : 1.0;
-            acc = fma((double)t.y, dev_log_pos(p), acc);
+            acc = fma((double)t.y, dev_log_tab(p, sLog), acc);
         }
     }
     acc = wave_sum(acc);
@@ -723,7 +761,7 @@ __device__ void lda_reduce_block(const ReduceArgs& r)
     if (blockIdx.x == 0 && ty >= 4 && ty < 8 && r.ll_cells && r.do_ll) {      // wave 1 of block 0: ll numerator of pass t-1 from the ll blocks' cells
         const int lane = (ty * 16 + tx) & 63;
         double v = 0.0;
-        for (int i = lane; i < r.n_ll; i += 64) v += cell_wait(r.ll_cells + 2 * i, r.ll_seq, r.ctl);
+        v = cells_wait_sum(r.ll_cells, r.n_ll, lane, r.ll_seq, r.ctl);
         v = wave_sum(v);
         if (lane == 0) r.stats[r.VK] = v;
     }
@@ -897,7 +935,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
         double v = 0.0;
         if (r.do_ll) {
-            for (int i = lane; i < n_ll; i += 64) v += cell_wait(ms.cells + 2 * (ms.nred + i), ms.seq, r.ctl);
+            v = cells_wait_sum(ms.cells + 2 * ms.nred, n_ll, lane, ms.seq, r.ctl);
             v = wave_sum(v);
             if (P2P && lane == 0) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
         }
@@ -1834,7 +1872,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
         bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
                       (!m->ilda || (m->ids.SJ <= 16 && !mmm_comm_active(ctx)));
-        const size_t lds_red = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+        const size_t lds_red = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP + MMM_LOGTAB_N);      // beta table | theta rows | log table
         int cap = 0;       // residency of the launch whose blocks wait for each other
         if (merged) {
             const int ai = m->ilda ? 2 : r.p2p;
@@ -1903,7 +1941,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_stats_terms<KPV>, dim3(m->V + 1), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, m->V, m->K,
                                                   m->term_ptr.p, m->tpost.p, m->aexp.p, m->expElnbeta[(t + 2) % 3].p, r); })
         } else if (r.n_ll > 0) {
-            const size_t lds = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP);
+            const size_t lds = lds_red;
             MMM_KP_SWITCH(m, {
                 auto k = k_lda_reduce_ll<KPV>;
                 if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_m = true; }

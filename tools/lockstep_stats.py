@@ -32,6 +32,10 @@ for it in range(npass):
                 row += "  G=%d: x%.3f" % (G, nn.max(axis=1).sum() * G / n.sum())
             out.append(row)
         print("pass %2d: " % (it + 1) + " | ".join(out))
+    if it == npass - 2:
+        stp = m.solver_stats(per_doc=True)
+        prev = (np.abs(stp["per_doc_nu"]).copy(), np.abs(stp["per_doc_lambda"]).copy())
     if it == npass - 1:
+        st = m.solver_stats(per_doc=True)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        np.savez(os.path.join(ROOT, "gpurun_out", "nev_cfg%d.npz" % cfgn), nu=np.abs(st["per_doc_nu"]), lam=np.abs(st["per_doc_lambda"]))
+        np.savez(os.path.join(ROOT, "gpurun_out", "nev_cfg%d.npz" % cfgn), nu=np.abs(st["per_doc_nu"]), lam=np.abs(st["per_doc_lambda"]), nu_prev=prev[0], lam_prev=prev[1])
