@@ -23,6 +23,7 @@
 // SURVEY.md §7): one objective evaluation per trip of a single wave-uniform loop, per-group state, select-based commits.
 #include <memory>
 #include "dev_math.h"
+#include "mmm_logtab.h"
 #include "mmm_internal.h"
 
 namespace {
@@ -1409,7 +1410,9 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     const int g = lane / L, l = lane % L;
     const double* sP = TAB_LDS ? smem : phieff;                   // [GT]: staged, or (wide tables) read through L2
     double* sPr = smem + (TAB_LDS ? GT : 0) + wid * 64 + g * L;   // the group's props
+    const double* sLog = smem + (((TAB_LDS ? GT : 0) + kWavesS * 64 + 1) & ~1);      // [256] log table (dev_log_tab), 16-byte aligned
     if (TAB_LDS && compute_ll) { for (int i = tid; i < GT; i += kBlockS) smem[i] = phieff[i]; }
+    if (compute_ll && tid < MMM_LOGTAB_N) smem[(((TAB_LDS ? GT : 0) + kWavesS * 64 + 1) & ~1) + tid] = g_mmm_logtab[tid];
     __syncthreads();
     int mod_l = 0;
     for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) mod_l = m;
@@ -1444,7 +1447,7 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
                 const int2 t = c.tc[start + w];
                 double p = 0.0;
                 for (int k = 0; k < Km; ++k) p = fma(sPr[off + k], tb[k * Vm + t.x], p);
-                a += (double)t.y * dev_log_pos(p);
+                a += (double)t.y * dev_log_tab(p, sLog);
             }
             acc[m] += a;
         }
@@ -1904,7 +1907,8 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     const int M = m->dm.M;
     const size_t r0 = sc.rep0;
     const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
-    const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
+    const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64 + 1 + MMM_LOGTAB_N,      // table | props | log table
+                                                 gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
     auto kll = m->wide ? (m->L == 16 ? k_ctm_loglik<false, 16> : (m->L == 32 ? k_ctm_loglik<false, 32> : k_ctm_loglik<false, 64>))
                        : (m->L == 16 ? k_ctm_loglik<true, 16> : (m->L == 32 ? k_ctm_loglik<true, 32> : k_ctm_loglik<true, 64>));
     if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
