@@ -255,8 +255,12 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     bool valid = d < D;
     double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-    int64_t start = valid ? a.c.doc_ptr[d] : 0;
-    int W = valid ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
+    // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
+    // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
+    // document has the same V / L chunks (static register indices, no per-step shuffles)
+    const bool rows = SINGLE && VT != 0 && VT <= PRE * L && a.c.ell != nullptr;
+    int64_t start = (valid && !rows) ? a.c.doc_ptr[d] : 0;
+    int W = (valid && !rows) ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
     // SINGLE: the table stays in registers (<= 5 entries per thread: KP*V <= 12 * 96, >= 4 waves) until just before the barrier, so
     // that the prologue arithmetic below runs while these loads are in flight instead of after them
     constexpr int TB = KP <= 10 ? 4 : 5;
@@ -285,14 +289,25 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     bool first = true;
     for (;;) {
         // ---- groups start at rotated chunks so that the G documents of a wave instruction touch different term ranges of the slab
-        const int nch = (W + L - 1) / L;
+        constexpr int NCHR = VT ? (VT + L - 1) / L : 1;      // chunks of a padded row
+        const int nch = rows ? NCHR : (W + L - 1) / L;
         const int rot = nch > 0 ? g % nch : 0;
         const int2* __restrict__ tcd = a.c.tc + start;
         int nchmax = nch;
-        if (G >= 2) nchmax = max(nchmax, __shfl_xor(nchmax, 32, MMM_WAVE));
-        if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
-        nchmax = __builtin_amdgcn_readfirstlane(nchmax);
-        if (SINGLE || first) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
+        if (!rows) {
+            if (G >= 2) nchmax = max(nchmax, __shfl_xor(nchmax, 32, MMM_WAVE));
+            if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
+            nchmax = __builtin_amdgcn_readfirstlane(nchmax);
+        }
+        if (rows) {
+            const int2* __restrict__ row = a.c.ell + (size_t)(valid ? d : 0) * VT;
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                int c = j + rot; if (c >= NCHR) c -= NCHR;
+                const int w = c * L + l;
+                tcp[j] = (valid && j < NCHR && w < VT) ? row[w] : make_int2(-1, 0);
+            }
+        } else if (SINGLE || first) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= nch) c -= nch;
@@ -347,6 +362,17 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             double av[KP], acc[KP];
 #pragma unroll
             for (int k = 0; k < KP; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
+            if (rows) {
+#pragma unroll
+                for (int j = 0; j < PRE; ++j) {
+                    if (j < NCHR) {
+                        int2 tcv = tcp[j];
+                        const bool act = tcv.x >= 0;
+                        tcv.x = act ? tcv.x : 0;
+                        lda_chunk<KP, LL>(tcv, act, V, av, acc, sB, sBeta, myT, slab, ll_acc);
+                    }
+                }
+            } else
 #pragma unroll 2
             for (int j = 0; j < nchmax; ++j) {
                 int2 tcv = tcp[0];
@@ -1907,7 +1933,10 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             if (cap - nred_ < 1) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: the reduce launch cannot hold its %d reduce blocks and one ll block at once (%d resident)", nred_, cap);
             r.n_ll = std::min(r.n_ll, cap - nred_);       // the ll blocks stride over the documents: fewer blocks, same sums per block id
         }
-        EstepArgs a{m->dev(), m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
+        static const bool rows_env = getenv("MMM_LDA_ROWS") == nullptr || atoi(getenv("MMM_LDA_ROWS")) != 0;
+        LdaDev edev = m->dev();
+        if (!rows_env) edev.ell = nullptr;
+        EstepArgs a{edev, m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
