@@ -35,6 +35,25 @@ def test_lda_transform(mmm, oracle):
     np.testing.assert_allclose(th_g.sum(axis=0), 1.0, rtol=1e-13)
 
 
+def test_lda_transform_and_heldout_on_dense_row_handles(mmm, oracle, monkeypatch):
+    """Handles that took the dense-row E-step build (forced): the frozen-topic passes and the stage API keep to the CSR sweeps."""
+    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    g, o, Xn = _lda_pair(mmm, oracle, D=200, K=10, seed=6)
+    assert g.geometry()["dense"] == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        th_g = mmm.transform(g, Xn, maxiter=40, tol=1e-5)
+    th_o, _ = o.transform(Xn, maxiter=40, tol=1e-5)
+    np.testing.assert_allclose(th_g, th_o.reshape(len(Xn), g.K).T, rtol=1e-9)
+    hg = mmm.fit_heldout(Xn, g, maxiter=30)
+    ho = o.fit_heldout(Xn, maxiter=30)
+    assert len(hg.ll_history) == len(ho.ll_hist)
+    np.testing.assert_allclose(hg.ll_history, ho.ll_hist, rtol=1e-10)
+    # stage API after fused passes on the same handle
+    mmm.update_γ(g); o.update_gamma(); mmm.update_ϕ(g); o.update_phi(); mmm.update_λ(g); o.update_lambda()
+    np.testing.assert_allclose(g.λ, o.lam.reshape(g.V, g.K, order="F"), rtol=1e-8)
+
+
 def test_lda_transform_stops_like_the_reference(mmm, oracle):
     g, o, Xn = _lda_pair(mmm, oracle, seed=9)
     th_o, onew = o.transform(Xn, maxiter=200, tol=1e-4)
