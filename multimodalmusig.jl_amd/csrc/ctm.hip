@@ -344,7 +344,10 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     double* sScr = smem;                               // [NW][SCRW]
     double* sS = sScr + (size_t)NW * SCRW;             // [MK*MK]   (PH 1)
     double* sMu = sS + MK * MK;                        // [MK]      (PH 1)
-    double* sB = sScr + (size_t)NW * SCRW;             // [GT]      (PH 0)
+    // the modality-major sweep of the fused pass needs one a_k row per group: half the scratch (BASELINE config 4: 82,400 -> 78,304 bytes
+    // per block, which is what lets two blocks share a CU's 160 KB)
+    const bool slabpass = PH == 0 && !WIDE && (flags & F_SLAB);
+    double* sB = sScr + (size_t)NW * (slabpass ? MMM_WAVE : SCRW);             // [GT]      (PH 0)
     double* sSlab = sB + GT;                           // [NW][GT]  (PH 0, F_SLAB)
     if (PH == 1) {
         for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = p_invSigma[i];
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
             int slabn = 0;
             for (int m = 0; m < M; ++m) slabn = max(slabn, dm.K[m] * dm.V[m]);
             double* myslab = sSlab + (size_t)wid * slabn;
-            double* scr = sScr + ((size_t)wid * G + g) * 2 * L;      // a_k of the group's document
+            double* scr = sScr + ((size_t)wid * G + g) * L;          // a_k of the group's document
             int ml = 0;
             for (int m = 0; m < M; ++m) if (l >= dm.koff[m] && l < dm.koff[m + 1]) ml = m;
             if (a.expE_keep && blockIdx.x == 0) for (int i = tid; i < GT; i += blockDim.x) a.expE_keep[rep * GT + i] = sB[i];
@@ -1716,7 +1719,7 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 {
     const int G = MMM_WAVE / m->L;
     if (m->wide) return sizeof(double) * (size_t)m->waves_e * G * 2 * m->L;
-    size_t n = (size_t)m->dm.GT + (size_t)m->waves_e * G * 2 * m->L;
+    size_t n = (size_t)m->dm.GT + (size_t)m->waves_e * G * ((flags & F_SLAB) ? 1 : 2) * m->L;      // (the fused pass: one scratch row per group)
     int slabn = 0;      // a wave's slab holds one modality at a time
     for (int i = 0; i < m->dm.M; ++i) slabn = std::max(slabn, m->dm.K[i] * m->dm.V[i]);
     if (flags & F_SLAB) n += (size_t)m->waves_e * slabn;
