@@ -2192,6 +2192,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
     if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
+    if (const char* gs = getenv("MMM_CTM_GRID_S")) m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * std::max(1, atoi(gs))));
     m->waves_s = 4;
     // solve phase: packed document groups (sum K lanes per document) for the shapes with a build; MMM_CTM_PACK=0: the 16-lane rows (A/B)
     m->Ls = m->L;
