@@ -293,6 +293,48 @@ def test_fused_pass_matches_stage_sequence_and_oracle(mmm, oracle, rule):
     assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
 
 
+def _random_shapes(n, seed):
+    """(D, K, V, means, features) drawn over the dispatch space of the kernels: 1-3 modalities, sum K from 2 to 40 (16- / 32- / 64-lane
+    document groups, the packed and the several-coordinates-per-lane solve builds, table widths 8 / 10 / 16 / 32), vocabularies of
+    8-130 terms, corpora from a fraction of a wave step to several steps per wave, every third case an IMMCTM with 2 feature axes."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        M = int(rng.integers(1, 4))
+        K = [int(rng.integers(2, 14)) for _ in range(M)]
+        if i % 5 == 4:
+            K = [int(rng.integers(12, 20)) for _ in range(2)]          # sum K > 32: 64-lane groups
+        V = [int(rng.integers(8, 131)) for _ in range(M)]
+        D = int(rng.integers(20, 420))
+        means = [int(rng.integers(3 * v, 30 * v)) for v in V]
+        feats = None
+        if i % 3 == 2:
+            feats = []
+            for v in V:
+                a1 = int(rng.integers(2, 5))
+                a2 = -(-v // a1)
+                feats.append(np.array([[t % a1 + 1, t // a1 + 1] for t in range(v)]))
+                assert feats[-1][:, 1].max() == a2
+        out.append((D, K, V, means, feats))
+    return out
+
+
+@pytest.mark.parametrize("idx,shape", list(enumerate(_random_shapes(20, 20261004))))
+def test_random_shapes_bit_identical_to_oracle(mmm, oracle, idx, shape):
+    """Three fused passes on randomly drawn shapes: the whole state and every document's evaluation counts equal the order-matched
+    oracle's, whatever builds the shape dispatches to."""
+    D, K, V, means, feats = shape
+    X, g, o = _pair(mmm, oracle, D, K, V, seed=900 + idx, means=means, imm_features=feats, order="device")
+    MK = sum(K)
+    check = mmm._lib.check
+    for it in range(3):
+        check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        o.twin_pass(True)
+        _same_state(g, o, D, MK)
+        st = g.solver_stats(per_doc=True)
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D]), (g.geometry(), it)
+
+
 def _fit_case(case):
     if case == "mm":
         return dict(D=80, K=[5, 4], V=[40, 24], seed=5, means=[600, 80])
