@@ -223,6 +223,44 @@ def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_
     _cmp_state(g2, o, 1e-8)
 
 
+def _random_lda_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        K = int(rng.integers(1, 25))
+        V = int(rng.integers(5, 200))
+        D = int(rng.integers(3, 700))
+        mean_n = int(rng.integers(V // 2 + 1, 12 * V))
+        out.append((D, V, K, mean_n))
+    return out
+
+
+@pytest.mark.parametrize("idx,shape", list(enumerate(_random_lda_shapes(16, 20261004))))
+def test_random_shapes_every_estep_build_against_oracle(mmm, oracle, monkeypatch, idx, shape):
+    """Randomly drawn (D, V, K, document length): six fused passes through the default build of the shape, the grid-stride loop (a 3-block
+    grid), the dense-row build (where the shape has one) and the wide-table path, each against the oracle."""
+    D, V, K, mean_n = shape
+    envs = [{}, {"MMM_LDA_GRID": "3"}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_WIDE": "1"}]
+    ll_o = None
+    for env in envs:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        X, g, o = _pair(mmm, oracle, D, V, K, seed=400 + idx, mean_n=mean_n, empty=(0,) if D > 4 else ())
+        for k in env:
+            monkeypatch.delenv(k)
+        geo = g.geometry()
+        if "MMM_LDA_WIDE" in env:
+            assert geo["wide"] == 1
+        ll_g = mmm.fit(g, maxiter=6, tol=0.0, verbose=False)
+        if ll_o is None:
+            ll_o = o.fit(maxiter=6, tol=0.0); ref = o
+        np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9, err_msg=str((env, geo)))
+        np.testing.assert_allclose(g.λ, ref.lam.reshape(V, K, order="F"), rtol=1e-9, err_msg=str((env, geo)))
+        np.testing.assert_allclose(g.γ, ref.gamma.reshape(D, K).T, rtol=1e-9, err_msg=str((env, geo)))
+        assert g.elbo == pytest.approx(ref.elbo_value, rel=1e-9)
+        g.close()
+
+
 def test_dense_row_build_is_not_taken_for_sparse_or_duplicated_rows(mmm, oracle, monkeypatch):
     """Documents that list a term twice (the reference treats the rows separately) or a sparse corpus keep the CSR sweep."""
     monkeypatch.setenv("MMM_LDA_DENSE", "1")
