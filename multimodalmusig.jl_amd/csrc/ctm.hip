@@ -1249,6 +1249,11 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             for (int e = tid; e < nf * Vm; e += nt) sh_feat[e] = feat[e];
             __syncthreads();
         }
+        // the topic's gamma / Elnphi rows (sum(J) values) stay in LDS between the three steps below: written to the model arrays once,
+        // never read back from memory (each read-back was a global round trip inside a 10-block launch)
+        constexpr int kRow = 512;
+        __shared__ double sh_gam[kRow], sh_eln[kRow];
+        const bool rows = SJ <= kRow;
         if (a.gamma_from_stats) for (int e = tid; e < SJ; e += nt) {
             int jj = e, i = 0;
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; ++i; }
@@ -1256,26 +1261,32 @@ __global__ __launch_bounds__(256) void k_ctm_mstep_topics(MstepArgs a)
             if (staged) { for (int v = 0; v < Vm; ++v) if (sh_feat[i * Vm + v] == jj) s += sh_row[v]; }
             else for (int v = 0; v < Vm; ++v) if (feat[i * Vm + v] == jj) s += sG[go + k * Vm + v];
             q.gamma[mg + k * SJ + e] = s;
+            if (rows) sh_gam[e] = s;
         }
+        else if (rows) for (int e = tid; e < SJ; e += nt) sh_gam[e] = q.gamma[mg + k * SJ + e];
         __syncthreads();
+        const double* gam = rows ? sh_gam : q.gamma + mg + (size_t)k * SJ;
         // Elnphi[m][k][i][j] = psi(gamma) - psi(sum_j gamma)   (IMMCTM.jl:188-197)
         for (int e = tid; e < SJ; e += nt) {
             int jj = e, i = 0, jo = 0;
             while (jj >= tp.J[ao + i]) { jj -= tp.J[ao + i]; jo += tp.J[ao + i]; ++i; }
             double cs = 0.0;
-            for (int j = 0; j < tp.J[ao + i]; ++j) cs += q.gamma[mg + k * SJ + jo + j];
-            q.Elnphi[mg + k * SJ + e] = dev_digamma_ar(q.gamma[mg + k * SJ + e]) - dev_digamma_ar(cs);
+            for (int j = 0; j < tp.J[ao + i]; ++j) cs += gam[jo + j];
+            const double el = dev_digamma_ar(gam[e]) - dev_digamma_ar(cs);
+            q.Elnphi[mg + k * SJ + e] = el;
+            if (rows) sh_eln[e] = el;
         }
         __syncthreads();
+        const double* eln = rows ? sh_eln : q.Elnphi + mg + (size_t)k * SJ;
         // effective [k][v] tables: Eeff = sum_i Elnphi[..][f_vi]; phieff = prod_i gamma[..][f_vi] / sum_j gamma[..][j]
         for (int v = tid; v < Vm; v += nt) {
             double se = 0.0, pp = 1.0; int jo = 0;
             for (int i = 0; i < nf; ++i) {
-                const int Ji = tp.J[ao + i], f = feat[i * Vm + v];
+                const int Ji = tp.J[ao + i], f = (staged ? sh_feat[i * Vm + v] : feat[i * Vm + v]);
                 double cs = 0.0;
-                for (int j = 0; j < Ji; ++j) cs += q.gamma[mg + k * SJ + jo + j];
-                se += q.Elnphi[mg + k * SJ + jo + f];
-                pp *= q.gamma[mg + k * SJ + jo + f] / cs;
+                for (int j = 0; j < Ji; ++j) cs += gam[jo + j];
+                se += eln[jo + f];
+                pp *= gam[jo + f] / cs;
                 jo += Ji;
             }
             q.Eeff[go + k * Vm + v] = se; q.expEeff[go + k * Vm + v] = ar_exp(se); q.phieff[go + k * Vm + v] = pp;
