@@ -395,7 +395,7 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
 
 
 @pytest.mark.parametrize("env,case,expect", [({"MMM_CTM_CPL": "0", "MMM_CTM_PACK": "0"}, "imm10", (16, 1)), ({"MMM_CTM_CPL": "0"}, "imm10", (10, 1)),
-                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)),
+                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)), ({"MMM_CTM_CPL": "3"}, "cfg4_shape", (32, 1)),
                                              ({}, "mm33", (6, 1)), ({}, "mm66", (12, 1))])
 def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, env, case, expect):
     """The solve phase has three lane layouts: one coordinate per lane in 16/32/64-lane DPP rows (mma_group), packed groups of sum K
