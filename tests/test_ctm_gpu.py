@@ -304,6 +304,7 @@ def _random_shapes(n, seed):
         K = [int(rng.integers(2, 14)) for _ in range(M)]
         if i % 5 == 4:
             K = [int(rng.integers(12, 20)) for _ in range(2)]          # sum K > 32: 64-lane groups
+            M = 2
         V = [int(rng.integers(8, 131)) for _ in range(M)]
         D = int(rng.integers(20, 420))
         means = [int(rng.integers(3 * v, 30 * v)) for v in V]

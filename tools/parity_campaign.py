@@ -1,0 +1,58 @@
+"""One-off randomized parity campaign on the GPU box (not part of the test-suite: tests/test_ctm_gpu.py and tests/test_lda_gpu.py keep 20 + 16
+fixed draws of the same generators): N random CTM shapes bit for bit against the order-matched oracle, N random LDA shapes through every
+E-step build against the oracle at 1e-9.  python tools/parity_campaign.py [N] [seed]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import mmm_pkg, np_ref
+from oracle import oracle as orc
+import test_ctm_gpu as T
+import test_lda_gpu as TL
+
+mmm = mmm_pkg.load()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+bad = 0
+geos = {}
+for idx, (D, K, V, means, feats) in enumerate(T._random_shapes(N, seed)):
+    try:
+        X, g, o = T._pair(mmm, orc, D, K, V, seed=5000 + idx, means=means, imm_features=feats, order="device")
+        geo = g.geometry(); key = (geo["L"], geo["Ls"], geo["cpl"], geo["waves_e"]); geos[key] = geos.get(key, 0) + 1
+        for it in range(3):
+            mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+            o.twin_pass(True)
+            T._same_state(g, o, D, sum(K))
+            st = g.solver_stats(per_doc=True)
+            assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+        g.close()
+    except Exception as e:      # noqa: BLE001
+        bad += 1
+        print("CTM case %d FAILED: D=%d K=%s V=%s imm=%s: %s" % (idx, D, K, V, feats is not None, str(e)[:300]))
+print("CTM: %d shapes, %d failures; (L, Ls, cpl, waves_e) seen: %s" % (N, bad, sorted(geos.items())))
+badl = 0
+builds = {}
+for idx, (D, V, K, mean_n) in enumerate(TL._random_lda_shapes(N, seed + 1)):
+    try:
+        ref = None
+        for env in [{}, {"MMM_LDA_GRID": "3"}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_WIDE": "1"}]:
+            os.environ.update(env)
+            X, lam0 = np_ref.synth_lda(D, V, K, seed=7000 + idx, mean_n=mean_n)
+            g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+            for k in env:
+                del os.environ[k]
+            geo = g.geometry(); key = (geo["single_step"], geo["dense"], geo["wide"], geo["L"]); builds[key] = builds.get(key, 0) + 1
+            ll_g = mmm.fit(g, maxiter=6, tol=0.0, verbose=False)
+            if ref is None:
+                ref = orc.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0); ll_o = ref.fit(maxiter=6, tol=0.0)
+            np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+            np.testing.assert_allclose(g.λ, ref.lam.reshape(V, K, order="F"), rtol=1e-9)
+            np.testing.assert_allclose(g.γ, ref.gamma.reshape(D, K).T, rtol=1e-9)
+            g.close()
+    except Exception as e:      # noqa: BLE001
+        badl += 1
+        for k in ("MMM_LDA_GRID", "MMM_LDA_DENSE", "MMM_LDA_WIDE"):
+            os.environ.pop(k, None)
+        print("LDA case %d FAILED: D=%d V=%d K=%d mean_n=%d env=%s: %s" % (idx, D, V, K, mean_n, env, str(e)[:300]))
+print("LDA: %d shapes x 4 builds, %d failures; (single_step, dense, wide, L) seen: %s" % (N, badl, sorted(builds.items())))
+sys.exit(1 if bad or badl else 0)
