@@ -55,4 +55,52 @@ for idx, (D, V, K, mean_n) in enumerate(TL._random_lda_shapes(N, seed + 1)):
             os.environ.pop(k, None)
         print("LDA case %d FAILED: D=%d V=%d K=%d mean_n=%d env=%s: %s" % (idx, D, V, K, mean_n, env, str(e)[:300]))
 print("LDA: %d shapes x 4 builds, %d failures; (single_step, dense, wide, L) seen: %s" % (N, badl, sorted(builds.items())))
-sys.exit(1 if bad or badl else 0)
+# ---- restart batches: R replicas in one handle == R single fits, bit for bit (the replicas ride on grid.y of every kernel)
+import test_ctm_batch_gpu as TB
+badb = 0
+nb = max(1, N // 5)
+for idx, (D, K, V, means, feats) in enumerate(T._random_shapes(nb, seed + 2)):
+    try:
+        R = 3
+        X, _ = np_ref.synth_mm(D, V, K, seed=8000 + idx, means=means, empty_frac=0.1)
+        g0 = TB._inits(K, V, R, 8100 + idx, feats)
+        batch = TB._make(mmm, K, V, X, g0, feats, restarts=R)
+        hists = mmm.fit_restarts(batch, maxiter=8, tol=2e-3)
+        for r in range(R):
+            single = TB._make(mmm, K, V, X, g0[r], feats)
+            h = mmm.fit(single, maxiter=8, tol=2e-3, verbose=False)
+            assert np.array_equal(h, hists[r]), "ll history of restart %d" % r
+            batch.select(r)
+            for f in TB.FIELDS:
+                assert np.array_equal(batch._get(f), single._get(f)), "restart %d field %s" % (r, f)
+            single.close()
+        batch.close()
+    except Exception as e:      # noqa: BLE001
+        badb += 1
+        print("BATCH case %d FAILED: D=%d K=%s V=%s imm=%s: %s" % (idx, D, K, V, feats is not None, str(e)[:300]))
+print("restart batches: %d shapes x 3 replicas, %d failures" % (nb, badb))
+# ---- ILDA: random topic counts / corpora over the 96-term, 3-feature factorisation; default build and the dense-row build
+import test_ilda_gpu as TI
+badi = 0
+rng = np.random.default_rng(seed + 3)
+for idx in range(nb):
+    D, K = int(rng.integers(5, 500)), int(rng.integers(1, 16))
+    try:
+        for env in [{}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_GRID": "2"}]:
+            os.environ.update(env)
+            X, g, o = TI._pair(mmm, orc, D, K, seed=9000 + idx)
+            for k in env:
+                del os.environ[k]
+            ll_g = mmm.fit(g, maxiter=8, tol=0.0, verbose=False)
+            ll_o = o.fit(maxiter=8, tol=0.0)
+            np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+            for i in range(3):
+                np.testing.assert_allclose(g.λ[i], o.mat(o.lam, i), rtol=1e-8)
+            g.close()
+    except Exception as e:      # noqa: BLE001
+        badi += 1
+        for k in ("MMM_LDA_GRID", "MMM_LDA_DENSE"):
+            os.environ.pop(k, None)
+        print("ILDA case %d FAILED: D=%d K=%d env=%s: %s" % (idx, D, K, env, str(e)[:300]))
+print("ILDA: %d shapes x 3 builds, %d failures" % (nb, badi))
+sys.exit(1 if bad or badl or badb or badi else 0)
