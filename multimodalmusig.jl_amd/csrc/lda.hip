@@ -154,8 +154,19 @@ __device__ unsigned long long g_lda_stamps[16];
             if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_lda_stamps[10 + ((i) != 0)] = r_;        \
         }                                                                                                    \
     } while (0)
+// stamps of the merged reduce + ll + M-step launch: s_memrealtime (100 MHz) of one chosen wave per role
+__device__ unsigned long long g_red_stamps[32];
+#define MMM_RSTAMP(cond, i)                                                                                  \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+        unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                            \
+        if (cond) g_red_stamps[i] = r_;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
 #else
 #define MMM_STAMP(i) do { } while (0)
+#define MMM_RSTAMP(cond, i) do { } while (0)
 #endif
 
 __device__ __forceinline__ void lds_wave_sync()
@@ -670,9 +681,13 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     }
     int64_t start = (!ell && valid) ? c.doc_ptr[d] : 0;
     int W = (!ell && valid) ? (int)(c.doc_ptr[d + 1] - start) : 0;
-    for (int i = tid; i < KP * V; i += 1024) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
+    // term-major copy [v][KP] of beta_{t-1}: a lane reads the KP entries of its term as 16-byte pairs at immediate offsets (lane stride
+    // 8 KP bytes: the 16 lanes of a document group cover the banks once), instead of KP reads with an address computed for each
+    for (int i = tid; i < KP * V; i += 1024) { const int v = i / KP, k = i - v * KP; sBeta[i] = (k < K) ? bprev[(size_t)k * V + v] : 0.0; }
     if (tid < MMM_LOGTAB_N) sLog[tid] = g_mmm_logtab[tid];
+    MMM_RSTAMP(lb == 0 && tid == 0, 20);       // own loads (gamma row, document row, table entries) have arrived
     __syncthreads();
+    MMM_RSTAMP(lb == 0 && tid == 0, 21);       // tables staged by all waves
     double acc = 0.0;
     if (ell) {
         const int nch = (V + L - 1) / L;
@@ -702,11 +717,11 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
                 if (j >= nch) break;
                 const int2 t = pre[j];
                 const bool act = t.x >= 0;
-                const double* bc = sBeta + (act ? t.x : 0);
+                const double* bc = sBeta + (size_t)(act ? t.x : 0) * KP;
                 double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-                for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
-                if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
+                for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k], p0); p1 = fma(tv[k + 1], bc[k + 1], p1); }
+                if (KP & 1) p0 = fma(tv[KP - 1], bc[KP - 1], p0);
                 const double p = act ? p0 + p1 : 1.0;
                 acc = fma((double)t.y, dev_log_tab(p, sLog), acc);
             }
@@ -735,18 +750,20 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
             const int w = j * L + l;
             const bool act = w < W;
             const int2 t = act ? tcd[w] : make_int2(0, 0);
-            const double* bc = sBeta + t.x;
+            const double* bc = sBeta + (size_t)t.x * KP;
             double p0 = 0.0, p1 = 0.0;
 #pragma unroll
-            for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k * V], p0); p1 = fma(tv[k + 1], bc[(k + 1) * V], p1); }
-            if (KP & 1) p0 = fma(tv[KP - 1], bc[(KP - 1) * V], p0);
+            for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k], p0); p1 = fma(tv[k + 1], bc[k + 1], p1); }
+            if (KP & 1) p0 = fma(tv[KP - 1], bc[KP - 1], p0);
             const double p = act ? p0 + p1 : 1.0;
             acc = fma((double)t.y, dev_log_tab(p, sLog), acc);
         }
     }
+    MMM_RSTAMP(lb == 0 && tid == 0, 22);       // sweep done
     acc = wave_sum(acc);
     if (lane == 0) s_w[wid] = acc;
     __syncthreads();
+    MMM_RSTAMP(lb == 0 && tid == 0, 23);       // all waves done
     if (tid == 0) {
         double v = 0.0;
 #pragma unroll
@@ -860,11 +877,15 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     __shared__ double sm[64][17];
     const int stop = r.ctl->stop;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
+    MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 0);                         // reduce block 1, wave 0
+    MMM_RSTAMP(blockIdx.x == 0 && tid == 64, 8);                        // tail wave
+    MMM_RSTAMP((int)blockIdx.x == ms.nred && tid == 0, 16);              // first ll block
     if ((int)blockIdx.x >= ms.nred) {        // ---- ll block: numerator of pass t-1 into its cell
         if (stop) return;
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
         const int lb = (int)blockIdx.x - ms.nred, n_ll = (int)gridDim.x - ms.nred;
         lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nred - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        MMM_RSTAMP((int)blockIdx.x == ms.nred && tid == 0, 17);
         return;
     }
     // ---- reduce block: 16 entries of the statistics (as lda_reduce_block)
@@ -876,6 +897,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         if (P2P && rb == 0 && tid == 0) { p2p_send(r.px, r.p2p_seq, 0, 0.0); (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0); }
         return;
     }
+    MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 1);                         // partial loads done
     sm[ty][tx] = acc;
     __syncthreads();
     if (ty < 8) {
@@ -885,6 +907,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         sm[ty * 8][tx] = v;
     }
     __syncthreads();
+    MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 2);                         // tree done
     if (ty == 0) {                           // lanes 0..15 of wave 0
         double v = 0.0;
 #pragma unroll
@@ -943,9 +966,11 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         const double got = (tx < nb) ? cell_wait(ms.cells + 2 * (k * nb + tx), ms.seq, r.ctl) : 0.0;
         double cs = 0.0;
         for (int j = 0; j < nb; ++j) cs += __shfl(got, j, 16);
+        MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 3);                     // column sum in hand
         const double el = dev_digamma_pos(real ? lam : 1.0) - dev_digamma_pos(cs);
         const size_t o = (size_t)k * V + vv;
         if (real) { ms.lambda.s[slot][o] = lam; ms.Elnbeta.s[slot][o] = el; ms.expElnbeta.s[slot][o] = exp(el); ms.beta.s[slot][o] = lam / cs; }
+        MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 4);                     // M-step stores done
         }
     }
     if (ms.ll_join && rb > 0) {              // (uniform per block; block 0 keeps the pass tail)
@@ -961,7 +986,9 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
         double v = 0.0;
         if (r.do_ll) {
+            MMM_RSTAMP(lane == 0, 9);
             v = cells_wait_sum(ms.cells + 2 * ms.nred, n_ll, lane, ms.seq, r.ctl);
+            MMM_RSTAMP(lane == 0, 10);
             v = wave_sum(v);
             if (P2P && lane == 0) { p2p_send(r.px, r.p2p_seq, r.VK, v); v = p2p_recv_sum(r.px, r.p2p_seq, r.VK, v); }
         }
@@ -977,6 +1004,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
             if (!halt) r.ctl->t = r.t;
             r.ctl->ticket = 0;
         }
+        MMM_RSTAMP(lane == 0, 11);
     }
 }
 
@@ -2088,6 +2116,10 @@ static int run_chunks_pipelined(mmm_lda* m, int maxiter, int* enq_out, Enqueue e
 extern "C" int mmm_diag_lda_stamps(unsigned long long out[16])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lda_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+extern "C" int mmm_diag_red_stamps(unsigned long long out[32])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_red_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
 }
 #endif
 
