@@ -269,7 +269,8 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
     // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
     // document has the same V / L chunks (static register indices, no per-step shuffles)
-    const bool rows = SINGLE && VT != 0 && VT <= PRE * L && a.c.ell != nullptr;
+    const bool drows = SINGLE && VT != 0 && VT <= PRE * L && a.c.dense != nullptr;      // rows of counts: term = slot, 4 bytes per slot
+    const bool rows = drows || (SINGLE && VT != 0 && VT <= PRE * L && a.c.ell != nullptr);
     int64_t start = (valid && !rows) ? a.c.doc_ptr[d] : 0;
     int W = (valid && !rows) ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
     // SINGLE: the table stays in registers (<= 5 entries per thread: KP*V <= 12 * 96, >= 4 waves) until just before the barrier, so
@@ -310,7 +311,16 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
             nchmax = __builtin_amdgcn_readfirstlane(nchmax);
         }
-        if (rows) {
+        if (drows) {
+            const int* __restrict__ row = a.c.dense + (size_t)(valid ? d : 0) * a.c.Vp;
+#pragma unroll
+            for (int j = 0; j < PRE; ++j) {
+                int c = j + rot; if (c >= NCHR) c -= NCHR;
+                const int w = c * L + l;
+                const int n = (valid && j < NCHR && w < VT) ? row[w] : 0;
+                tcp[j] = make_int2(n > 0 ? w : -1, n);
+            }
+        } else if (rows) {
             const int2* __restrict__ row = a.c.ell + (size_t)(valid ? d : 0) * VT;
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
@@ -1615,6 +1625,7 @@ struct mmm_lda {
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
     bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
+    bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
     DevBuf<double> partial, stats[2], scratch, llpart, llpart2, elbopart, ll_hist;
@@ -1650,7 +1661,7 @@ struct mmm_lda {
     IldaDesc ids{};
     DevBuf<int> features;
     DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
-    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, dense ? cnt_dense.p : nullptr, 16 * SL}; }
+    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, drows ? cnt_dense.p : nullptr, 16 * SL}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
@@ -1963,7 +1974,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         static const bool rows_env = getenv("MMM_LDA_ROWS") == nullptr || atoi(getenv("MMM_LDA_ROWS")) != 0;
         LdaDev edev = m->dev();
-        if (!rows_env) edev.ell = nullptr;
+        if (!rows_env) { edev.ell = nullptr; edev.dense = nullptr; }
         EstepArgs a{edev, m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
@@ -2162,20 +2173,27 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     // dense-row E-step (k_lda_estep_dense): a dense corpus (at least half of the D x V entries present, no term listed twice in a
     // document) of at least 192 documents per CU, topics and vocabulary within the register budget of a lane (SL KP <= 64
     // doubles).  MMM_LDA_DENSE=1 takes it for any corpus that has the shape (tests), 0 never.
-    bool dense = false;
+    // Rows of counts (drows): a dense corpus over <= 128 terms is also kept as rows of 16 SL int32 counts -- 4 bytes per term slot against
+    // 8 per nonzero -- which the single-step E-step build (96-term vocabularies) and the ll blocks read instead of the padded (term,count)
+    // rows: BASELINE config 2 21.2 -> 19.9 us per iteration on the same box.  MMM_LDA_DROWS=0 keeps the (term,count) rows (A/B).
+    bool dense = false, drows = false;
     const int SL = dense_slots(V);
     {
         const char* de = getenv("MMM_LDA_DENSE");
         const int dmode = de ? atoi(de) : -1;
-        const bool shape = SL > 0 && L == 16 && KP >= 4 && KP * SL <= 64 && D > 0 && !getenv("MMM_LDA_WIDE");
+        static const bool drows_env = getenv("MMM_LDA_DROWS") == nullptr || atoi(getenv("MMM_LDA_DROWS")) != 0;
+        const bool rshape = SL > 0 && L == 16 && D > 0 && !getenv("MMM_LDA_WIDE");          // rows of counts make sense
+        const bool shape = rshape && KP >= 4 && KP * SL <= 64;                               // ... and the dense-row E-step build exists
+        const bool dense_enough = 2 * nnz >= (int64_t)D * V;
         bool dup = false;
-        if (shape && dmode != 0) {
+        if (rshape && ((shape && dmode != 0) || (drows_env && dense_enough))) {
             std::vector<int> seen((size_t)V, -1);
             for (int d = 0; d < D && !dup; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) { if (seen[(size_t)term[e]] == d) { dup = true; break; } seen[(size_t)term[e]] = d; }
         }
         const bool big = D >= 192 * ctx->num_cu;      // measured on MI355X (K = 10, V = 96): 40k documents 59.1 vs 58.3 us per iteration for the CSR sweep, 80k 85.6 vs 98.4
-        dense = shape && !dup && dmode != 0 && (dmode > 0 || (big && 2 * nnz >= (int64_t)D * V));
+        dense = shape && !dup && dmode != 0 && (dmode > 0 || (big && dense_enough));
+        drows = drows_env && rshape && !dup && dense_enough;
     }
     const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
                        !getenv("MMM_LDA_WAVES");
@@ -2196,7 +2214,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     mmm_lda* m = guard.get();
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
     m->waves_e = waves; m->lds_e = wide ? 0 : lds_for(waves); m->lds_tab = tabB; m->wide = wide;
-    m->dense = dense && !wide; m->SL = SL;
+    m->dense = dense && !wide; m->SL = SL; m->drows = (dense || drows) && !wide;
     if (const char* s = wide ? nullptr : getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
@@ -2246,7 +2264,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         m->stats_waves = 1;
         while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
     }
-    if (m->dense) {
+    if (m->dense && m->lds_d > 160 * 1024) m->drows = drows && !wide;
+    if (m->drows) {
         const int Vp = 16 * SL;
         std::vector<int> rows((size_t)D * Vp, 0);
         for (int d = 0; d < D; ++d)
@@ -2260,7 +2279,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     {   // padded rows for the ll blocks (V <= 128 slots, no duplicate terms: then a document always fits its row)
         int64_t maxW = 0;
         for (int d = 0; d < D; ++d) maxW = std::max<int64_t>(maxW, doc_ptr[d + 1] - doc_ptr[d]);
-        if (V <= 128 && maxW <= V && D > 0 && !wide && !m->dense) {
+        if (V <= 128 && maxW <= V && D > 0 && !wide && !m->drows) {
             ell.assign((size_t)D * V, make_int2(-1, 0));
             for (int d = 0; d < D; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
