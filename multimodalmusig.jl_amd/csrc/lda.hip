@@ -53,6 +53,7 @@ struct LdaDev {
                           // waiting for doc_ptr (built when V <= 128 and no document lists a term twice)
     const int* dense;     // [D][Vp] rows of counts (the dense-row E-step's corpus), or NULL; the ll blocks then read these instead of ell
     int Vp;
+    const unsigned short* dense16;   // the same rows as 16-bit counts (every count < 65536), or NULL: 2 bytes per term slot
 };
 
 struct LdaCtl {
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
     // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
     // document has the same V / L chunks (static register indices, no per-step shuffles)
-    const bool drows = SINGLE && VT != 0 && VT <= PRE * L && a.c.dense != nullptr;      // rows of counts: term = slot, 4 bytes per slot
+    const bool drows = SINGLE && VT != 0 && VT <= PRE * L && (a.c.dense != nullptr || a.c.dense16 != nullptr);      // rows of counts: term = slot, 4 or 2 bytes per slot
     const bool rows = drows || (SINGLE && VT != 0 && VT <= PRE * L && a.c.ell != nullptr);
     int64_t start = (valid && !rows) ? a.c.doc_ptr[d] : 0;
     int W = (valid && !rows) ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
@@ -313,11 +314,14 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         }
         if (drows) {
             const int* __restrict__ row = a.c.dense + (size_t)(valid ? d : 0) * a.c.Vp;
+            const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid ? d : 0) * a.c.Vp;
+            const bool h16 = a.c.dense16 != nullptr;
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= NCHR) c -= NCHR;
                 const int w = c * L + l;
-                const int n = (valid && j < NCHR && w < VT) ? row[w] : 0;
+                const bool in = valid && j < NCHR && w < VT;
+                const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
                 tcp[j] = make_int2(n > 0 ? w : -1, n);
             }
         } else if (rows) {
@@ -677,13 +681,15 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     bool valid = d < D;
     double gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     constexpr int PRE = 128 / L;          // padded rows: every chunk of the document is requested up front, no doc_ptr needed
-    const bool dense = L == 16 && c.dense != nullptr;       // rows of counts: term = slot index, 4 bytes per slot, table columns read in lane order
+    const bool dense = L == 16 && (c.dense != nullptr || c.dense16 != nullptr);       // rows of counts: term = slot index, 4 or 2 bytes per slot, table columns read in lane order
+    const bool h16 = c.dense16 != nullptr;
     const bool ell = dense || c.ell != nullptr;
     int2 pre[PRE];
     if (dense) {
         const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
+        const unsigned short* __restrict__ row16 = c.dense16 + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
-        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, row[j * L + l]) : make_int2(-1, 0);
+        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[j * L + l] : row[j * L + l]) : make_int2(-1, 0);
     } else if (ell) {
         const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
@@ -707,8 +713,9 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
                 gp = (valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
                 if (dense) {
                     const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
+                    const unsigned short* __restrict__ row16 = c.dense16 + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
-                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, row[j * L + l]) : make_int2(-1, 0);
+                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[j * L + l] : row[j * L + l]) : make_int2(-1, 0);
                 } else {
                     const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
@@ -1623,6 +1630,7 @@ struct mmm_lda {
     double alpha = 0, eta = 0;
     double Nglobal = 0, Dglobal = 0;
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
+    DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits and the dense-row E-step build (which reads cnt_dense) is not in use
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
     bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
     bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
@@ -1661,7 +1669,7 @@ struct mmm_lda {
     IldaDesc ids{};
     DevBuf<int> features;
     DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
-    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, drows ? cnt_dense.p : nullptr, 16 * SL}; }
+    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, (drows && !cnt16.p) ? cnt_dense.p : nullptr, 16 * SL, cnt16.p}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
@@ -1974,7 +1982,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         }
         static const bool rows_env = getenv("MMM_LDA_ROWS") == nullptr || atoi(getenv("MMM_LDA_ROWS")) != 0;
         LdaDev edev = m->dev();
-        if (!rows_env) { edev.ell = nullptr; edev.dense = nullptr; }
+        if (!rows_env) { edev.ell = nullptr; edev.dense = nullptr; edev.dense16 = nullptr; }
         EstepArgs a{edev, m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
@@ -2265,7 +2273,19 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
     }
     if (m->dense && m->lds_d > 160 * 1024) m->drows = drows && !wide;
-    if (m->drows) {
+    static const bool rows16_env = getenv("MMM_LDA_ROWS16") == nullptr || atoi(getenv("MMM_LDA_ROWS16")) != 0;
+    int maxcount = 0;
+    for (int64_t e = 0; e < nnz; ++e) maxcount = std::max(maxcount, count[e]);
+    if (m->drows && !m->dense && rows16_env && maxcount < 65536) {
+        const int Vp = 16 * SL;
+        std::vector<unsigned short> rows((size_t)D * Vp, 0);
+        for (int d = 0; d < D; ++d)
+            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + term[e]] = (unsigned short)count[e];
+        hipError_t e_ = m->cnt16.alloc(rows.size());
+        if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(cnt16): %s", hipGetErrorString(e_)); return rc; }
+        MMM_HIP(ctx, hipMemcpyAsync(m->cnt16.p, rows.data(), sizeof(unsigned short) * rows.size(), hipMemcpyHostToDevice, st));
+        MMM_HIP(ctx, hipStreamSynchronize(st));
+    } else if (m->drows) {
         const int Vp = 16 * SL;
         std::vector<int> rows((size_t)D * Vp, 0);
         for (int d = 0; d < D; ++d)
