@@ -467,7 +467,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
 // of the term-major table and 2 KP + 16 f64 instructions; no atomics in the loop.  HBM per document: 4 Vp bytes of counts instead of
 // 8 bytes per nonzero.  Same formulas as k_lda_estep (LDA.jl:69-108); the sums are associated per lane, then lanes, waves, blocks.
 template <int KP, int SL>
-__global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt)
+__global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int L = 16, G = MMM_WAVE / L, Vp = L * SL;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
     double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     int c[SL];
 #pragma unroll
-    for (int q = 0; q < SL; ++q) c[q] = valid ? cnt[(size_t)d * Vp + q * L + l] : 0;
+    for (int q = 0; q < SL; ++q) c[q] = valid ? (cnt16 ? (int)cnt16[(size_t)d * Vp + q * L + l] : cnt[(size_t)d * Vp + q * L + l]) : 0;
     for (int i = tid; i < Vp * KP; i += blockDim.x) {
         const int v = i / KP, k = i % KP;
         sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         int cn[SL];
         if (validn && l < K) gkn = gam[(size_t)dn * K + l];
 #pragma unroll
-        for (int q = 0; q < SL; ++q) cn[q] = validn ? cnt[(size_t)dn * Vp + q * L + l] : 0;
+        for (int q = 0; q < SL; ++q) cn[q] = validn ? (cnt16 ? (int)cnt16[(size_t)dn * Vp + q * L + l] : cnt[(size_t)dn * Vp + q * L + l]) : 0;
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k)
         const double S = group_sum<L>(gk);
         const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
@@ -1630,7 +1630,7 @@ struct mmm_lda {
     double alpha = 0, eta = 0;
     double Nglobal = 0, Dglobal = 0;
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
-    DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits and the dense-row E-step build (which reads cnt_dense) is not in use
+    DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits (then cnt_dense is not built)
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
     bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
     bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
@@ -1750,7 +1750,7 @@ int go_dense(mmm_lda* m, const EstepArgs& a)
         mmm_ctx* ctx = m->ctx;
         auto k = k_lda_estep_dense<KPV, SLV>;
         if (!m->attr_d) { int rc = set_lds(ctx, k, m->lds_d); if (rc) return rc; m->attr_d = true; }
-        hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p);
+        hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p, (const unsigned short*)m->cnt16.p);
         return MMM_OK;
     } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no dense-row build for KP=%d SL=%d", KPV, SLV);
 }
@@ -2276,7 +2276,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     static const bool rows16_env = getenv("MMM_LDA_ROWS16") == nullptr || atoi(getenv("MMM_LDA_ROWS16")) != 0;
     int maxcount = 0;
     for (int64_t e = 0; e < nnz; ++e) maxcount = std::max(maxcount, count[e]);
-    if (m->drows && !m->dense && rows16_env && maxcount < 65536) {
+    if (m->drows && rows16_env && maxcount < 65536) {
         const int Vp = 16 * SL;
         std::vector<unsigned short> rows((size_t)D * Vp, 0);
         for (int d = 0; d < D; ++d)
