@@ -261,6 +261,25 @@ def test_random_shapes_every_estep_build_against_oracle(mmm, oracle, monkeypatch
         g.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_DROWS": "0"}, {"MMM_LDA_ROWS16": "0"}, {"MMM_LDA_ROWS": "0"}])
+def test_rows_of_counts_with_a_count_beyond_16_bits(mmm, oracle, monkeypatch, env):
+    """Dense corpora are also kept as rows of counts (16-bit where every count fits, else 32-bit) for the single-step E-step build, the ll
+    blocks and the dense-row build; one count of 70,000 forces the 32-bit rows; every switch that selects another data path gives the
+    oracle's fit."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for big in (False, True):
+        X, lam0 = np_ref.synth_lda(300, 96, 10, seed=21, mean_n=900)
+        if big:
+            X[5][0, 1] = 70000
+        g = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
+        o = oracle.LdaOracle(10, 0.1, 0.1, X, V=96, lambda0=lam0)
+        np.testing.assert_allclose(mmm.fit(g, maxiter=10, tol=0.0, verbose=False), o.fit(maxiter=10, tol=0.0), rtol=1e-9)
+        np.testing.assert_allclose(g.λ, o.lam.reshape(96, 10, order="F"), rtol=1e-9)
+        np.testing.assert_allclose(g.γ, o.gamma.reshape(300, 10).T, rtol=1e-9)
+        g.close()
+
+
 def test_dense_row_build_is_not_taken_for_sparse_or_duplicated_rows(mmm, oracle, monkeypatch):
     """Documents that list a term twice (the reference treats the rows separately) or a sparse corpus keep the CSR sweep."""
     monkeypatch.setenv("MMM_LDA_DENSE", "1")
