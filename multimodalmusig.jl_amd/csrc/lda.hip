@@ -270,8 +270,8 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
     // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
     // document has the same V / L chunks (static register indices, no per-step shuffles)
-    const bool drows = SINGLE && VT != 0 && VT <= PRE * L && (a.c.dense != nullptr || a.c.dense16 != nullptr);      // rows of counts: term = slot, 4 or 2 bytes per slot
-    const bool rows = drows || (SINGLE && VT != 0 && VT <= PRE * L && a.c.ell != nullptr);
+    const bool drows = VT != 0 && VT <= PRE * L && (a.c.dense != nullptr || a.c.dense16 != nullptr);      // rows of counts: term = slot, 4 or 2 bytes per slot
+    const bool rows = drows || (VT != 0 && VT <= PRE * L && a.c.ell != nullptr);      // (the grid-stride build requests the next step's row a step ahead)
     int64_t start = (valid && !rows) ? a.c.doc_ptr[d] : 0;
     int W = (valid && !rows) ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
     // SINGLE: the table stays in registers (<= 5 entries per thread: KP*V <= 12 * 96, >= 4 waves) until just before the barrier, so
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     int d1 = 0; bool valid1 = false; int64_t start1 = 0; int W1 = 0;
     if (!SINGLE) {
         d1 = base + stride + g; valid1 = (base + stride < D) && d1 < D;
-        start1 = valid1 ? a.c.doc_ptr[d1] : 0;
-        W1 = valid1 ? (int)(a.c.doc_ptr[d1 + 1] - start1) : 0;
+        start1 = (valid1 && !rows) ? a.c.doc_ptr[d1] : 0;
+        W1 = (valid1 && !rows) ? (int)(a.c.doc_ptr[d1 + 1] - start1) : 0;
     }
     int2 tcp[PRE];                           // (term,count) of the first PRE chunks of the current step
     bool first = true;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             if (G >= 4) nchmax = max(nchmax, __shfl_xor(nchmax, 16, MMM_WAVE));
             nchmax = __builtin_amdgcn_readfirstlane(nchmax);
         }
-        if (drows) {
+        if (drows && (SINGLE || first)) {
             const int* __restrict__ row = a.c.dense + (size_t)(valid ? d : 0) * a.c.Vp;
             const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid ? d : 0) * a.c.Vp;
             const bool h16 = a.c.dense16 != nullptr;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
                 const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
                 tcp[j] = make_int2(n > 0 ? w : -1, n);
             }
-        } else if (rows) {
+        } else if (rows && !drows && (SINGLE || first)) {
             const int2* __restrict__ row = a.c.ell + (size_t)(valid ? d : 0) * VT;
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
                 const int w = c * L + l;
                 tcp[j] = (valid && j < NCHR && w < VT) ? row[w] : make_int2(-1, 0);
             }
-        } else if (SINGLE || first) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
+        } else if (!rows && (SINGLE || first)) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= nch) c -= nch;
@@ -368,20 +368,42 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
         int d2 = 0; bool valid2 = false; int64_t start2 = 0; int W2 = 0;
         const bool more = !SINGLE && base + stride < D;
         if (more) {
-            const int nch1 = (W1 + L - 1) / L;
+            const int nch1 = rows ? NCHR : (W1 + L - 1) / L;
             const int rot1 = nch1 > 0 ? g % nch1 : 0;
             const int2* __restrict__ tcd1 = a.c.tc + start1;
+            if (drows) {
+                const int* __restrict__ row = a.c.dense + (size_t)(valid1 ? d1 : 0) * a.c.Vp;
+                const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid1 ? d1 : 0) * a.c.Vp;
+                const bool h16 = a.c.dense16 != nullptr;
+#pragma unroll
+                for (int j = 0; j < PRE; ++j) {
+                    int c = j + rot1; if (c >= NCHR) c -= NCHR;
+                    const int w = c * L + l;
+                    const bool in = valid1 && j < NCHR && w < VT;
+                    const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
+                    tcn[j] = make_int2(n > 0 ? w : -1, n);
+                }
+            } else if (rows) {
+                const int2* __restrict__ row = a.c.ell + (size_t)(valid1 ? d1 : 0) * VT;
+#pragma unroll
+                for (int j = 0; j < PRE; ++j) {
+                    int c = j + rot1; if (c >= NCHR) c -= NCHR;
+                    const int w = c * L + l;
+                    tcn[j] = (valid1 && j < NCHR && w < VT) ? row[w] : make_int2(-1, 0);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot1; if (c >= nch1) c -= nch1;
                 const int w = c * L + l;
                 tcn[j] = ((j < nch1) && (w < W1)) ? tcd1[w] : make_int2(-1, 0);
             }
+            }
             gkn = (valid1 && l < K) ? gam[(size_t)d1 * K + l] : (l < K ? 1.0 : 0.0);
             gpn = (LL && valid1 && l < K) ? gprev[(size_t)d1 * K + l] : (l < K ? 1.0 : 0.0);
             d2 = base + 2 * stride + g; valid2 = (base + 2 * stride < D) && d2 < D;
-            start2 = valid2 ? a.c.doc_ptr[d2] : 0;
-            W2 = valid2 ? (int)(a.c.doc_ptr[d2 + 1] - start2) : 0;
+            start2 = (valid2 && !rows) ? a.c.doc_ptr[d2] : 0;
+            W2 = (valid2 && !rows) ? (int)(a.c.doc_ptr[d2 + 1] - start2) : 0;
         }
         {
             double av[KP], acc[KP];
