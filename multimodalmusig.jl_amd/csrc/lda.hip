@@ -270,8 +270,8 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
     // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
     // document has the same V / L chunks (static register indices, no per-step shuffles)
-    const bool drows = VT != 0 && VT <= PRE * L && (a.c.dense != nullptr || a.c.dense16 != nullptr);      // rows of counts: term = slot, 4 or 2 bytes per slot
-    const bool rows = drows || (VT != 0 && VT <= PRE * L && a.c.ell != nullptr);      // (the grid-stride build requests the next step's row a step ahead)
+    const bool drows = V <= PRE * L && (a.c.dense != nullptr || a.c.dense16 != nullptr);      // rows of counts: term = slot, 4 or 2 bytes per slot
+    const bool rows = drows || (V <= PRE * L && a.c.ell != nullptr);      // (the grid-stride build requests the next step's row a step ahead)
     int64_t start = (valid && !rows) ? a.c.doc_ptr[d] : 0;
     int W = (valid && !rows) ? (int)(a.c.doc_ptr[d + 1] - start) : 0;
     // SINGLE: the table stays in registers (<= 5 entries per thread: KP*V <= 12 * 96, >= 4 waves) until just before the barrier, so
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     bool first = true;
     for (;;) {
         // ---- groups start at rotated chunks so that the G documents of a wave instruction touch different term ranges of the slab
-        constexpr int NCHR = VT ? (VT + L - 1) / L : 1;      // chunks of a padded row
+        const int NCHR = VT ? (VT + L - 1) / L : (V + L - 1) / L;      // chunks of a padded row (<= PRE)
         const int nch = rows ? NCHR : (W + L - 1) / L;
         const int rot = nch > 0 ? g % nch : 0;
         const int2* __restrict__ tcd = a.c.tc + start;
@@ -320,17 +320,17 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= NCHR) c -= NCHR;
                 const int w = c * L + l;
-                const bool in = valid && j < NCHR && w < VT;
+                const bool in = valid && j < NCHR && w < V;
                 const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
                 tcp[j] = make_int2(n > 0 ? w : -1, n);
             }
         } else if (rows && !drows && (SINGLE || first)) {
-            const int2* __restrict__ row = a.c.ell + (size_t)(valid ? d : 0) * VT;
+            const int2* __restrict__ row = a.c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= NCHR) c -= NCHR;
                 const int w = c * L + l;
-                tcp[j] = (valid && j < NCHR && w < VT) ? row[w] : make_int2(-1, 0);
+                tcp[j] = (valid && j < NCHR && w < V) ? row[w] : make_int2(-1, 0);
             }
         } else if (!rows && (SINGLE || first)) {               // first step: loads issued before the prologue math (later steps: requested a step ahead)
 #pragma unroll
@@ -379,17 +379,17 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
                 for (int j = 0; j < PRE; ++j) {
                     int c = j + rot1; if (c >= NCHR) c -= NCHR;
                     const int w = c * L + l;
-                    const bool in = valid1 && j < NCHR && w < VT;
+                    const bool in = valid1 && j < NCHR && w < V;
                     const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
                     tcn[j] = make_int2(n > 0 ? w : -1, n);
                 }
             } else if (rows) {
-                const int2* __restrict__ row = a.c.ell + (size_t)(valid1 ? d1 : 0) * VT;
+                const int2* __restrict__ row = a.c.ell + (size_t)(valid1 ? d1 : 0) * V;
 #pragma unroll
                 for (int j = 0; j < PRE; ++j) {
                     int c = j + rot1; if (c >= NCHR) c -= NCHR;
                     const int w = c * L + l;
-                    tcn[j] = (valid1 && j < NCHR && w < VT) ? row[w] : make_int2(-1, 0);
+                    tcn[j] = (valid1 && j < NCHR && w < V) ? row[w] : make_int2(-1, 0);
                 }
             } else {
 #pragma unroll
