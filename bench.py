@@ -10,17 +10,25 @@ LDA.jl:201-209, MMCTM.jl:462-479, IMMCTM.jl:440-451) over one batch of synthetic
   --scaling weak        (default) every rank holds its own corpus of the configuration's size
   --scaling strong      the ONE corpus of the configuration's size, documents sharded over the ranks (balanced by nonzeros)
 
-N > 1: one all-reduce of the packed sufficient statistics and of the ll numerators per iteration (xGMI mailboxes, ncclAllReduce
-as fallback; the line reports which in config.allreduce).
+The default invocation (config 2) also measures configs 4 and 5 for a bounded number of steps and attaches them to the same JSON
+line under "also" (--no-also switches that off); the headline keys are config 2's.
+
+N > 1: one process per GPU.  `python3 bench.py --gpus N` starts its N rank processes ITSELF (children of a parent that never touches
+the GPU; rank r -> device r mod #devices) and relays rank 0's line; under `python -m torch.distributed.run` (WORLD_SIZE set by the
+launcher) the process is a rank and starts nothing.  One all-reduce of the packed sufficient statistics and of the ll numerators per
+iteration (xGMI mailboxes, ncclAllReduce as fallback; the line reports which, per rank, in config.allreduce_per_rank).  Ranks that have to
+share a card (more ranks than devices: a one-card rehearsal of the N > 1 path) talk over gloo on the host side and set the mailboxes
+up from host-exchanged IPC handles -- RCCL refuses two ranks on one device.
 
 Contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over
 ranks.  That timed region is repeated R times (--repeats, default 9): `ms_per_step` / `value` are the MEDIAN region, min / max beside
-them (a 20-step region of config 2 lasts 0.5 ms; one region alone carries the +-40 us of the bracketing synchronisations).
+them (a 20-step region of config 2 lasts 0.4 ms; one region alone carries the +-40 us of the bracketing synchronisations).
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +41,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-F64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz: 39.3 T fma/s
+F64_VALU_PEAK_TF = 78.6     # MI355X vector FP64; 256 CUs x 4 SIMD x 16 f64 lanes x 2.4 GHz x 2 flop
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
+SCLK_HZ = 2.4e9
 
 CONFIGS = {
     2: dict(model="lda", K=10, V=96, docs=10000, name="LDA K=10 alpha=eta=0.1, %d docs x 96 SNV terms (BASELINE configs[1])"),
@@ -165,61 +175,149 @@ def parity_probe_ctm(pkg, cfg, seed):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps iterations each; the median is reported")
-    ap.add_argument("--docs", type=int, default=0, help="documents per GPU (weak) / in total (strong); default: the configuration's size")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    if args.steps is None:
-        args.steps = 50 if cfg["model"] == "lda" else 10
-    if args.warmup is None:
-        args.warmup = 5 if cfg["model"] == "lda" else 2
+# ----------------------------------------------------------------------------------------------------------- self-launch
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
 
-    import numpy as np
-    import torch                       # first: the library then binds to the HIP runtime torch has loaded
-    import torch.distributed as dist
-    import mmm_pkg
+
+def launch_ranks(n, argv, timeout_s):
+    """`python3 bench.py --gpus N` without a launcher: start the N rank processes as CHILDREN (this parent has made no GPU call --
+    nothing above imports torch or loads the library), relay rank 0's JSON line, fail if any rank fails or the job times out."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MMM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    deadline = time.time() + timeout_s
+    out0 = ""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 124
+        print("bench.py: the %d-rank job did not finish within %d s" % (n, timeout_s), file=sys.stderr)
+    finally:
+        for p in procs:
+            if p.poll() is None:       # exactly the processes started above, by handle
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pass
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if bad or rc or not line:
+        print("bench.py: rank exit codes %s%s" % (bad, "" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
+        sys.stdout.write(out0 or "")
+        sys.exit(rc or (bad[0][1] if bad else 1) or 1)
+    print(line[-1])
+    sys.exit(0)
+
+
+class Env:
+    """process group, device and library context of one rank"""
+
+    def __init__(self, gpus):
+        import numpy as np
+        import torch                       # first: the library then binds to the HIP runtime torch has loaded
+        import torch.distributed as dist
+        import mmm_pkg
+        self.np, self.torch, self.dist = np, torch, dist
+        self.pkg = pkg = mmm_pkg.load()
+        self.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != gpus:
+            if rank == 0:
+                print("bench.py: --gpus %d but WORLD_SIZE=%d" % (gpus, world), file=sys.stderr)
+            sys.exit(2)
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            print("bench.py: no GPU visible; the HIP path is the only path", file=sys.stderr)
+            sys.exit(3)
+        self.ndev = ndev
+        self.device = local % ndev
+        self.shared_card = world > ndev          # several ranks per device: host-side gloo + host-exchanged mailbox handles
+        torch.cuda.set_device(self.device)
+        self.ctx = ctx = pkg.Context(self.device)
+        self.cuda_pg = False
+        if world > 1 and not self.shared_card:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            self.cuda_pg = True
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.init_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        elif world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ctx.init_p2p(world, rank, self.allgather_obj, lambda v: min(self.allgather_obj(int(v))))
+        elif os.environ.get("MMM_FORCE_RCCL"):
+            # single-GPU rehearsal of the collective path: a one-rank communicator, every all-reduce goes through RCCL
+            ctx.init_comm(1, 0, pkg.comm_unique_id())
+
+    def allgather_obj(self, o):
+        if self.world == 1:
+            return [o]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, o)
+        return out
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def bcast(self, arr):
+        """rank 0's float64 array on every rank"""
+        if self.world == 1:
+            return arr
+        t = self.torch.from_numpy(self.np.ascontiguousarray(arr))
+        if self.cuda_pg:
+            t = t.cuda()
+        self.dist.broadcast(t, 0)
+        return t.cpu().numpy()
+
+    def allmax(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.cuda_pg else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def load_pmc(tname):
+    """committed counter summary (rocprofv3 --pmc passes of this command, tools/pmc_run.sh + tools/pmc_summary.py) of the dominant kernel"""
+    for rnd in ("r03", "r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, tname))
+        if os.path.exists(tp):
+            return json.load(open(tp)), os.path.basename(tp)
+    return None, None
+
+
+def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline, cpu_target_s=None):
+    """Measure one configuration on the ranks of `env`; rank 0 gets the result dictionary, the others None."""
+    np, pkg, ctx, world, rank = env.np, env.pkg, env.ctx, env.world, env.rank
     import np_ref
-    pkg = mmm_pkg.load()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local)
-    ctx = pkg.Context(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        ctx.init_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
-    elif os.environ.get("MMM_FORCE_RCCL"):
-        # single-GPU rehearsal of the collective path: a one-rank communicator, every all-reduce goes through RCCL
-        ctx.init_comm(1, 0, pkg.comm_unique_id())
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    cfg = CONFIGS[cfg_id]
     # ---- corpus: SURVEY section 8d generator, corpus seed = 20261003 + config index; weak: every rank its own corpus (seed + 1000 rank),
     # strong: every rank generates the one corpus and keeps its nnz-balanced contiguous shard
-    Dcfg = args.docs or cfg["docs"]
-    seed = 20261003 + (1 if args.config == 2 else args.config)
+    Dcfg = docs or cfg["docs"]
+    seed = 20261003 + (1 if cfg_id == 2 else cfg_id)
     K, V = cfg["K"], cfg["V"]
-    corpus_seed = seed + (1000 * rank if args.scaling == "weak" else 0)
+    corpus_seed = seed + (1000 * rank if scaling == "weak" else 0)
     if cfg["model"] == "lda":
         X, init = np_ref.synth_lda(Dcfg, V, K, seed=corpus_seed)
     else:
@@ -227,18 +325,14 @@ def main():
         if cfg["model"] == "immctm":
             GM = sum(K[i] * int(f.max(axis=0).sum()) for i, f in enumerate(snv3()))
             init = np.random.default_rng(1).integers(1, 101, size=GM).astype(np.float64)
-    if args.scaling == "strong" and world > 1:
+    if scaling == "strong" and world > 1:
         d0, d1 = pkg.shard_documents(X, world, rank)
         X = X[d0:d1]
     D = len(X)
     if world > 1 and cfg["model"] == "lda":                  # same lambda0 everywhere: take rank 0's
-        t = torch.from_numpy(np.ascontiguousarray(init)).cuda()
-        dist.broadcast(t, 0)
-        init = t.cpu().numpy()
+        init = env.bcast(init)
     elif world > 1 and cfg["model"] == "mmctm":
-        t = torch.from_numpy(np.concatenate([g.ravel() for g in init])).cuda()
-        dist.broadcast(t, 0)
-        flat = t.cpu().numpy(); o = 0; new = []
+        flat = env.bcast(np.concatenate([g.ravel() for g in init])); o = 0; new = []
         for g in init:
             new.append(flat[o:o + g.size].reshape(g.shape).copy()); o += g.size
         init = new
@@ -248,7 +342,7 @@ def main():
         model = pkg.LDA(K, alpha, eta, V, X, λ0=init, ctx=ctx)
         nnz = int(model._doc_ptr[-1])
 
-        def steps(n):
+        def run(n):
             pkg._lib.check(lib.mmm_lda_iterate(model._h, n), ctx.h, "mmm_lda_iterate")
     else:
         alpha = [0.1] * len(K)
@@ -258,76 +352,98 @@ def main():
             model = pkg.IMMCTM(K, alpha, snv3(), X, γ0=init, ctx=ctx)
         nnz = int(sum(model._nnz))
 
-        def steps(n):
+        def run(n):
             pkg._lib.check(lib.mmm_ctm_iterate(model._h, n, 1), ctx.h, "mmm_ctm_iterate")
 
-    steps(args.warmup)
+    run(warmup)
     regions = []
-    for _ in range(max(1, args.repeats)):
-        barrier()
+    for _ in range(max(1, repeats)):
+        env.barrier()
         t0 = time.perf_counter()
-        steps(args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        regions.append(dt)
+        run(steps)
+        env.barrier()
+        regions.append(env.allmax(time.perf_counter() - t0))
     dt = float(np.median(regions))
 
-    # Dominant-kernel duration: the same K steps again with every launch of the dominant kernel bracketed by a HIP event pair on
-    # the library's stream.  Kept out of the timed regions above because each hipEventRecord opens a ~5.6 us bubble in the otherwise
-    # back-to-back kernel stream (rocprofv3 trace: profiles/), i.e. +25 % on config 2's ms_per_step.
-    ctx.profile_begin()
-    steps(args.steps)
-    n_launch, k_ms = ctx.profile_end()
-    span1 = (k_ms / max(n_launch, 1)) * 1e-3
+    # Per-kernel durations: the same K steps again with the launches of one phase of the pass bracketed by a HIP event pair on the
+    # library's stream (mmm_ctx_profile_select).  Kept out of the timed regions above because each hipEventRecord opens a ~5.6 us bubble
+    # in the otherwise back-to-back kernel stream (rocprofv3 trace: profiles/), i.e. +25 % on config 2's ms_per_step.
+    def span_us(phase, repeat=1):
+        ctx.profile_begin(repeat=repeat, phase=phase)
+        run(steps)
+        n, ms = ctx.profile_end()
+        return n, (ms / max(n, 1)) * 1e3
+
+    n_launch, span1 = span_us(0)
+    phases = {}
     if cfg["model"] == "lda":
-        # ... and once more with the (idempotent) kernel launched twice inside every span: the difference of the two spans is the
-        # kernel's own duration, without the ~4 us an event pair adds around a single launch (what rocprofv3 reports)
-        ctx.profile_begin(repeat=2)
-        steps(args.steps)
-        n_launch2, k_ms2 = ctx.profile_end()
-        ctx.profile_begin(repeat=1); ctx.profile_end()
-        span2 = (k_ms2 / max(n_launch2, 1)) * 1e-3
-        avg_s = span2 - span1 if span2 > span1 > 0 else span1
+        # ... and once more with the (idempotent) E-step kernel launched twice inside every span: the difference of the two spans is
+        # the kernel's own duration, without the ~4 us an event pair adds around a single launch (what rocprofv3 reports)
+        _, span2 = span_us(0, repeat=2)
+        avg_us = span2 - span1 if span2 > span1 > 0 else span1
+        pair_us = max(span1 - avg_us, 0.0)               # what an event pair adds around one launch
+        _, tail = span_us(1)
+        phases = {"estep": avg_us, "reduce_ll_mstep": max(tail - pair_us, 0.0)}
     else:
         span2 = None
-        avg_s = span1        # a millisecond kernel: the ~4 us of the event pair are < 0.5 %
+        avg_us = span1        # a millisecond kernel: the ~4 us of the event pair are < 0.5 %
+        phases = {"solve": span1, "theta": span_us(1)[1], "moments_reduce_topics": span_us(2)[1], "gauss_props_loglik": span_us(3)[1]}
+    ctx.profile_begin(repeat=1, phase=0); ctx.profile_end()
+    avg_s = avg_us * 1e-6
 
+    transports = env.allgather_obj(ctx.transport)
+    nranks_seen = env.allgather_obj(int(lib.mmm_comm_nranks(ctx.h)))
+    docs_per_rank = env.allgather_obj(D)
+    res = None
     if rank == 0:
-        docs_step = (D * world) if args.scaling == "weak" else Dcfg
-        Dtot = docs_step
+        docs_step = sum(docs_per_rank)
+        ms_step = dt / steps * 1e3
         res = {
-            "metric": "E-step docs/sec", "value": docs_step * args.steps / dt, "unit": "docs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "ms_per_step_min": min(regions) / args.steps * 1e3, "ms_per_step_max": max(regions) / args.steps * 1e3, "repeats": len(regions),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (cfg["name"] % Dcfg) + (" per GPU" if args.scaling == "weak" and world > 1 else "") +
+            "metric": "E-step docs/sec", "value": docs_step * steps / dt, "unit": "docs/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": ms_step,
+            "ms_per_step_min": min(regions) / steps * 1e3, "ms_per_step_max": max(regions) / steps * 1e3, "repeats": len(regions),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (cfg["name"] % Dcfg) + (" per GPU" if scaling == "weak" and world > 1 else "") +
                                    ", nnz(rank 0)=%d, one EM iteration per step" % nnz,
-                       "docs_rank0": D, "docs_total": Dtot, "terms": V, "topics": K,
-                       "sharding": "docs x%d (%s)" % (world, args.scaling), "allreduce": ctx.transport},
+                       "docs_rank0": D, "docs_total": docs_step, "docs_per_rank": docs_per_rank, "terms": V, "topics": K,
+                       "sharding": "docs x%d (%s)" % (world, scaling), "allreduce": ctx.transport, "allreduce_per_rank": transports,
+                       "comm_nranks": nranks_seen[0], "comm_nranks_per_rank": nranks_seen,
+                       "devices_visible": env.ndev, "ranks_share_a_card": bool(env.shared_card)},
         }
+        if scaling == "strong" and world > 1:
+            res["config"]["note"] = ("strong scaling of a %d-document corpus: the per-iteration exchange has a fixed latency of the order of the "
+                                     "iteration itself, so the 10k-document LDA corpus cannot speed up 6x on 8 GPUs; weak scaling is the "
+                                     "curve that can" % Dcfg)
+        res["iteration"] = {"kernel_us": phases, "sum_kernel_us": sum(phases.values()), "ms_per_step_us": ms_step * 1e3,
+                            "kernel_fraction_of_step": sum(phases.values()) / (ms_step * 1e3) if ms_step > 0 else None,
+                            "timing": "HIP-event spans per phase of the pass (mmm_ctx_profile_select) in repeats of the timed K steps; LDA spans "
+                                      "are corrected by the event-pair overhead measured differentially on the E-step kernel"}
         if cfg["model"] == "lda":
             ll = np.zeros(1); n = pkg._lib.C.c_int()
             pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
             res["ll_last"] = float(ll[0])
-            # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch: 8 B per nonzero
-            # (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in registers, the
-            # topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
+            # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch by SURVEY section 8d's
+            # figure: 8 B per nonzero (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in
+            # registers, the topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
             # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
+            # As implemented the kernel may read rows of counts instead of (term,count) pairs: 16 SL slots of 2 or 4 bytes per document.
             algo_bytes = 8.0 * nnz + 24.0 * K * D
             geo = model.geometry()
-            kname = ("k_lda_estep_dense<%d,%d> (rows of counts, 4 B per term slot: the kernel moves %d B per document where the CSR figure "
-                     "counts 8 B per nonzero)" % (geo["KP"], geo["SL"], 4 * 16 * geo["SL"] + 24 * K)) if geo["dense"] else \
+            row_bytes = geo.get("row_bytes", 0)
+            impl_bytes = (float(row_bytes) * D if row_bytes else 8.0 * nnz) + 24.0 * K * D
+            kname = ("k_lda_estep_dense<%d,%d> (rows of counts)" % (geo["KP"], geo["SL"])) if geo["dense"] else \
                     ("k_lda_estep<%d,%d,..,%s>" % (geo["KP"], geo["L"], "single step" if geo["single_step"] else "grid stride"))
             achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+            achieved_impl = impl_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": kname, "launches": n_launch, "avg_us": avg_s * 1e6,
+                               "kernel": kname, "launches": n_launch, "avg_us": avg_us,
                                "algorithmic_bytes_per_launch": algo_bytes,
-                               "event_span_1_launch_us": span1 * 1e6, "event_span_2_launches_us": span2 * 1e6,
+                               "algorithmic_bytes_as_implemented": impl_bytes, "achieved_as_implemented": achieved_impl,
+                               "frac_as_implemented": achieved_impl / HBM_PEAK_GBS,
+                               "bytes_model": "SURVEY 8d: 8 B x nnz + 24 B x K x D.  As implemented: %s + 24 B x K x D" %
+                                              (("%d B per document (rows of counts / padded rows)" % row_bytes) if row_bytes else "8 B x nnz"),
+                               "event_span_1_launch_us": span1, "event_span_2_launches_us": span2,
                                "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
                                          "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"}
             tname = "lda_estep"
@@ -344,7 +460,8 @@ def main():
             tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
             res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "k_ctm_estep<L,1,...> (solve phase: update_nu! + update_lambda!)", "launches": n_launch, "avg_us": avg_s * 1e6,
+                               "kernel": "solve phase (update_nu! + update_lambda!): %d lanes per document, %d coordinate(s) per lane" % (model.geometry()["Ls"], max(model.geometry()["cpl"], 1)),
+                               "launches": n_launch, "avg_us": avg_us,
                                "algorithmic_bytes_per_launch": algo_bytes,
                                "f64_valu": {"achieved": tf, "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TF,
                                             "flops_per_launch": flops,
@@ -352,27 +469,76 @@ def main():
                                             "mma_evaluations_per_document": (st["n_eval_nu"] + st["n_eval_lambda"]) / max(D, 1)},
                                "timing": "HIP events on the library's stream around the kernel, inside a repeat of the timed K steps"}
             res["n_capped"] = st["n_capped"]
-            tname = "ctm_solve_cfg%d" % args.config
-        tp = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % tname)
-        if not os.path.exists(tp):
-            tp = os.path.join(ROOT, "profiles", "r01_traffic_%s.json" % tname)
-        if world == 1 and D == cfg["docs"] and os.path.exists(tp):
-            tr = json.load(open(tp))
+            tname = "ctm_solve_cfg%d" % cfg_id
+        tr, tfile = load_pmc(tname)
+        if world == 1 and D == cfg["docs"] and tr:
             res["roofline"]["traffic"] = tr["hbm_bytes_per_launch_gfx950_corrected"]
-            res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + os.path.basename(tp)
+            res["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch_gfx950_corrected"] / algo_bytes
+            res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + tfile
+            cnt = tr.get("counters_per_launch", {})
+            if cfg["model"] == "lda" and cnt.get("SQ_INSTS_VALU") and avg_s > 0:
+                # the ceiling that binds a cache-resident 11-MB working set: vector instruction issue.  A wave's VALU instruction occupies its
+                # SIMD for 4 cycles (64 lanes over 16-lane f64 pipes: f64 FMA / DPP moves take longer, so this is a lower bound of the busy time)
+                inst = float(cnt["SQ_INSTS_VALU"])
+                floor_us = inst * 4.0 / N_SIMD / SCLK_HZ * 1e6
+                res["roofline"]["f64_valu"] = {"valu_wave_instructions_per_launch": inst, "issue_floor_us": floor_us, "frac": floor_us / avg_us,
+                                               "unit": "fraction of the kernel's duration that the vector pipes need at 4 cycles per wave instruction, "
+                                                       "evenly spread over %d SIMDs at %.1f GHz" % (N_SIMD, SCLK_HZ / 1e9),
+                                               "source": "SQ_INSTS_VALU of profiles/" + tfile}
         if world == 1:
             if cfg["model"] == "lda":
                 res.update(parity_probe_lda(pkg, K, 0.1, 0.1, V, seed + 7))
             else:
                 res.update(parity_probe_ctm(pkg, cfg, seed + 7))
-            if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline_lda(X, init, K, 0.1, 0.1) if cfg["model"] == "lda" else cpu_baseline_ctm(cfg, X, init)
+            if cpu_baseline:
+                kw = {} if cpu_target_s is None else {"target_s": cpu_target_s}
+                res["cpu_baseline"] = cpu_baseline_lda(X, init, K, 0.1, 0.1, **kw) if cfg["model"] == "lda" else cpu_baseline_ctm(cfg, X, init, **kw)
                 res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
     model.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps iterations each; the median is reported")
+    ap.add_argument("--docs", type=int, default=0, help="documents per GPU (weak) / in total (strong); default: the configuration's size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="default invocation only: do not attach configs 4 and 5 under \"also\"")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="self-launched --gpus N: seconds before the ranks are killed")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout)       # never returns; no GPU call has been made by this process
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 50 if cfg["model"] == "lda" else 10
+    if args.warmup is None:
+        args.warmup = 5 if cfg["model"] == "lda" else 2
+
+    env = Env(args.gpus)
+    res = run_config(env, args.config, args.scaling, args.steps, args.warmup, args.repeats, args.docs, not args.no_cpu_baseline)
+    # the other two throughput configurations of BASELINE.json, bounded, on the same ranks, in the same line
+    if args.config == 2 and not args.docs and not args.no_also:
+        also = {}
+        for c in (4, 5):
+            t0 = time.perf_counter()
+            try:
+                r = run_config(env, c, args.scaling, 10, 2, 5, 0, not args.no_cpu_baseline, cpu_target_s=8.0)
+            except Exception as e:       # noqa: BLE001 -- the headline stands on its own
+                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            if env.rank == 0:
+                r["wall_s_including_corpus_generation_and_cpu_baseline"] = time.perf_counter() - t0
+                also["cfg%d" % c] = r
+        if env.rank == 0:
+            res["also"] = also
+    if env.rank == 0:
+        print(json.dumps(res))
+        sys.stdout.flush()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -41,6 +41,7 @@ extern "C" {
 
 enum {
     MMM_OK = 0,
+    MMM_DEFERRED = 1,         /* mmm_ctx_destroy with live models: communicator and mailboxes released now, the rest with the last model */
     MMM_ERR_ARG = -1,         /* bad argument / inconsistent sizes                         */
     MMM_ERR_HIP = -2,         /* a HIP runtime call failed (message has hipGetErrorString) */
     MMM_ERR_RCCL = -3,        /* an RCCL call failed                                       */
@@ -57,6 +58,8 @@ typedef struct mmm_ctm mmm_ctm;
 int mmm_version(void);
 /* Create a context on HIP device `device_id` with its own non-blocking stream. */
 int mmm_ctx_create(int device_id, mmm_ctx** out);
+/* With models still alive on it (a garbage-collected host destroys in no particular order) the context gives up its communicator and
+ * mailboxes at once and returns MMM_DEFERRED; stream and memory go with the last mmm_*_destroy.  Such models may be destroyed, not used. */
 int mmm_ctx_destroy(mmm_ctx* ctx);
 /* Message of the last error on this ctx (ctx == NULL: last error of a failed mmm_ctx_create). */
 const char* mmm_last_error(const mmm_ctx* ctx);
@@ -71,6 +74,10 @@ int mmm_ctx_profile_begin(mmm_ctx* ctx);
 /* repeat = 2: every profiled span holds the (idempotent) LDA E-step kernel twice; the difference of the spans measured with
  * repeat 2 and repeat 1 is the kernel's duration without the ~4 us that an event pair adds around a single launch. */
 int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat);
+/* which launches the spans bracket: 0 (default) the dominant kernel; LDA 1 = everything of a pass after the E-step kernel
+ * (reduction, ll sweep, M-step); CTM 1 = theta phase, 2 = moments + reduction + M-step, 3 = props / log-likelihood launches.
+ * Lets bench.py account for the whole iteration kernel by kernel (its `iteration` block). */
+int mmm_ctx_profile_select(mmm_ctx* ctx, int phase);
 int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 
 /* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------
@@ -146,6 +153,10 @@ int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n);
  * the wide-table path (tables beyond LDS), [5] = 1 for the dense-row build (dense corpus over <= 128 terms: rows of counts,
  * statistics accumulated in registers), [6] = its term slots per lane, [7] = topics padded to. */
 int mmm_lda_geometry(const mmm_lda* m, int out[8]);
+/* Bytes of corpus the E-step build reads per document when the handle keeps rows (rows of 16- or 32-bit counts: 2 or 4 bytes x 16 x
+ * slots per lane; padded (term,count) rows: 8 x V); 0 when it sweeps the CSR arrays (8 bytes per nonzero + offsets).  bench.py's
+ * "algorithmic bytes as implemented". */
+int mmm_lda_row_bytes(const mmm_lda* m);
 /* fit!(model; maxiter, tol) -- LDA.jl:198-224: iterate until |dll|/|ll| < tol after > 10 passes, then ELBO. */
 int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged,
                 double* elbo);

@@ -49,6 +49,7 @@ _SIGS = {
     "mmm_ctx_device_name": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "mmm_ctx_profile_begin": (C.c_int, [vp]),
     "mmm_ctx_profile_repeat": (C.c_int, [vp, C.c_int]),
+    "mmm_ctx_profile_select": (C.c_int, [vp, C.c_int]),
     "mmm_ctx_profile_end": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
@@ -73,6 +74,7 @@ _SIGS = {
     "mmm_lda_iterate": (C.c_int, [vp, C.c_int]),
     "mmm_lda_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_lda_geometry": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "mmm_lda_row_bytes": (C.c_int, [vp]),
     "mmm_lda_fit": (C.c_int, [vp, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_solver_opts_default": (None, [C.POINTER(SolverOpts)]),
     "mmm_lda_infer": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -164,8 +166,9 @@ class Context:
         check(lib().mmm_ctx_device_name(self.h, b, 64), self.h)
         return b.value.decode()
 
-    def profile_begin(self, repeat=1):
+    def profile_begin(self, repeat=1, phase=0):
         check(lib().mmm_ctx_profile_repeat(self.h, int(repeat)), self.h, "mmm_ctx_profile_repeat")
+        check(lib().mmm_ctx_profile_select(self.h, int(phase)), self.h, "mmm_ctx_profile_select")
         check(lib().mmm_ctx_profile_begin(self.h), self.h, "mmm_ctx_profile_begin")
 
     def profile_end(self):

@@ -1819,6 +1819,7 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
     if (flags & (F_ZETA | F_THETA_COMPUTE | F_THETA_STORED | F_SLAB)) {
         const size_t lds = estep_lds(m, flags);
         if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM theta phase needs %zu B of LDS (> 160 KiB)", lds);
+        ProfSpan span(m->ctx, 1);   // mmm_ctx_profile_select(1): theta phase
         if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
     }
     if (flags & (F_NU | F_LAMBDA)) {
@@ -2022,6 +2023,8 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     if (rc) return rc;
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
     const size_t r0 = sc.rep0;
+    ProfSpan* mid_span = new ProfSpan(ctx, 2);      // mmm_ctx_profile_select(2): moments, reduction, all-reduce, topic M-step
+    struct SpanGuard { ProfSpan*& p; ~SpanGuard() { delete p; } } mid_guard{mid_span};
     hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                        m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
     MMM_LAUNCH_CHECK(ctx);
@@ -2048,8 +2051,10 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     const int do_sig = (update_sigma || m->immctm) ? 1 : 0;
     if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, 1, 1))) return rc;
     if ((fit_flags & MMM_FIT_AUTO_ALPHA) && (rc = run_update_alpha(m, sc))) return rc;      // MMCTM.jl:472-474
+    delete mid_span; mid_span = nullptr;
     // update_props! and the log-likelihoods
     if ((rc = ensure_hist(m, 1))) return rc;
+    ProfSpan ll_span(ctx, 3);                       // mmm_ctx_profile_select(3): Gaussian M-step block + props + log-likelihood launches
     const int M = dm.M;
     int nh = 0;       // the replicas still running share one history length (fit_scope checks it)
     for (int i = 0; i < sc.nrep; ++i)

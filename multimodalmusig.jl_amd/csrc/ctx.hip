@@ -43,9 +43,19 @@ int mmm_ctx_create(int device_id, mmm_ctx** out)
 int mmm_ctx_destroy(mmm_ctx* ctx)
 {
     if (!ctx) return MMM_OK;
-    if (ctx->live_models > 0) { ctx->destroy_pending = true; return MMM_OK; }      // released by the last model's destroy
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // nothing in flight may still touch the pinned block or the events
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // nothing in flight may still touch the pinned block, the events or a peer
+    if (ctx->live_models.load() > 0) {
+        // models outlive their context (a garbage-collected host): give up everything that involves other ranks NOW, while they are
+        // still there -- the models may only be destroyed after this call, not used -- and leave the rest to the last model's destroy
+        mmm_p2p_release(ctx);
+        if (ctx->comm) { (void)ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+        ctx->nranks = 1; ctx->rank = 0;
+        ctx->destroy_pending.store(true);
+        if (ctx->live_models.load() > 0) return MMM_DEFERRED;
+        bool expect = true;      // the last model went away in between: whoever flips the flag runs the teardown
+        if (!ctx->destroy_pending.compare_exchange_strong(expect, false)) return MMM_DEFERRED;
+    }
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pin_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
@@ -88,6 +98,14 @@ int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat)
     if (!ctx) return MMM_ERR_ARG;
     MMM_CHECK(ctx, repeat >= 1 && repeat <= 4, "mmm_ctx_profile_repeat: repeat must be 1..4");
     ctx->prof_repeat = repeat;
+    return MMM_OK;
+}
+
+int mmm_ctx_profile_select(mmm_ctx* ctx, int phase)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    MMM_CHECK(ctx, phase >= 0 && phase <= 7, "mmm_ctx_profile_select: phase must be 0..7");
+    ctx->prof_phase = phase;
     return MMM_OK;
 }
 
@@ -144,8 +162,10 @@ void mmm_solver_opts_default(mmm_solver_opts* o)
 
 } // extern "C"
 
-void mmm_ctx_model_created(mmm_ctx* ctx) { ++ctx->live_models; }
+void mmm_ctx_model_created(mmm_ctx* ctx) { ctx->live_models.fetch_add(1); }
 void mmm_ctx_model_destroyed(mmm_ctx* ctx)
 {
-    if (--ctx->live_models <= 0 && ctx->destroy_pending) { ctx->destroy_pending = false; (void)mmm_ctx_destroy(ctx); }
+    if (ctx->live_models.fetch_sub(1) - 1 > 0) return;
+    bool expect = true;
+    if (ctx->destroy_pending.compare_exchange_strong(expect, false)) (void)mmm_ctx_destroy(ctx);
 }

@@ -84,9 +84,11 @@ __device__ __forceinline__ double dev_digamma_ar(double x) { return (x > 0.0 && 
 // tab[2 j + 1] = log c_j, c_j the midpoint of the mantissa interval): x = 2^e m, r = m / c_j - 1 (|r| < 2^-8), log x = e ln 2 + log c_j
 // + log1p(r) with log1p by its series to r^6.  15 instructions and one 16-byte LDS read instead of ~35; absolute error < 5e-16
 // (2.5e-15 relative where |log x| > 0.05) -- for the log-likelihood sweeps, whose sums are compared at 1e-9.
+__device__ __forceinline__ double dev_log_pos(double x);
 __device__ __forceinline__ double dev_log_tab(double x, const double* __restrict__ tab)
 {
     const int hi = __double2hiint(x), lo = __double2loint(x);
+    if (__builtin_expect(hi < 0x00100000, 0)) return x > 0.0 ? dev_log_pos(x) : (x == 0.0 ? -__builtin_inf() : __builtin_nan(""));      // zero, subnormal, negative: as log()
     const int e = (hi >> 20) - 1023, j = (hi >> 13) & 127;
     const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);
     const double2 t = *reinterpret_cast<const double2*>(tab + 2 * j);

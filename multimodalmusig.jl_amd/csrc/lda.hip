@@ -568,7 +568,8 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
 #pragma unroll
             for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
             if (KP & 1) s0 += b[KP - 1];
-            const double r = (double)c[q] * dev_rcp(s0 + s1);
+            // a slot without mass must not see 0 x rcp(0): with tiny priors the normaliser of a never-observed term underflows to 0
+            const double r = c[q] > 0 ? (double)c[q] * dev_rcp(s0 + s1) : 0.0;
 #pragma unroll
             for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
             // one slot at a time, its statistics updated here (left alone the compiler sinks the SL KP updates to the end of the step and keeps
@@ -1735,7 +1736,9 @@ int residency_cap(mmm_ctx* ctx, Kern kern, size_t lds, int* cap)
 {
     int nb = 0;
     MMM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 1024, lds));
-    *cap = nb * ctx->num_cu;
+    // the blocks of such a launch wait for each other, so every one of them must be on the chip at once.  nb x #CU holds when the device is
+    // ours alone; a few CUs are left out of the count so that a short kernel of another stream or process does not turn a wait into a timeout
+    *cap = nb * std::max(1, ctx->num_cu - 4);
     if (const char* e = getenv("MMM_LDA_RESIDENT_CAP")) *cap = std::min(*cap, std::max(0, atoi(e)));
     return MMM_OK;
 }
@@ -2010,10 +2013,11 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
             ProfSpan span(ctx);
-            const int reps = ctx->profiling ? ctx->prof_repeat : 1;
+            const int reps = span.on ? ctx->prof_repeat : 1;
             for (int q = 0; q < reps && !rc; ++q) rc = launch_estep(m, a);
         }
         if (rc) return rc;
+        ProfSpan tail_span(ctx, 1);      // mmm_ctx_profile_select(1): everything of the pass after the E-step kernel
         const int nred = (r.VK + 15) / 16;
         if (merged) {
             const size_t lds = lds_red;
@@ -2256,7 +2260,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     if (m->dense)      // [16 SL][KP] table | [waves][K][V] slabs | [waves][G][KP] a_k | [waves][64][KP] gamma sums
         m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * K * V + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
-    if (m->dense && m->lds_d > 160 * 1024) m->dense = false;
+    if (m->dense && m->lds_d > 160 * 1024) { m->dense = false; m->drows = drows && !wide; }      // no dense-row build: rows only if the corpus is dense enough
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); return rc; } } while (0)
@@ -2294,7 +2298,6 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         m->stats_waves = 1;
         while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
     }
-    if (m->dense && m->lds_d > 160 * 1024) m->drows = drows && !wide;
     static const bool rows16_env = getenv("MMM_LDA_ROWS16") == nullptr || atoi(getenv("MMM_LDA_ROWS16")) != 0;
     int maxcount = 0;
     for (int64_t e = 0; e < nnz; ++e) maxcount = std::max(maxcount, count[e]);
@@ -2321,7 +2324,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     {   // padded rows for the ll blocks (V <= 128 slots, no duplicate terms: then a document always fits its row)
         int64_t maxW = 0;
         for (int d = 0; d < D; ++d) maxW = std::max<int64_t>(maxW, doc_ptr[d + 1] - doc_ptr[d]);
-        if (V <= 128 && maxW <= V && D > 0 && !wide && !m->drows) {
+        // (the ll blocks take their lanes per document from KP, the rows of counts serve 16-lane groups only: K = 13..15 needs the padded rows too)
+        if (V <= 128 && maxW <= V && D > 0 && !wide && (!m->drows || m->KP > 15)) {
             ell.assign((size_t)D * V, make_int2(-1, 0));
             for (int d = 0; d < D; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) ell[(size_t)d * V + (e - doc_ptr[d])] = tc[(size_t)e];
@@ -2569,6 +2573,14 @@ int mmm_lda_geometry(const mmm_lda* m, int out[8])
     out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->single_step ? 1 : 0; out[4] = m->wide ? 1 : 0;
     out[5] = m->dense ? 1 : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
     return MMM_OK;
+}
+
+int mmm_lda_row_bytes(const mmm_lda* m)
+{
+    if (!m || m->wide) return 0;
+    if (m->drows) return (m->cnt16.p ? 2 : 4) * 16 * m->SL;
+    if (m->tc_ell.p && !m->dense) return 8 * m->V;
+    return 0;
 }
 
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)

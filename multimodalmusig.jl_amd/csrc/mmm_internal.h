@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -30,6 +31,7 @@ struct mmm_ctx {
     // HIP-event spans around the dominant kernel (mmm_ctx_profile_begin/end)
     bool profiling = false;
     int prof_repeat = 1;          // launches of the dominant kernel inside each profiled span (differential timing)
+    int prof_phase = 0;           // which launches of a pass the spans bracket (mmm_ctx_profile_select; 0 = the dominant kernel)
     std::vector<hipEvent_t> ev;   // pairs: ev[2i] start, ev[2i+1] stop
     size_t ev_used = 0;
     // pipelined fits: two pinned 64-byte slots + events for in-stream snapshots of a model's control block, so that the host
@@ -39,8 +41,10 @@ struct mmm_ctx {
     // models created on this context and still alive.  mmm_ctx_destroy with live models only marks the context; the last
     // mmm_*_destroy then releases it -- a garbage-collected host (Julia finalizers run in no particular order) may destroy
     // the context before its models without a use-after-free.
-    int live_models = 0;
-    bool destroy_pending = false;
+    // Finalizers may run on any thread, hence atomics; the communicator and the mailboxes are released at mmm_ctx_destroy itself (peers
+    // and the runtime are still up then), only the stream, the events and the memory that models still reference wait for the last model.
+    std::atomic<int> live_models{0};
+    std::atomic<bool> destroy_pending{false};
 };
 
 void mmm_ctx_model_created(mmm_ctx* ctx);
@@ -49,7 +53,7 @@ void mmm_ctx_model_destroyed(mmm_ctx* ctx);      // may delete ctx
 // RAII span: records an event pair around a launch while profiling is on
 struct ProfSpan {
     mmm_ctx* ctx; bool on;
-    explicit ProfSpan(mmm_ctx* c) : ctx(c), on(c->profiling) {
+    explicit ProfSpan(mmm_ctx* c, int phase = 0) : ctx(c), on(c->profiling && c->prof_phase == phase) {
         if (!on) return;
         if (ctx->ev_used + 2 > ctx->ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } ctx->ev.push_back(e); }

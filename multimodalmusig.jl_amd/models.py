@@ -133,7 +133,8 @@ class LDA:
         """E-step build and launch geometry of the handle (mmm_lda_geometry)."""
         g = (C.c_int * 8)()
         check(lib().mmm_lda_geometry(self._h, g), self.ctx.h, "geometry")
-        return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "single_step": g[3], "wide": g[4], "dense": g[5], "SL": g[6], "KP": g[7]}
+        return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "single_step": g[3], "wide": g[4], "dense": g[5], "SL": g[6], "KP": g[7],
+                "row_bytes": int(lib().mmm_lda_row_bytes(self._h))}
 
     def close(self):
         if self._h:

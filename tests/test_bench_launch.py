@@ -1,0 +1,63 @@
+"""`python3 bench.py --gpus N` starts its own rank processes (the form the driver uses for N = 1 must also work for N > 1 without an
+external launcher).  On the GPU box: two ranks rehearsed on the one card -- gloo on the host side, mailboxes from host-exchanged IPC
+handles, the folded exchange in every iteration -- and the line must say what ran.  Without a GPU: the parent must come back with a
+non-zero exit code instead of hanging or printing a line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_self_launch_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test below")
+    p = _bench("--gpus", "2", "--docs", "50", "--launch-timeout", "240", timeout=300)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "no GPU visible" in p.stderr
+
+
+@pytest.mark.gpu
+def test_two_self_launched_ranks_on_one_card():
+    p = _bench("--gpus", "2", "--docs", "2000", "--steps", "10", "--warmup", "2", "--repeats", "3", "--launch-timeout", "600")
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 2 and c["comm_nranks"] == 2 and c["comm_nranks_per_rank"] == [2, 2]
+    assert c["allreduce_per_rank"] == ["p2p", "p2p"] and c["docs_per_rank"] == [2000, 2000] and c["docs_total"] == 4000
+    assert r["value"] > 0 and abs(r["value"] - 4000 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert "also" not in r          # --docs given: only the one configuration
+    # strong scaling: the one corpus split by nonzeros
+    p = _bench("--gpus", "2", "--docs", "2000", "--steps", "10", "--warmup", "2", "--repeats", "3", "--scaling", "strong")
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert sum(r["config"]["docs_per_rank"]) == 2000 and r["config"]["docs_total"] == 2000 and "note" in r["config"]
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_keeps_its_keys():
+    p = _bench("--docs", "2000", "--steps", "10", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline")
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "iteration", "elbo_rel_err_vs_oracle"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["config"]["comm_nranks"] == 1 and r["config"]["allreduce"] == "none"
+    rf = r["roofline"]
+    assert rf["algorithmic_bytes_as_implemented"] <= rf["algorithmic_bytes_per_launch"]
+    assert 0 < r["iteration"]["kernel_fraction_of_step"] < 1.5
+    assert r["elbo_rel_err_vs_oracle"] < 1e-5

@@ -333,10 +333,32 @@ def test_context_may_be_destroyed_before_its_models(mmm):
     a = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0, ctx=ctx)
     b = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0, ctx=ctx)
     L = mmm.lib()
-    assert L.mmm_ctx_destroy(ctx.h) == 0          # deferred: two models alive
-    ll = mmm.fit(a, maxiter=3, tol=0.0, verbose=False)   # the context still works
+    assert L.mmm_ctx_destroy(ctx.h) == 1          # MMM_DEFERRED: two models alive (communicator / mailboxes are given up at once)
+    ll = mmm.fit(a, maxiter=3, tol=0.0, verbose=False)   # stream and memory are still there
     assert np.all(np.isfinite(ll))
     ha, hb = a._h, b._h
     a._h = mmm._lib.C.c_void_p(); b._h = mmm._lib.C.c_void_p(); ctx.h = mmm._lib.C.c_void_p()     # the Python objects must not destroy again
     assert L.mmm_lda_destroy(ha) == 0
     assert L.mmm_lda_destroy(hb) == 0             # releases the context
+
+
+def test_dense_row_build_with_a_never_observed_term_and_tiny_priors(mmm, monkeypatch):
+    """ADVICE r2: with eta = alpha = 1e-3 the normaliser sum_k a_k exp(Elnbeta_kv) of a term that no document contains underflows to 0;
+    the dense-row build visits every slot of a row, so a slot without mass must contribute 0, not 0 x rcp(0) = NaN.  Checked against the
+    CSR sweep (which never sees such a slot) on the same corpus."""
+    X, lam0 = np_ref.synth_lda(400, 96, 10, seed=5, mean_n=600)
+    dead = 37
+    X = [x[x[:, 0] != dead + 1] for x in X]           # term ids are 1-based in X
+    lam0 = np.ones_like(lam0)
+    fits = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMM_LDA_DENSE", mode)
+        g = mmm.LDA(10, 1e-3, 1e-3, 96, X, λ0=lam0)
+        assert g.geometry()["dense"] == int(mode)
+        ll = mmm.fit(g, maxiter=60, tol=0.0, verbose=False)
+        fits[mode] = (ll, np.array(g.γ), np.array(g.λ))
+        g.close()
+    for a, b in zip(fits["1"], fits["0"]):
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+        np.testing.assert_allclose(a, b, rtol=1e-9)
+    assert np.all(np.abs(fits["1"][2][dead] - 1e-3) < 1e-12)      # lambda of the dead term = eta
