@@ -153,6 +153,11 @@ static int orc_stop_x(int n, const double* x, const double* oldx, double xtol_re
     return 1;
 }
 
+/* optional trace of the solver's inner iterations, for tests/test_mma_independent.py: row = [rho, gval, wval, fcur, sigma[n], xcur[n]] */
+static double* g_mma_trace = NULL; static int g_mma_trace_cap = 0; static int g_mma_trace_rows = 0;
+void orc_mma_set_trace(double* buf, int cap_rows) { g_mma_trace = buf; g_mma_trace_cap = cap_rows; g_mma_trace_rows = 0; }
+int orc_mma_trace_rows(void) { return g_mma_trace_rows; }
+
 int orc_mma_minimize(int n, orc_objective f, void* data, const double* lb, const double* ub,
                      double* x, double* minf, double xtol_rel, double xtol_abs, int xtol_rule,
                      int max_eval, int* n_outer)
@@ -198,6 +203,11 @@ int orc_mma_minimize(int n, orc_objective f, void* data, const double* lb, const
                 wval += 0.5 * dx2 * denominv;
             }
             fcur = f(n, xcur, dfdx_cur, data); ++nev;
+            if (g_mma_trace && g_mma_trace_rows < g_mma_trace_cap) {
+                double* row = g_mma_trace + (size_t)g_mma_trace_rows++ * (4 + 2 * (size_t)n);
+                row[0] = rho; row[1] = gval; row[2] = wval; row[3] = fcur;
+                memcpy(row + 4, sigma, sizeof(double) * n); memcpy(row + 4 + n, xcur, sizeof(double) * n);
+            }
             int inner_done = gval >= fcur;
             if (fcur < fbest) {
                 fbest = fcur;

@@ -49,6 +49,8 @@ typedef double (*orc_objective)(int n, const double* x, double* grad, void* data
 /* xtol_rule: 0 = NLopt >= 2.7 (L1 norm rule), 1 = NLopt <= 2.6 (per-coordinate rule).
  * minimises f. lb/ub may be NULL (= -inf/+inf). Returns number of objective evaluations (>0) or
  * -1 when the evaluation cap was hit. x is overwritten with the best accepted point. */
+void orc_mma_set_trace(double* buf, int cap_rows);   /* test hook: one row [rho, gval, wval, fcur, sigma[n], xcur[n]] per inner iteration */
+int orc_mma_trace_rows(void);
 int orc_mma_minimize(int n, orc_objective f, void* data, const double* lb, const double* ub,
                      double* x, double* minf, double xtol_rel, double xtol_abs, int xtol_rule,
                      int max_eval, int* n_outer);

@@ -61,6 +61,8 @@ def lib():
     L.orc_logmvbeta.restype = C.c_double; L.orc_logmvbeta.argtypes = [C.c_int, f64p]
     L.orc_inv_logdet.argtypes = [C.c_int, f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.orc_mma_minimize.restype = C.c_int
+    L.orc_mma_set_trace.restype = None; L.orc_mma_set_trace.argtypes = [C.c_void_p, C.c_int]
+    L.orc_mma_trace_rows.restype = C.c_int; L.orc_mma_trace_rows.argtypes = []
     L.orc_mma_minimize.argtypes = [C.c_int, OBJ_CB, C.c_void_p, C.c_void_p, C.c_void_p, f64p,
                                    C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.POINTER(C.c_int)]
@@ -165,10 +167,15 @@ def inv_logdet(A):
     return rc, Ai.reshape(n, n, order="F"), ld.value, sg.value
 
 
-def mma_minimize(fun, x0, lb=None, ub=None, xtol_rel=1e-4, xtol_abs=1e-4, rule=0, max_eval=100000):
-    """fun(x) -> (value, grad); minimised. Returns (x, fmin, n_eval, n_outer)."""
+def mma_minimize(fun, x0, lb=None, ub=None, xtol_rel=1e-4, xtol_abs=1e-4, rule=0, max_eval=100000, trace=False):
+    """fun(x) -> (value, grad); minimised. Returns (x, fmin, n_eval, n_outer); with trace=True a fifth item, the array of the solver's
+    inner iterations, one row [rho, gval, wval, fcur, sigma[n], xcur[n]] each."""
     x = np.array(x0, dtype=np.float64)
     n = x.size
+    tbuf = None
+    if trace:
+        tbuf = np.zeros((4096, 4 + 2 * n))
+        lib().orc_mma_set_trace(tbuf.ctypes.data_as(C.c_void_p), tbuf.shape[0])
 
     def cb(nn, xp, gp, _):
         xv = np.ctypeslib.as_array(xp, shape=(nn,))
@@ -184,6 +191,10 @@ def mma_minimize(fun, x0, lb=None, ub=None, xtol_rel=1e-4, xtol_abs=1e-4, rule=0
                                  lbp.ctypes.data if lbp is not None else None,
                                  ubp.ctypes.data if ubp is not None else None,
                                  x, C.byref(minf), xtol_rel, xtol_abs, rule, max_eval, C.byref(no))
+    if trace:
+        rows = lib().orc_mma_trace_rows()
+        lib().orc_mma_set_trace(None, 0)
+        return x, minf.value, nev, no.value, tbuf[:rows].copy()
     return x, minf.value, nev, no.value
 
 

@@ -172,3 +172,73 @@ def synth_mm(D, V, K, seed, means=None, conc=0.1, empty_frac=0.0):
         X.append(doc)
     gamma0 = [rng.integers(1, 101, size=(K[m], V[m])).astype(np.float64) for m in range(M)]
     return X, gamma0
+
+
+# ------------------------------------------------------------------------------------ LD_MMA, independent restatement
+def ccsa_mma(fun, x0, lower=None, xtol_rel=1e-4, xtol_abs=1e-4, rule=0, max_eval=100000):
+    """Conservative convex separable approximations with MMA-type approximating functions and NO nonlinear constraint, minimising
+    fun(x) -> (value, gradient) over x >= lower.  Written from K. Svanberg, "A class of globally convergent optimization methods based on
+    conservative convex separable approximations", SIAM J. Optim. 12 (2002) 555-573, in the form NLopt documents for LD_MMA
+    (NLopt algorithms manual, "MMA (Method of Moving Asymptotes) and CCSA"; stopping rules: NLopt reference, xtol_rel / xtol_abs) --
+    NOT from oracle/mmm_oracle.c; tests/test_mma_independent.py holds the two against each other step by step.
+
+    Around the best point y found so far (value F, gradient g) the approximation is
+        G(y + d) = F + sum_j [ g_j s_j^2 d_j + (|g_j| s_j + rho/2) d_j^2 ] / (s_j^2 - d_j^2),          |d_j| <= 0.9 s_j,
+    separable and strictly convex in each d_j; s are the asymptote distances (1 when a bound is infinite), rho the conservativity
+    parameter.  Inner iterations raise rho until G(candidate) >= f(candidate); outer iterations relax rho and move the asymptotes
+    by the sign pattern of the last two steps.
+    rule 0: NLopt >= 2.7 stop  (|x - x_old|_1 < xtol_rel |x|_1, or every |dx_j| < xtol_abs);  rule 1: NLopt <= 2.6 (per coordinate:
+    |dx| < xtol_abs or |dx| < xtol_rel (|x| + |x_old|)/2 or, with xtol_rel > 0, dx == 0).
+    Returns (best x, best value, number of evaluations, trace); trace = one dict per inner iteration."""
+    y = np.array(x0, dtype=np.float64)                   # best point so far
+    n = y.size
+    lo = np.full(n, -np.inf) if lower is None else np.broadcast_to(np.asarray(lower, dtype=np.float64), (n,)).copy()
+    s = np.ones(n)                                       # no finite upper bound anywhere on this path
+    rho = 1.0
+    F, g = fun(y.copy()); g = np.array(g, dtype=np.float64)
+    evals = 1
+    cand = y.copy()                                      # the latest candidate (the sequence whose steps drive s and the stop test)
+    steps = []                                           # candidates at the end of the previous outer iterations
+    trace = []
+    while evals < max_eval:
+        start = cand.copy()
+        conservative = False
+        while not conservative:
+            # minimiser of every one-dimensional piece: root of  u d^2 + 2 v s^2 d + u s^2 = 0  inside the asymptotes
+            u = g * (s * s)                                              # (the root is ill-conditioned next to a bound, |u| ~ v s: keep NLopt's operand order)
+            v = np.abs(g) * s + 0.5 * rho
+            with np.errstate(invalid="ignore", divide="ignore"):
+                d = (u / v) / (-1.0 - np.sqrt(np.abs(1.0 - (u / (v * s)) ** 2)))
+            c = y + d
+            c = np.maximum(c, lo)                                        # box
+            c = np.minimum(np.maximum(c, y - 0.9 * s), y + 0.9 * s)      # move limit
+            d = c - y
+            inv = 1.0 / (s * s - d * d)
+            G = F
+            W = 0.0
+            for j in range(n):                                           # sums in coordinate order
+                G += (g[j] * (s[j] * s[j] * d[j]) + (abs(g[j]) * s[j] + 0.5 * rho) * (d[j] * d[j])) * inv[j]
+                W += 0.5 * (d[j] * d[j]) * inv[j]
+            fc, gc = fun(c.copy()); evals += 1
+            trace.append(dict(rho=rho, sigma=s.copy(), x=c.copy(), fcur=fc, gval=G, wval=W))
+            conservative = G >= fc
+            cand = c
+            if fc < F:
+                F, y, g = fc, c.copy(), np.array(gc, dtype=np.float64)
+            if evals >= max_eval:
+                return y, F, evals, trace
+            if not conservative and fc > G:
+                rho = min(10.0 * rho, 1.1 * (rho + (fc - G) / W))
+        dxs = np.abs(cand - start)
+        if rule == 0:
+            done = dxs.sum() < xtol_rel * np.abs(cand).sum() or bool(np.all(dxs < xtol_abs))
+        else:
+            done = bool(np.all((dxs < xtol_abs) | (dxs < xtol_rel * 0.5 * (np.abs(cand) + np.abs(start))) | ((xtol_rel > 0) & (cand == start))))
+        if done:
+            break
+        rho = max(0.1 * rho, 1e-5)
+        if steps:                                                        # from the second outer iteration on
+            osc = (cand - start) * (start - steps[-1])
+            s = s * np.where(osc < 0, 0.7, np.where(osc > 0, 1.2, 1.0))
+        steps.append(start)
+    return y, F, evals, trace
