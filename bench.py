@@ -374,9 +374,8 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
         n, ms = ctx.profile_end()
         return n, (ms / max(n, 1)) * 1e3
 
-    n_launch, span1 = span_us(0)
-    phases = {}
     if cfg["model"] == "lda":
+        n_launch, span1 = span_us(0)
         # ... and once more with the (idempotent) E-step kernel launched twice inside every span: the difference of the two spans is
         # the kernel's own duration, without the ~4 us an event pair adds around a single launch (what rocprofv3 reports)
         _, span2 = span_us(0, repeat=2)
@@ -384,10 +383,20 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
         pair_us = max(span1 - avg_us, 0.0)               # what an event pair adds around one launch
         _, tail = span_us(1)
         phases = {"estep": avg_us, "reduce_ll_mstep": max(tail - pair_us, 0.0)}
+        step_us_profiled = dt / steps * 1e6
     else:
+        # millisecond passes: every phase bracketed in ONE repeat of the K steps (the solves get shorter as the fit converges, so
+        # phases measured in different passes would not add up), and that repeat's own wall time beside them
         span2 = None
-        avg_us = span1        # a millisecond kernel: the ~4 us of the event pair are < 0.5 %
-        phases = {"solve": span1, "theta": span_us(1)[1], "moments_reduce_topics": span_us(2)[1], "gauss_props_loglik": span_us(3)[1]}
+        ctx.profile_begin(repeat=1, phase=8)
+        env.barrier(); t0 = time.perf_counter()
+        run(steps)
+        ph = ctx.profile_end_phases()
+        step_us_profiled = (time.perf_counter() - t0) / steps * 1e6
+        names = {0: "solve", 1: "theta", 2: "moments_reduce_topics", 3: "gauss_props_loglik"}
+        phases = {names[i]: ms / steps * 1e3 for i, (n, ms) in ph.items()}
+        n_launch = ph[0][0]
+        avg_us = span1 = ph[0][1] / max(ph[0][0], 1) * 1e3        # a millisecond kernel: the ~4 us of the event pair are < 0.5 %
     ctx.profile_begin(repeat=1, phase=0); ctx.profile_end()
     avg_s = avg_us * 1e-6
 
@@ -414,10 +423,11 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             res["config"]["note"] = ("strong scaling of a %d-document corpus: the per-iteration exchange has a fixed latency of the order of the "
                                      "iteration itself, so the 10k-document LDA corpus cannot speed up 6x on 8 GPUs; weak scaling is the "
                                      "curve that can" % Dcfg)
-        res["iteration"] = {"kernel_us": phases, "sum_kernel_us": sum(phases.values()), "ms_per_step_us": ms_step * 1e3,
-                            "kernel_fraction_of_step": sum(phases.values()) / (ms_step * 1e3) if ms_step > 0 else None,
-                            "timing": "HIP-event spans per phase of the pass (mmm_ctx_profile_select) in repeats of the timed K steps; LDA spans "
-                                      "are corrected by the event-pair overhead measured differentially on the E-step kernel"}
+        res["iteration"] = {"kernel_us": phases, "sum_kernel_us": sum(phases.values()), "step_us": step_us_profiled,
+                            "kernel_fraction_of_step": sum(phases.values()) / step_us_profiled if step_us_profiled > 0 else None,
+                            "timing": "HIP-event spans per phase of the pass (mmm_ctx_profile_select) in repeats of the timed K steps; LDA: one phase per "
+                                      "repeat, spans corrected by the event-pair overhead measured differentially on the E-step kernel, step_us = "
+                                      "the timed regions' median; CTM: all phases in one repeat, step_us = that repeat's wall time per step"}
         if cfg["model"] == "lda":
             ll = np.zeros(1); n = pkg._lib.C.c_int()
             pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)

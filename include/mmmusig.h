@@ -75,9 +75,12 @@ int mmm_ctx_profile_begin(mmm_ctx* ctx);
  * repeat 2 and repeat 1 is the kernel's duration without the ~4 us that an event pair adds around a single launch. */
 int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat);
 /* which launches the spans bracket: 0 (default) the dominant kernel; LDA 1 = everything of a pass after the E-step kernel
- * (reduction, ll sweep, M-step); CTM 1 = theta phase, 2 = moments + reduction + M-step, 3 = props / log-likelihood launches.
+ * (reduction, ll sweep, M-step); CTM 1 = theta phase, 2 = moments + reduction + M-step, 3 = props / log-likelihood launches;
  * Lets bench.py account for the whole iteration kernel by kernel (its `iteration` block). */
 int mmm_ctx_profile_select(mmm_ctx* ctx, int phase);
+/* phase 8 brackets every phase at once; mmm_ctx_profile_end_phases then returns span counts and summed durations per phase (0..7).  For
+ * passes of milliseconds (CTM), where the few microseconds an event pair adds do not matter. */
+int mmm_ctx_profile_end_phases(mmm_ctx* ctx, int n_spans[8], double total_ms[8]);
 int mmm_ctx_profile_end(mmm_ctx* ctx, int* n_launches, double* total_ms);
 
 /* ---- multi-GPU: documents are sharded across ranks, sufficient statistics are all-reduced (RCCL) ---------

@@ -50,6 +50,7 @@ _SIGS = {
     "mmm_ctx_profile_begin": (C.c_int, [vp]),
     "mmm_ctx_profile_repeat": (C.c_int, [vp, C.c_int]),
     "mmm_ctx_profile_select": (C.c_int, [vp, C.c_int]),
+    "mmm_ctx_profile_end_phases": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_ctx_profile_end": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mmm_comm_init_rank": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p]),
@@ -176,6 +177,12 @@ class Context:
         n = C.c_int(); ms = C.c_double()
         check(lib().mmm_ctx_profile_end(self.h, C.byref(n), C.byref(ms)), self.h, "mmm_ctx_profile_end")
         return n.value, ms.value
+
+    def profile_end_phases(self):
+        """after profile_begin(phase=8): {phase: (number of spans, summed milliseconds)} of the phases that were launched"""
+        n = (C.c_int * 8)(); ms = (C.c_double * 8)()
+        check(lib().mmm_ctx_profile_end_phases(self.h, n, ms), self.h, "mmm_ctx_profile_end_phases")
+        return {i: (n[i], ms[i]) for i in range(8) if n[i]}
 
     def init_comm(self, nranks, rank, unique_id):
         check(lib().mmm_comm_init_rank(self.h, int(nranks), int(rank), unique_id), self.h, "mmm_comm_init_rank")

@@ -297,6 +297,7 @@ struct CtmEArgs {
     // fused pass (F_SLAB): the theta phase also keeps lambda_{t-1} and the exp table of this pass (theta_t is rebuilt from them on
     // demand) -- it reads both anyway, which saves the copy launch.  Base of replica 0, may be NULL.
     double* lam_keep; double* expE_keep;
+    int* claim;             // split solve launches: the launch's document counter (one per replica, 32 ints apart; zero at launch), or NULL
 };
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
@@ -714,12 +715,53 @@ struct LamObjC {
 // to its slowest document with the other slots idle -- 1.3-2x the mean at 32 slots); a new document's first evaluation f(x0)
 // rides in the common trip with the candidate point = x0.  Every document goes through exactly the operations of mma_group,
 // whatever its slot and its neighbours.
+// Documents handed out on demand (split solve launches): the LD_MMA solves of a corpus take very different numbers of evaluations, so
+// static document ranges leave SIMDs idle behind the slowest wave (50,000 documents over 3,072 waves: the slowest SIMD carries ~25 % more
+// than the mean).  A block's slots take TICKETS from a counter in LDS; ticket t stands for entry t % kClaimChunk of the block's
+// (t / kClaimChunk)-th chunk of documents, and chunks come from one counter in device memory, kClaimChunk documents per atomic (a
+// returning device-scope atomic on this 8-XCD part is a round trip to the memory side: one per document would serialise).  The slot
+// that takes the first ticket of chunk c requests chunk c + 1, so a chunk is there before its tickets are drawn; its start is published
+// in a small ring in LDS, tagged with the chunk number.  Which slot solves which document changes nothing in the results.
+constexpr int kClaimChunk = 32, kClaimRing = 8;
+struct ClaimPool { int tix; int pad; unsigned long long ring[kClaimRing]; };
+
+// every lane of the wave calls; `want`: this lane leads a slot that needs a document.  Returns the document index (>= D: none left).
+__device__ __forceinline__ int claim_doc(ClaimPool* pool, int* gcnt, bool want, int lane)
+{
+    const unsigned long long fm = __ballot(want);
+    const int n = __popcll(fm);
+    int t0 = 0;
+    if (lane == 0) t0 = __hip_atomic_fetch_add(&pool->tix, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    const int t = t0 + __popcll(fm & ((1ull << lane) - 1ull));
+    const int c = t / kClaimChunk, off = t % kClaimChunk;
+    if (want && off == 0) {       // first ticket of chunk c: fetch chunk c + 1 (chunk 0 is fetched when the block starts)
+        const int s = __hip_atomic_fetch_add(gcnt, kClaimChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pool->ring[(c + 1) % kClaimRing], ((unsigned long long)(c + 2) << 32) | (unsigned int)s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    int d = 0x7fffffff;
+    bool pending = want;
+    for (int spin = 0; __any(pending) && spin < (1 << 22); ++spin) {      // (the cap is never reached: an exit condition every wave has)
+        if (pending) {
+            const unsigned long long e = __hip_atomic_load(&pool->ring[c % kClaimRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((int)(e >> 32) == c + 1) { d = (int)(unsigned int)e + off; pending = false; }
+        }
+        if (__any(pending)) __builtin_amdgcn_s_sleep(2);
+    }
+    return d;
+}
+
 template <int MKT, int LPD, bool SB, class Obj>
-__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out)
+__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out,
+                                            ClaimPool* pool = nullptr, int* gcnt = nullptr)
 {
     constexpr int CPL = CplGeom<MKT, LPD>::CPL, G = MMM_WAVE / LPD;
     const int g = lane / LPD, l = lane % LPD;
     int d = r0 + g, next = r0 + G;
+    if (pool) {       // r0 = 0, r1 = D: documents on demand
+        d = claim_doc(pool, gcnt, l == 0, lane);
+        d = __shfl(d, g * LPD, MMM_WAVE);
+    }
     bool have = d < r1, fresh = true;
     double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL], xprevprev[CPL];
     double rho = 1.0, fbest = 0.0;
@@ -807,10 +849,14 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
                 obj.store(dc, d, x);
                 if (nev_out && l == 0) nev_out[d] = capped ? -nev : nev;
             }
-            // the finished slots take the next documents of the range, in slot order
+            // the finished slots take the next documents of the range, in slot order (or the next documents anyone has not taken yet)
             const unsigned long long fm = __ballot(finished && l == 0);
-            const int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
+            int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
             next += __popcll(fm);
+            if (pool) {
+                nd = claim_doc(pool, gcnt, finished && l == 0, lane);
+                nd = __shfl(nd, g * LPD, MMM_WAVE);
+            }
             if (finished) {
                 d = nd; have = nd < r1;
                 obj.load(dc, have ? d : -1, x);
@@ -822,7 +868,9 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
     }
 }
 
-template <int MKT, int LPD, int OCC, bool SB>
+// WHICH: 1 = update_ν! only, 2 = update_λ! only, 3 = both (a build with one solve keeps only that solve's registers: the ν solve needs
+// neither the Σ⁻¹ table nor the difference vectors in LDS)
+template <int MKT, int LPD, int OCC, bool SB, int WHICH = 3>
 __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -844,15 +892,34 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     // LDS: [MK rows][ROW] invSigma (padded) | [NW][G][MK + 2] difference vectors
     double* sS = smem;
     double* sScr = sS + MK * Gm::ROW;
-    for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
-        const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
-        sS[e] = (q < CPL && ll < Gm::ACT) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
+    if constexpr ((WHICH & 2) != 0) {
+        for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
+            const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
+            sS[e] = (q < CPL && ll < Gm::ACT) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // the wave's documents: a contiguous range
+    // the wave's documents: a contiguous range, or (split launches with a claim counter) whatever is next
     const int nwaves = gridDim.x * NW, w = blockIdx.x * NW + wid;
     const int per = (D + nwaves - 1) / nwaves;
-    const int r0 = min(D, w * per), r1 = min(D, r0 + per);
+    int r0 = min(D, w * per), r1 = min(D, r0 + per);
+    __shared__ ClaimPool s_pool;
+    ClaimPool* pool = nullptr;
+    int* gcnt = nullptr;
+    if constexpr (WHICH != 3) {
+        if (a.claim) {
+            gcnt = a.claim + rep * 32;
+            pool = &s_pool;
+            if (tid == 0) {
+                s_pool.tix = 0;
+                for (int i = 1; i < kClaimRing; ++i) s_pool.ring[i] = 0ull;
+                const int s0 = __hip_atomic_fetch_add(gcnt, kClaimChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_pool.ring[0] = (1ull << 32) | (unsigned int)s0;
+            }
+            __syncthreads();
+            r0 = 0; r1 = D;
+        }
+    }
     int mod_q[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -863,23 +930,25 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     }
     const SolveOpts o = a.opt;
     // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ -- for every document of the range
-    if (a.flags & F_NU) {
+    if constexpr ((WHICH & 1) != 0) if (a.flags & F_NU) {
         NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0; }
         obj.l = l; obj.lane_on = lane_on;
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, pool, gcnt);
     }
     // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (WHICH == 3) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
-    if (a.flags & F_LAMBDA) {
+    if constexpr ((WHICH & 2) != 0) if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.mu[q] = lane_on ? p_mu[l * CPL + q] : 0.0; }
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam, pool, gcnt);
     }
 }
 
@@ -1674,6 +1743,9 @@ struct mmm_ctm {
     int L = 64, GM = 0 /* model-layout gamma size */;
     int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 12), or 2 / 4 (cpl > 1)
     int cpl = 1;                   // coordinates per lane in the solve phase (k_ctm_solve_cpl: sum K = 10, 14, 28)
+    // split solve phase: update_ν! and update_λ! as two launches, each in its own lane layout (nu_Ls lanes x nu_cpl coordinates; the λ
+    // solve in the layout of Ls / cpl / persist)
+    bool split = false; int nu_Ls = 0, nu_cpl = 0, nu_occ = 4, lam_occ = 4, grid_nu = 1;
     bool persist = false;          // solve phase by k_ctm_solve_cpl (persistent waves, document slots refilled): cpl > 1, or cpl = 1 with Ls = L
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
@@ -1685,6 +1757,7 @@ struct mmm_ctm {
     DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff, expEeff_prev, phieff;   // [R][...]
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
     DevBuf<int> nev_nu, nev_lam, status, active, npass;
+    DevBuf<int> claim;             // [2][R][32]: document counters of the split nu / lambda launches
     int stop_enable = 0; double stop_tol = 0.0;     // set by fit_scope around a pass: the ll kernels apply the stopping rule
     int* pin_flags = nullptr;                       // pinned [2][2R]: snapshots of (active | status) the host reads one pass late
     std::vector<int> h_active, n_hist;        // per replica
@@ -1747,6 +1820,30 @@ size_t solve_lds(const mmm_ctm* m)
     return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * scrw);
 }
 
+// update_ν! alone, several coordinates per lane (split solve phase)
+int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
+{
+    mmm_ctx* ctx = m->ctx;
+    auto go = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3(m->grid_nu, nrep), dim3(m->waves_s * MMM_WAVE), 0, ctx->stream, a);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    };
+    const int key = m->dm.MK * 10000 + m->nu_Ls * 10 + m->nu_occ;
+    switch (key) {
+        case 280082: return go(k_ctm_solve_cpl<28, 8, 2, false, 1>);
+        case 280083: return go(k_ctm_solve_cpl<28, 8, 3, false, 1>);
+        case 280084: return go(k_ctm_solve_cpl<28, 8, 4, false, 1>);
+        case 280162: return go(k_ctm_solve_cpl<28, 16, 2, false, 1>);
+        case 280163: return go(k_ctm_solve_cpl<28, 16, 3, false, 1>);
+        case 280164: return go(k_ctm_solve_cpl<28, 16, 4, false, 1>);
+        case 280166: return go(k_ctm_solve_cpl<28, 16, 6, false, 1>);
+        case 280042: return go(k_ctm_solve_cpl<28, 4, 2, false, 1>);
+        case 280043: return go(k_ctm_solve_cpl<28, 4, 3, false, 1>);
+    }
+    return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no split nu-solve build for sum K = %d, %d lanes, %d waves per SIMD", m->dm.MK, m->nu_Ls, m->nu_occ);
+}
+
 template <int PH>
 int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
@@ -1763,9 +1860,19 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             // builds: 2 waves per SIMD, chains of the coordinates interleaved by the scheduler (sum K = 10: 245 VGPRs, no scratch; 263 us at
             // config 5 against 323 us for the 3-wave build with one coordinate at a time); sum K = 14 / 28: the 2-wave builds with scheduling barriers
             if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
-            if (m->dm.MK == 28 && m->Ls == 8) return go(k_ctm_solve_cpl<28, 8, 2, false>);
+            if (m->dm.MK == 28 && m->Ls == 8 && !m->split) return go(k_ctm_solve_cpl<28, 8, 2, false>);
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
             if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
+            if (!m->split && m->dm.MK == 28 && m->Ls == 16) return go(k_ctm_solve_cpl<28, 16, 3, false>);
+            if (m->split && m->dm.MK == 28 && m->Ls == 16) {
+                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 16, 2, false, 2>);
+                if (m->lam_occ == 3) return go(k_ctm_solve_cpl<28, 16, 3, false, 2>);
+                return go(k_ctm_solve_cpl<28, 16, 4, false, 2>);
+            }
+            if (m->split && m->dm.MK == 28 && m->Ls == 8) {
+                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 8, 2, false, 2>);
+                return go(k_ctm_solve_cpl<28, 8, 3, false, 2>);
+            }
             return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
         }
         if (m->Ls != m->L) {       // packed groups: sum K lanes per document
@@ -1824,7 +1931,20 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
     }
     if (flags & (F_NU | F_LAMBDA)) {
         ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
-        if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
+        if (m->split) {             // update_ν! and update_λ! as two launches, each in its own lane layout
+            CtmEArgs b = a;
+            static const bool dyn = getenv("MMM_CTM_CLAIM") == nullptr || atoi(getenv("MMM_CTM_CLAIM")) != 0;
+            for (int which = 0; which < 2; ++which) {
+                if (!(flags & (which == 0 ? F_NU : F_LAMBDA))) continue;
+                b.flags = flags & ~(which == 0 ? F_LAMBDA : F_NU);
+                b.claim = nullptr;
+                if (dyn && (which == 0 || m->persist)) {       // documents on demand: the launch's counters start at 0
+                    b.claim = m->claim.p + ((size_t)which * m->R + r0) * 32;
+                    MMM_HIP(m->ctx, hipMemsetAsync(b.claim, 0, sizeof(int) * 32 * sc.nrep, m->ctx->stream));
+                }
+                if ((rc = which == 0 ? launch_nu_split(m, b, sc.nrep) : launch_phase<1>(m, b, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
+            }
+        } else if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
     }
     return MMM_OK;
 }
@@ -2217,9 +2337,11 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         const bool allow = !pe || atoi(pe) != 0;
         if (allow && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
         // several coordinates per lane (k_ctm_solve_cpl): sum K = 10 -> 2 lanes x 5 coordinates (32 document slots per wave; BASELINE config 5:
-        // solve phase 334 -> 263 us).  Builds for sum K = 14 (2 x 7) and 28 (8 lanes, 7 of them x 4) exist but do not beat one coordinate per
-        // lane there (config 4: 762 vs 726 us; a 4 x 7 build: 1105 us -- two waves per SIMD do not hide the chains of 4-7 coordinates as
-        // four waves with one coordinate each do); MMM_CTM_CPL=2 selects them (tests, A/B), MMM_CTM_CPL=0 switches the path off.
+        // solve phase 334 -> 263 us); sum K = 28 -> 16 lanes, 14 of them x 2 coordinates (round 3; 4 slots per wave, 134 VGPRs at 3 waves per
+        // SIMD, no scratch: BASELINE config 4 solve phase 1,096 -> 974 us at pass 20, 794 -> 757 us at pass 60 -- and the sums of a document
+        // are associated exactly as the 32-lane butterfly associates them, so not a bit changes).  Other builds for sum K = 14 (2 x 7) and
+        // 28 (8 lanes, 7 of them x 4; 32 lanes x 1) exist and do not beat these: MMM_CTM_CPL=2 / 3 select them (tests, A/B), MMM_CTM_CPL=0
+        // switches the path off (one coordinate per lane, lock step: k_ctm_estep<L, 1>).
         const char* ce = getenv("MMM_CTM_CPL");
         const int cmode = ce ? atoi(ce) : 1;
         if (cmode != 0) {
@@ -2227,14 +2349,24 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
             else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
+            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }         // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
             if (m->cpl > 1) m->persist = true;
+        }
+        // MMM_CTM_SPLIT="nuLanes:nuWaves:lamLanes:lamWaves" (sum K = 28): the two solves as two launches with their own layouts
+        if (const char* sp = getenv("MMM_CTM_SPLIT")) {
+            int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            if (dm.MK == 28 && sscanf(sp, "%d:%d:%d:%d", &a1, &a2, &a3, &a4) == 4 && a1 > 0) {
+                m->split = true; m->nu_Ls = a1; m->nu_cpl = (28 + a1 - 1) / a1; m->nu_occ = a2; m->lam_occ = a4;
+                m->Ls = a3; m->cpl = (28 + a3 - 1) / a3; m->persist = m->cpl > 1;
+            }
         }
     }
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
     // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
     // slots work through (a finished slot takes the range's next document)
-    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * (m->cpl > 1 ? 2 : 4)));
+    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * ((m->split || m->Ls == 16) ? m->lam_occ : (m->cpl > 1 ? 2 : 4))));
+    if (m->split) { const int Gn = MMM_WAVE / m->nu_Ls; m->grid_nu = std::max(1, std::min((D + m->waves_s * Gn - 1) / (m->waves_s * Gn), ctx->num_cu * m->nu_occ)); }
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks
     {
@@ -2254,7 +2386,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
     A(partial, m->wide ? 1 : Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
     A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
-    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz);
+    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz); A(claim, 2 * Rz * 32);
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * M * (D + 1), hipMemcpyHostToDevice, st));
@@ -2625,7 +2757,7 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = m->cpl; out[7] = 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = m->cpl; out[7] = m->split ? m->nu_cpl : 0;
     return MMM_OK;
 }
 

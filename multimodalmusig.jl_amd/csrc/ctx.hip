@@ -104,8 +104,24 @@ int mmm_ctx_profile_repeat(mmm_ctx* ctx, int repeat)
 int mmm_ctx_profile_select(mmm_ctx* ctx, int phase)
 {
     if (!ctx) return MMM_ERR_ARG;
-    MMM_CHECK(ctx, phase >= 0 && phase <= 7, "mmm_ctx_profile_select: phase must be 0..7");
+    MMM_CHECK(ctx, phase >= 0 && phase <= 8, "mmm_ctx_profile_select: phase must be 0..7, or 8 for all of them");
     ctx->prof_phase = phase;
+    return MMM_OK;
+}
+
+int mmm_ctx_profile_end_phases(mmm_ctx* ctx, int n_spans[8], double total_ms[8])
+{
+    if (!ctx || !n_spans || !total_ms) return MMM_ERR_ARG;
+    ctx->profiling = false;
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i) { n_spans[i] = 0; total_ms[i] = 0.0; }
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        MMM_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        const int ph = ctx->ev_phase.size() > i / 2 ? (ctx->ev_phase[i / 2] & 7) : 0;
+        n_spans[ph]++; total_ms[ph] += ms;
+    }
+    ctx->ev_used = 0;
     return MMM_OK;
 }
 

@@ -33,6 +33,7 @@ struct mmm_ctx {
     int prof_repeat = 1;          // launches of the dominant kernel inside each profiled span (differential timing)
     int prof_phase = 0;           // which launches of a pass the spans bracket (mmm_ctx_profile_select; 0 = the dominant kernel)
     std::vector<hipEvent_t> ev;   // pairs: ev[2i] start, ev[2i+1] stop
+    std::vector<int> ev_phase;    // phase of pair i (prof_phase = kProfAll brackets every phase)
     size_t ev_used = 0;
     // pipelined fits: two pinned 64-byte slots + events for in-stream snapshots of a model's control block, so that the host
     // can look at chunk i's stop flag while chunk i+1 is already running (lazily created)
@@ -53,8 +54,10 @@ void mmm_ctx_model_destroyed(mmm_ctx* ctx);      // may delete ctx
 // RAII span: records an event pair around a launch while profiling is on
 struct ProfSpan {
     mmm_ctx* ctx; bool on;
-    explicit ProfSpan(mmm_ctx* c, int phase = 0) : ctx(c), on(c->profiling && c->prof_phase == phase) {
+    explicit ProfSpan(mmm_ctx* c, int phase = 0) : ctx(c), on(c->profiling && (c->prof_phase == phase || c->prof_phase == 8)) {
         if (!on) return;
+        if (ctx->ev_phase.size() < ctx->ev_used / 2 + 1) ctx->ev_phase.resize(ctx->ev_used / 2 + 1);
+        ctx->ev_phase[ctx->ev_used / 2] = phase;
         if (ctx->ev_used + 2 > ctx->ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } ctx->ev.push_back(e); }
         }

@@ -510,7 +510,7 @@ class CtmOracle:
             s.Ls = int(geometry.get("Ls", 0) or s.L)
             s.cpl = int(geometry.get("cpl", 1) or 1)
             assert s.L in (16, 32, 64) and s.L >= self.MK and s.grid_e >= 1 and s.waves_e >= 1 and s.grid_m >= 1
-            assert (s.cpl == 1 and self.MK <= s.Ls <= 64) or (s.cpl > 1 and self.MK % s.cpl == 0 and s.Ls * s.cpl >= self.MK and s.Ls in (2, 4, 8))
+            assert (s.cpl == 1 and self.MK <= s.Ls <= 64) or (s.cpl > 1 and self.MK % s.cpl == 0 and s.Ls * s.cpl >= self.MK and s.Ls in (2, 4, 8, 16))
         self.s = s
         lib().orc_ctm_init(C.byref(s))
 

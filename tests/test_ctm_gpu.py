@@ -397,12 +397,17 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
 
 @pytest.mark.parametrize("env,case,expect", [({"MMM_CTM_CPL": "0", "MMM_CTM_PACK": "0"}, "imm10", (16, 1)), ({"MMM_CTM_CPL": "0"}, "imm10", (10, 1)),
                                              ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)), ({"MMM_CTM_CPL": "3"}, "cfg4_shape", (32, 1)),
+                                             ({}, "cfg4_shape", (16, 2)), ({"MMM_CTM_CPL": "0"}, "cfg4_shape", (32, 1)),
+                                             ({"MMM_CTM_SPLIT": "16:3:16:3"}, "cfg4_shape", (16, 2)), ({"MMM_CTM_SPLIT": "16:4:16:4", "MMM_CTM_CLAIM": "0"}, "cfg4_shape", (16, 2)),
+                                             ({"MMM_CTM_SPLIT": "16:3:32:4"}, "cfg4_shape", (32, 1)),
                                              ({}, "mm33", (6, 1)), ({}, "mm66", (12, 1))])
 def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, env, case, expect):
     """The solve phase has three lane layouts: one coordinate per lane in 16/32/64-lane DPP rows (mma_group), packed groups of sum K
     lanes (6 / 10 / 12; ds_bpermute tree), and several coordinates per lane (k_ctm_solve_cpl; sum K = 10 by default, 14 and 28 on
-    request).  Each associates the sums over a document differently; the oracle mirrors the layout the handle reports
-    (geometry Ls / cpl) and the fit must stay bit-identical in all of them."""
+    request; round 3: 16 lanes x 2 coordinates for sum K = 28 by default).  Each associates the sums over a document differently; the
+    oracle mirrors the layout the handle reports (geometry Ls / cpl) and the fit must stay bit-identical in all of them.  MMM_CTM_SPLIT
+    runs update_nu! and update_lambda! as two launches whose slots take their documents on demand (claim_doc; MMM_CTM_CLAIM=0: static
+    ranges) -- which slot solves which document changes nothing."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     if case == "imm10":

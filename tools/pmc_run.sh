@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes of bench.py, one pass per counter set (SQ: <= 8 counters per pass; FETCH_SIZE and WRITE_SIZE never share a
 # pass -- MI355X_MICROARCH.md "rocprofv3 PMC slots").  The profiled program comes directly after `--` (no env / sh hop).
+# PMC_PROG=tools/diag_solve_split.py profiles that script instead of bench.py.
 # usage: tools/pmc_run.sh <outdir under gpurun_out> <tag> <passes: e.g. "A B C D"> -- <bench.py arguments>
 set -u
 out=$1; tag=$2; passes=$3; shift 4
@@ -14,6 +15,6 @@ SETS[C]="FETCH_SIZE"
 SETS[D]="WRITE_SIZE"
 SETS[E]="GRBM_GUI_ACTIVE"
 for p in $passes; do
-  rocprofv3 --pmc ${SETS[$p]} --output-format csv -d "$R/$out/${tag}_$p" -o "${tag}_$p" -- python3 "$R/bench.py" "$@" > "$R/$out/${tag}_$p.json" 2> "$R/$out/${tag}_$p.err" || echo "pass $p failed"
+  rocprofv3 --pmc ${SETS[$p]} --output-format csv -d "$R/$out/${tag}_$p" -o "${tag}_$p" -- python3 "$R/${PMC_PROG:-bench.py}" "$@" > "$R/$out/${tag}_$p.json" 2> "$R/$out/${tag}_$p.err" || echo "pass $p failed"
   echo "pass $p done: $(ls $R/$out/${tag}_$p 2>/dev/null | head -3 | tr '\n' ' ')"
 done
