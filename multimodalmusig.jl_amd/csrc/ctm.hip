@@ -1840,6 +1840,9 @@ int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
         case 280166: return go(k_ctm_solve_cpl<28, 16, 6, false, 1>);
         case 280042: return go(k_ctm_solve_cpl<28, 4, 2, false, 1>);
         case 280043: return go(k_ctm_solve_cpl<28, 4, 3, false, 1>);
+        case 100022: return go(k_ctm_solve_cpl<10, 2, 2, false, 1>);
+        case 100023: return go(k_ctm_solve_cpl<10, 2, 3, false, 1>);
+        case 100024: return go(k_ctm_solve_cpl<10, 2, 4, false, 1>);
     }
     return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no split nu-solve build for sum K = %d, %d lanes, %d waves per SIMD", m->dm.MK, m->nu_Ls, m->nu_occ);
 }
@@ -1859,7 +1862,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             };
             // builds: 2 waves per SIMD, chains of the coordinates interleaved by the scheduler (sum K = 10: 245 VGPRs, no scratch; 263 us at
             // config 5 against 323 us for the 3-wave build with one coordinate at a time); sum K = 14 / 28: the 2-wave builds with scheduling barriers
-            if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
+            if (m->dm.MK == 10 && m->Ls == 2 && !m->split) return go(k_ctm_solve_cpl<10, 2, 2, false>);
             if (m->dm.MK == 28 && m->Ls == 8 && !m->split) return go(k_ctm_solve_cpl<28, 8, 2, false>);
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
             if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
@@ -1868,6 +1871,11 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
                 if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 16, 2, false, 2>);
                 if (m->lam_occ == 3) return go(k_ctm_solve_cpl<28, 16, 3, false, 2>);
                 return go(k_ctm_solve_cpl<28, 16, 4, false, 2>);
+            }
+            if (m->split && m->dm.MK == 10 && m->Ls == 2) {
+                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<10, 2, 2, false, 2>);
+                if (m->lam_occ == 3) return go(k_ctm_solve_cpl<10, 2, 3, false, 2>);
+                return go(k_ctm_solve_cpl<10, 2, 4, false, 2>);
             }
             if (m->split && m->dm.MK == 28 && m->Ls == 8) {
                 if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 8, 2, false, 2>);
@@ -2355,9 +2363,9 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         // MMM_CTM_SPLIT="nuLanes:nuWaves:lamLanes:lamWaves" (sum K = 28): the two solves as two launches with their own layouts
         if (const char* sp = getenv("MMM_CTM_SPLIT")) {
             int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            if (dm.MK == 28 && sscanf(sp, "%d:%d:%d:%d", &a1, &a2, &a3, &a4) == 4 && a1 > 0) {
-                m->split = true; m->nu_Ls = a1; m->nu_cpl = (28 + a1 - 1) / a1; m->nu_occ = a2; m->lam_occ = a4;
-                m->Ls = a3; m->cpl = (28 + a3 - 1) / a3; m->persist = m->cpl > 1;
+            if ((dm.MK == 28 || dm.MK == 10) && sscanf(sp, "%d:%d:%d:%d", &a1, &a2, &a3, &a4) == 4 && a1 > 0) {
+                m->split = true; m->nu_Ls = a1; m->nu_cpl = (dm.MK + a1 - 1) / a1; m->nu_occ = a2; m->lam_occ = a4;
+                m->Ls = a3; m->cpl = (dm.MK + a3 - 1) / a3; m->persist = m->cpl > 1;
             }
         }
     }

@@ -488,6 +488,9 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
 // whole launch (SL * KP doubles per lane) and reach the slab once, at the end.  Per term slot: a conflict-free 16-byte-per-lane read
 // of the term-major table and 2 KP + 16 f64 instructions; no atomics in the loop.  HBM per document: 4 Vp bytes of counts instead of
 // 8 bytes per nonzero.  Same formulas as k_lda_estep (LDA.jl:69-108); the sums are associated per lane, then lanes, waves, blocks.
+// v_max_f64 without the canonicalising v_max(x, x) the compiler puts before fmax()
+__device__ __forceinline__ double dev_max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <int KP, int SL>
 __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
 {
@@ -568,8 +571,9 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
 #pragma unroll
             for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
             if (KP & 1) s0 += b[KP - 1];
-            // a slot without mass must not see 0 x rcp(0): with tiny priors the normaliser of a never-observed term underflows to 0
-            const double r = c[q] > 0 ? (double)c[q] * dev_rcp(s0 + s1) : 0.0;
+            // a slot without mass must not see 0 x rcp(0) = NaN: with tiny priors the normaliser of a never-observed term underflows to 0.
+            // (v_max with the smallest normal: the bits of every other quotient are unchanged; a select on the count costs 150 spilled registers here)
+            const double r = (double)c[q] * dev_rcp(dev_max_raw(s0 + s1, 2.2250738585072014e-308));
 #pragma unroll
             for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
             // one slot at a time, its statistics updated here (left alone the compiler sinks the SL KP updates to the end of the step and keeps
@@ -618,6 +622,173 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * K * V + i];
         out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = s;
+    }
+}
+
+// The same data flow with 32-lane document groups in the term phase (round 3): a lane owns S3 = Vp / 32 term slots, HALF the statistics
+// registers of the 16-lane layout (S3 * KP doubles: 60 VGPRs at K = 10, V = 96, against 120), which is what lets a third wave per SIMD in
+// (one 12-wave block per CU, <= 168 VGPRs) -- the 16-lane build ran at 52 % VALU busy with two.  A wave step still covers four documents:
+// the Elntheta / a_k prologue in the 16-lane layout for all four at once (K + 1 lanes of 16 busy), then two term-phase sub-steps of two
+// documents each.  gamma_{t+1}: the lanes' partial sums meet in LDS, lane (k, part) of a document adds 16 of its 32 lanes' values, the
+// two parts meet through one DPP quad exchange.  The per-wave slabs exist only after the sweep and take the place of the gamma scratch,
+// as many waves at a time as fit there.
+template <int KP, int S3>
+__global__ __launch_bounds__(768, 1) void k_lda_estep_dense32(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int Vp = 32 * S3;
+    const int t = a.t;
+    const int stop = a.ctl->stop;
+    const double* __restrict__ gam = a.gamma.s[t % 3];
+    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
+    double* __restrict__ Eln = a.Elntheta.s[t % 3];
+    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
+    const int K = a.c.K, D = a.c.D, V = a.c.V;
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g16 = lane >> 4, l16 = lane & 15;      // prologue: 4 documents x 16 lanes
+    const int h = lane >> 5, l32 = lane & 31;        // term phase: 2 documents x 32 lanes
+    double* sT = smem;                                   // [Vp][KP] exp(Elnbeta_{t-1}), term-major; rows v >= V hold 1 (their counts are 0)
+    double* sA = sT + (size_t)Vp * KP;                   // [NW][4][KP] a_k of the wave step's four documents
+    double* sR = sA + (size_t)NW * 4 * KP;               // [NW][64][KP] gamma sums, lane-major; after the sweep: slabs [fit][K][V]
+    double* myA = sA + (size_t)wid * 4 * KP;
+    double* myR = sR + (size_t)wid * MMM_WAVE * KP;
+    const int stride = gridDim.x * NW * 4;
+    int base = (blockIdx.x * NW + wid) * 4;
+
+    double gk = (base + g16 < D && l16 < K) ? gam[(size_t)(base + g16) * K + l16] : (l16 < K ? 1.0 : 0.0);
+    int c[2][S3];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int dd = base + 2 * sub + h;
+#pragma unroll
+        for (int q = 0; q < S3; ++q) c[sub][q] = dd < D ? (cnt16 ? (int)cnt16[(size_t)dd * Vp + q * 32 + l32] : cnt[(size_t)dd * Vp + q * 32 + l32]) : 0;
+    }
+    for (int i = tid; i < Vp * KP; i += blockDim.x) {
+        const int v = i / KP, k = i % KP;
+        sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
+    }
+    double st[S3][KP];
+#pragma unroll
+    for (int q = 0; q < S3; ++q)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) st[q][k] = 0.0;
+    bool first = true;
+    for (;;) {
+        // ---- the next step's gamma rows and counts are requested before this step computes
+        const bool more = base + stride < D;
+        const int bn = base + stride;
+        double gkn = l16 < K ? 1.0 : 0.0;
+        if (more && bn + g16 < D && l16 < K) gkn = gam[(size_t)(bn + g16) * K + l16];
+        int cn[2][S3];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int dd = bn + 2 * sub + h;
+#pragma unroll
+            for (int q = 0; q < S3; ++q) cn[sub][q] = (more && dd < D) ? (cnt16 ? (int)cnt16[(size_t)dd * Vp + q * 32 + l32] : cnt[(size_t)dd * Vp + q * 32 + l32]) : 0;
+        }
+        // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k): four documents, 16 lanes each
+        const double S = group_sum<16>(gk);
+        const double ps = dev_digamma_pos(l16 < K ? gk : S);        // lane K of the group holds psi(S)
+        const double psS = __shfl(ps, g16 * 16 + K, MMM_WAVE);
+        const double el = ps - psS;
+        if (l16 < KP) myA[g16 * KP + l16] = (l16 < K) ? ar_exp(el) : 0.0;
+        if (first) {
+            if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
+            __syncthreads();
+            first = false;
+        } else lds_wave_sync();
+        if (base + g16 < D && l16 < K) Eln[(size_t)(base + g16) * K + l16] = el;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int dd = base + 2 * sub + h;
+            const double* Arow = myA + (2 * sub + h) * KP;
+            double acc[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc[k] = 0.0;
+            // ---- phi_kv n_v (LDA.jl:92-106) for the lane's S3 terms (a_k comes from LDS in every slot: a broadcast read, and 2 KP registers fewer)
+#pragma unroll
+            for (int q = 0; q < S3; ++q) {
+                const double* tb = sT + (size_t)(q * 32 + l32) * KP;
+                double b[KP], s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) b[k] = Arow[k] * tb[k];
+#pragma unroll
+                for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
+                if (KP & 1) s0 += b[KP - 1];
+                // a slot without mass must not see 0 x rcp(0) = NaN (see k_lda_estep_dense)
+                const double r = (double)c[sub][q] * dev_rcp(dev_max_raw(s0 + s1, 2.2250738585072014e-308));
+#pragma unroll
+                for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
+#pragma unroll
+                for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(st[q][k]));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- gamma_{t+1} = alpha + sum_v phi_kv n_v: lane (kk, part) adds 16 lanes' values of topic kk, the two parts meet by DPP
+#pragma unroll
+            for (int k = 0; k < KP; ++k) myR[(size_t)lane * KP + k] = acc[k];
+            lds_wave_sync();
+            {
+                const int kk = l32 >> 1, part = l32 & 1;
+                double tot = 0.0;
+                if (kk < K) {
+                    const double* col = myR + (size_t)(h * 32 + part * 16) * KP + kk;
+                    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) { r0 += col[j * KP]; r1 += col[(j + 1) * KP]; r2 += col[(j + 2) * KP]; r3 += col[(j + 3) * KP]; }
+                    tot = (r0 + r1) + (r2 + r3);
+                }
+                tot += dpp_mov_f64<0xB1>(tot);          // quad_perm [1,0,3,2]: the other part
+                if (kk < K && part == 0 && dd < D) gnext[(size_t)dd * K + kk] = a.c.alpha + tot;
+            }
+            lds_wave_sync();
+        }
+        base += stride;
+        if (base >= D) break;
+        gk = gkn;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int q = 0; q < S3; ++q) c[sub][q] = cn[sub][q];
+    }
+    // ---- the lanes' statistics -> per-wave slabs [K][V] in the gamma scratch, `fit` waves at a time; block sums in wave order
+    __syncthreads();
+    const int KV = K * V;
+    const int fit = max(1, (NW * MMM_WAVE * KP) / KV);
+    double accum[4] = {0.0, 0.0, 0.0, 0.0};              // K V <= 4 blockDim (checked by the host)
+    for (int w0 = 0; w0 < NW; w0 += fit) {
+        if (wid >= w0 && wid < w0 + fit) {
+            double* slab = sR + (size_t)(wid - w0) * KV;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (h == hh) {
+#pragma unroll
+                    for (int q = 0; q < S3; ++q) {
+                        const int v = q * 32 + l32;
+                        if (v < V) {
+#pragma unroll
+                            for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] = (hh ? slab[(size_t)k * V + v] : 0.0) + st[q][k];
+                        }
+                    }
+                }
+                lds_wave_sync();
+            }
+        }
+        __syncthreads();
+        const int nw = min(fit, NW - w0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * blockDim.x;
+            if (i < KV) for (int w = 0; w < nw; ++w) accum[j] += sR[(size_t)w * KV + i];
+        }
+        __syncthreads();
+    }
+    double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * blockDim.x;
+        if (i < KV) out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = accum[j];
     }
 }
 
@@ -1656,6 +1827,7 @@ struct mmm_lda {
     DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits (then cnt_dense is not built)
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
     bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
+    bool dense32 = false;       // ... its 32-lane build (k_lda_estep_dense32: 12-wave blocks, three waves per SIMD)
     bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
@@ -1780,6 +1952,18 @@ int go_dense(mmm_lda* m, const EstepArgs& a)
     } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no dense-row build for KP=%d SL=%d", KPV, SLV);
 }
 
+template <int KPV, int S3V>
+int go_dense32(mmm_lda* m, const EstepArgs& a)
+{
+    if constexpr (KPV * S3V <= 40) {
+        mmm_ctx* ctx = m->ctx;
+        auto k = k_lda_estep_dense32<KPV, S3V>;
+        if (!m->attr_d) { int rc = set_lds(ctx, k, m->lds_d); if (rc) return rc; m->attr_d = true; }
+        hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p, (const unsigned short*)m->cnt16.p);
+        return MMM_OK;
+    } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no 32-lane dense-row build for KP=%d S3=%d", KPV, S3V);
+}
+
 // term slots per lane of the dense-row build that covers V terms (0: none)
 int dense_slots(int V) { return V <= 32 ? 2 : (V <= 48 ? 3 : (V <= 96 ? 6 : (V <= 128 ? 8 : 0))); }
 
@@ -1787,6 +1971,20 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
     int rc = MMM_OK;
+    if (m->dense && m->dense32 && !a.do_ll) {
+        MMM_KP_SWITCH(m, {
+            if constexpr (KPV >= 4 && KPV <= 16) {
+                switch (m->SL) {
+                    case 2: rc = go_dense32<KPV, 1>(m, a); break;
+                    case 6: rc = go_dense32<KPV, 3>(m, a); break;
+                    default: rc = go_dense32<KPV, 4>(m, a); break;
+                }
+            }
+        })
+        if (rc) return rc;
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     if (m->dense && !a.do_ll) {
         MMM_KP_SWITCH(m, {
             if constexpr (KPV >= 4 && KPV <= 16) {
@@ -2260,7 +2458,22 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     if (m->dense)      // [16 SL][KP] table | [waves][K][V] slabs | [waves][G][KP] a_k | [waves][64][KP] gamma sums
         m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * K * V + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
-    if (m->dense && m->lds_d > 160 * 1024) { m->dense = false; m->drows = drows && !wide; }      // no dense-row build: rows only if the corpus is dense enough
+    {   // the 32-lane build: slots per lane even in the 16-lane count (rows of 32 S3 counts), sum K x slots within its registers, one
+        // 12-wave block per CU.  LDS: [32 S3][KP] table | [12][4][KP] a_k | [12][64][KP] gamma sums (later: slabs).  MMM_LDA_DENSE32=0: the 16-lane build
+        // Measured (round 3, K = 10, V = 96, 16-bit rows): 160k documents 90.0 vs 80.9 us, 640k 337 vs 280 us -- SLOWER than the 16-lane
+        // build: 168 VGPRs with 42 spilled, and the term phase (2 documents per sub-step) pays its LDS round trips twice per wave step.
+        // Off unless MMM_LDA_DENSE32=1 (tests keep it alive).
+        const bool d32_env = getenv("MMM_LDA_DENSE32") != nullptr && atoi(getenv("MMM_LDA_DENSE32")) != 0;
+        const int S3 = SL / 2;
+        if (m->dense && d32_env && (SL == 2 || SL == 6 || SL == 8) && KP >= 4 && KP <= 16 && KP * S3 <= 40 && K * V <= 4 * 768 && K * V <= 12 * 64 * KP &&
+            !getenv("MMM_LDA_WAVES") && !getenv("MMM_LDA_GRID")) {
+            m->dense32 = true;
+            m->waves_e = 12;
+            m->lds_d = sizeof(double) * ((size_t)32 * S3 * KP + (size_t)12 * 4 * KP + (size_t)12 * MMM_WAVE * KP);
+            m->grid_e = std::max(1, std::min((D + 47) / 48, ctx->num_cu));
+        }
+    }
+    if (m->dense && m->lds_d > 160 * 1024) { m->dense = false; m->dense32 = false; m->drows = drows && !wide; }      // no dense-row build: rows only if the corpus is dense enough
     m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); return rc; } } while (0)

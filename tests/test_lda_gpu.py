@@ -200,10 +200,14 @@ def test_degenerate_shapes(mmm, oracle):
 
 @pytest.mark.parametrize("D,V,K,mean_n", [(500, 96, 10, 500), (300, 40, 7, 200), (260, 128, 4, 900), (70, 20, 12, 100), (333, 90, 5, 60),
                                            (200, 33, 15, 300)])
-def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_n):
+@pytest.mark.parametrize("lanes32", ["0", "1"])
+def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_n, lanes32):
     """The dense-row E-step build (rows of counts, statistics in registers; taken by default for dense corpora too large for the single-step
-    build) forced on small corpora of every slot count it has builds for, sparse rows and empty documents included."""
+    build) forced on small corpora of every slot count it has builds for, sparse rows and empty documents included.  lanes32: its
+    32-lane variant (k_lda_estep_dense32, round 3: slower than the 16-lane build and off by default; where the shape has no such build
+    the 16-lane one runs)."""
     monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    monkeypatch.setenv("MMM_LDA_DENSE32", lanes32)
     X, g, o = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
     geo = g.geometry()
     assert geo["dense"] == 1 and geo["SL"] * 16 >= V and geo["single_step"] == 0
