@@ -1603,6 +1603,148 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* 
     }
 }
 
+// ---- more than 32 topics (round 3): the two sweeps of the wide path with the topic loops ROLLED -- runtime K <= 64, KP = K rounded up to
+// even -- so that no build per K is needed and nothing goes to scratch: a_k / theta_k of the wave's document sit in LDS (broadcast reads),
+// and the sums over a document's nonzeros (gamma_{t+1,k}) resp. over a term's postings (the lambda statistics) are kept as one LDS column
+// per lane and topic and added up across the lanes at the end.  The reference has no limit on K (LDA.jl:24-54); beyond 64 the per-document
+// kernels' "one topic per lane" prologues would have to be strided as well -- not built.
+// LDS per wave: [KP][64] column sums | [KP] a_k | [KP] theta_k.
+__global__ __launch_bounds__(kBlock) void k_lda_estep_big(EstepArgs a, double* __restrict__ aexp, const double* __restrict__ eBT,
+                                                          const double* __restrict__ betaT, int KP)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double shw[kWavesPerBlock];
+    if (a.ctl->stop) return;
+    const int t = a.t;
+    const double* __restrict__ gam = a.gamma.s[t % 3];
+    const double* __restrict__ gprev = a.gamma.s[(t + 2) % 3];
+    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
+    double* __restrict__ Eln = a.Elntheta.s[t % 3];
+    const int K = a.c.K, D = a.c.D;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double* wacc = smem + (size_t)wid * ((size_t)KP * MMM_WAVE + 2 * KP);
+    double* wav = wacc + (size_t)KP * MMM_WAVE;
+    double* wtv = wav + KP;
+    double wave_ll = 0.0;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < D; d += gridDim.x * kWavesPerBlock) {
+        const double gk = (lane < K) ? gam[(size_t)d * K + lane] : 0.0;
+        const double S = wave_sum(gk);
+        const double ps = dev_digamma_pos(lane < K ? gk : S);          // lanes >= K hold psi(S); with K = 64 no lane does
+        const double psS = (K < MMM_WAVE) ? wave_bcast(ps, K) : dev_digamma_pos(S);
+        const double el = ps - psS;
+        const double ak = (lane < K) ? exp(el) : 0.0;
+        if (lane < K) Eln[(size_t)d * K + lane] = el;
+        if (lane < KP) aexp[(size_t)d * KP + lane] = ak;      // D x KP rows, zero-padded
+        double th = 0.0;
+        if (a.do_ll) {
+            const double gp = (lane < K) ? gprev[(size_t)d * K + lane] : 0.0;
+            th = gp / wave_sum(gp);
+        }
+        lds_wave_sync();
+        if (lane < KP) { wav[lane] = ak; wtv[lane] = th; }
+        for (int k = 0; k < KP; ++k) wacc[(size_t)k * MMM_WAVE + lane] = 0.0;
+        lds_wave_sync();
+        const int64_t start = a.c.doc_ptr[d];
+        const int W = (int)(a.c.doc_ptr[d + 1] - start);
+        double ll = 0.0;
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int2 tc = a.c.tc[start + w];
+            const double n = (double)tc.y;
+            const double2* __restrict__ col = (const double2*)(eBT + (size_t)tc.x * KP);       // KP is even: 16-byte aligned
+            double s = 0.0;
+            for (int k = 0; k < KP; k += 2) {
+                const double2 b = col[k / 2];
+                s += wav[k] * b.x; s += wav[k + 1] * b.y;          // padded topics: 0 * 0
+            }
+            const double rn = n / s;
+            for (int k = 0; k < KP; k += 2) {
+                const double2 b = col[k / 2];
+                double* c0 = wacc + (size_t)k * MMM_WAVE + lane;
+                c0[0] = fma(wav[k] * b.x, rn, c0[0]);
+                c0[MMM_WAVE] = fma(wav[k + 1] * b.y, rn, c0[MMM_WAVE]);
+            }
+            if (a.do_ll) {
+                const double2* __restrict__ bc = (const double2*)(betaT + (size_t)tc.x * KP);
+                double p = 0.0;
+                for (int k = 0; k < KP; k += 2) { const double2 b = bc[k / 2]; p = fma(wtv[k], b.x, p); p = fma(wtv[k + 1], b.y, p); }
+                ll = fma(n, log(p), ll);
+            }
+        }
+        lds_wave_sync();
+        if (lane < K) {       // lane k adds its topic's 64 column sums, starting at column k (rotated: the lanes stay on different LDS banks)
+            const double* row = wacc + (size_t)lane * MMM_WAVE;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+            for (int j = 0; j < MMM_WAVE; j += 4) {
+                r0 += row[(j + lane) & 63]; r1 += row[(j + 1 + lane) & 63]; r2 += row[(j + 2 + lane) & 63]; r3 += row[(j + 3 + lane) & 63];
+            }
+            gnext[(size_t)d * K + lane] = a.c.alpha + ((r0 + r1) + (r2 + r3));
+        }
+        if (a.do_ll) wave_ll += wave_sum(ll);
+    }
+    if (a.do_ll) {
+        if (lane == 0) shw[wid] = wave_ll;
+        __syncthreads();
+        if (threadIdx.x == 0) a.llpart[blockIdx.x] = shw[0] + shw[1] + shw[2] + shw[3];
+    }
+}
+
+// the term-major sweep (k_lda_stats_terms) with rolled topic loops: block v < V = term v, at most 4 waves, each over a contiguous segment of
+// the term's postings; LDS: [waves][KP][64] column sums | [KP] the term's table column | [waves][KP] segment sums.  Block V: the ll partials.
+__global__ __launch_bounds__(256) void k_lda_stats_big(int V, int K, int KP, const int64_t* __restrict__ term_ptr, const int2* __restrict__ tpost,
+                                                       const double* __restrict__ aexp, const double* __restrict__ eB, ReduceArgs r)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (r.ctl->stop) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int v = blockIdx.x;
+    if (v == V) {
+        if (wid == 0) {
+            double s = 0.0;
+            for (int i = lane; i < r.nslab; i += MMM_WAVE) s += r.llpart[i];
+            s = wave_sum(s);
+            if (lane == 0) r.stats[r.VK] = s;
+        }
+        return;
+    }
+    double* wacc = smem + (size_t)wid * KP * MMM_WAVE;
+    double* seb = smem + (size_t)nw * KP * MMM_WAVE;
+    double* sh = seb + KP;
+    for (int k = threadIdx.x; k < KP; k += blockDim.x) seb[k] = (k < K) ? eB[(size_t)k * V + v] : 0.0;
+    for (int k = 0; k < KP; ++k) wacc[(size_t)k * MMM_WAVE + lane] = 0.0;
+    __syncthreads();
+    const int64_t p0 = term_ptr[v], p1 = term_ptr[v + 1];
+    const int64_t seg = (p1 - p0 + nw - 1) / nw;
+    const int64_t q0 = p0 + wid * seg, q1 = (q0 + seg < p1) ? q0 + seg : p1;
+    for (int64_t j = q0 + lane; j < q1; j += MMM_WAVE) {
+        const int2 dn = tpost[j];
+        const double2* __restrict__ ad = (const double2*)(aexp + (size_t)dn.x * KP);      // one contiguous run per posting
+        double s = 0.0;
+        for (int k = 0; k < KP; k += 2) { const double2 x = ad[k / 2]; s += x.x * seb[k]; s += x.y * seb[k + 1]; }
+        const double rn = (double)dn.y / s;
+        for (int k = 0; k < KP; k += 2) {
+            const double2 x = ad[k / 2];
+            double* c0 = wacc + (size_t)k * MMM_WAVE + lane;
+            c0[0] = fma(x.x * seb[k], rn, c0[0]);
+            c0[MMM_WAVE] = fma(x.y * seb[k + 1], rn, c0[MMM_WAVE]);
+        }
+    }
+    lds_wave_sync();
+    if (lane < KP) {
+        const double* row = wacc + (size_t)lane * MMM_WAVE;
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+        for (int j = 0; j < MMM_WAVE; j += 4) {
+            r0 += row[(j + lane) & 63]; r1 += row[(j + 1 + lane) & 63]; r2 += row[(j + 2 + lane) & 63]; r3 += row[(j + 3 + lane) & 63];
+        }
+        sh[(size_t)wid * KP + lane] = (r0 + r1) + (r2 + r3);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        double tot = 0.0;
+        for (int w = 0; w < nw; ++w) tot += sh[(size_t)w * KP + threadIdx.x];
+        r.stats[(size_t)threadIdx.x * V + v] = tot;
+    }
+}
+
 // block v < V: the statistics of term v (LDA.jl:103-105), its postings split into blockDim.x / 64 contiguous segments, one per
 // wave, lanes over a segment's postings in order, segment sums added in segment order.  Block V: the E-step's ll partials
 // summed into stats[V*K] (what lda_reduce_block's wave 1 does).
@@ -1689,7 +1831,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_gamma_from_phi(LdaDev c, const d
         if (Elntheta) {
             const double S = wave_sum(g);
             const double ps = dev_digamma(lane < K ? g : S);
-            const double el = ps - wave_bcast(ps, K);
+            const double el = ps - (K < MMM_WAVE ? wave_bcast(ps, K) : dev_digamma(S));
             if (lane < K) Elntheta[(size_t)d * K + lane] = el;
         }
     }
@@ -1703,7 +1845,7 @@ __global__ __launch_bounds__(kBlock) void k_lda_Elntheta(LdaDev c, const double*
         const double g = (lane < K) ? gamma[(size_t)d * K + lane] : 0.0;
         const double S = wave_sum(g);
         const double ps = dev_digamma(lane < K ? g : S);
-        const double el = ps - wave_bcast(ps, K);
+        const double el = ps - (K < MMM_WAVE ? wave_bcast(ps, K) : dev_digamma(S));
         if (lane < K) Elntheta[(size_t)d * K + lane] = el;
     }
 }
@@ -1857,6 +1999,7 @@ struct mmm_lda {
     DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x KP, written by the document sweep for the term sweep
     DevBuf<double> tabT;                // wide: [2][V][KP] term-major copies of the pass's exp(Elnbeta) and beta tables
     int stats_waves = 1;                // waves per term block of k_lda_stats_terms
+    bool attr_big = false, attr_bigs = false;
     int grid_e = 1, waves_e = 8, grid_s = 1;
     size_t lds_e = 0, lds_tab = 0;
     // ILDA (src/ILDA.jl): feature-factorised topics; the V x K rings then hold the effective tables
@@ -1875,6 +2018,7 @@ int pick_kp(int K)
 {
     static const int opts[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
     for (int o : opts) if (K <= o) return o;
+    if (K <= 64) return (K + 1) & ~1;      // 33..64 topics: the rolled-loop kernels (k_lda_estep_big, k_lda_stats_big), wide path only
     return -1;
 }
 
@@ -1890,7 +2034,7 @@ int pick_kp(int K)
         case 20: { constexpr int KPV = 20; __VA_ARGS__ } break;                                                        \
         case 24: { constexpr int KPV = 24; __VA_ARGS__ } break;                                                        \
         case 32: { constexpr int KPV = 32; __VA_ARGS__ } break;                                                        \
-        default: return mmm_fail((m)->ctx, MMM_ERR_UNSUPPORTED, "LDA: K=%d not supported (max 32)", (m)->K);    \
+        default: return mmm_fail((m)->ctx, MMM_ERR_UNSUPPORTED, "LDA: K=%d has no build on this path (the LDS builds stop at 32 topics)", (m)->K);    \
     }
 
 template <typename Kern>
@@ -2005,6 +2149,11 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
         const int slot = (a.t + 2) % 3;
         hipLaunchKernelGGL(k_lda_tables_by_term, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->V, m->K, m->KP,
                            (const double*)a.expElnbeta.s[slot], a.do_ll ? (const double*)a.beta.s[slot] : (const double*)nullptr, m->tabT.p, m->tabT.p + n);
+        if (m->KP > 32) {
+            const size_t lds = sizeof(double) * kWavesPerBlock * ((size_t)m->KP * MMM_WAVE + 2 * m->KP);
+            if (!m->attr_big) { if ((rc = set_lds(ctx, k_lda_estep_big, lds))) return rc; m->attr_big = true; }
+            hipLaunchKernelGGL(k_lda_estep_big, dim3(m->grid_e), dim3(kBlock), lds, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n, m->KP);
+        } else
         MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_estep_wide<KPV>, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n); })
         MMM_LAUNCH_CHECK(ctx);
         return MMM_OK;
@@ -2022,6 +2171,11 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
 int launch_phi(mmm_lda* m, const double* Elntheta, const double* expElnbeta)
 {
     mmm_ctx* ctx = m->ctx;
+    if (m->KP > 32) {       // 33..64 topics (off the iteration path): the 64-topic build, topics >= K skipped
+        hipLaunchKernelGGL((k_lda_phi<64, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     MMM_KP_SWITCH(m, {
         if (m->wide) hipLaunchKernelGGL((k_lda_phi<KPV, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
         else {
@@ -2038,6 +2192,11 @@ int launch_loglik(mmm_lda* m, const double* gamma, const double* beta, double* t
 {
     mmm_ctx* ctx = m->ctx;
     const size_t lds = compute_ll ? m->lds_tab : 0;
+    if (m->KP > 32) {
+        hipLaunchKernelGGL((k_lda_loglik<64, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     MMM_KP_SWITCH(m, {
         if (m->wide) hipLaunchKernelGGL((k_lda_loglik<KPV, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
         else {
@@ -2237,7 +2396,13 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             m->ll_pending = true;
             continue;
         }
-        if (m->wide) {
+        if (m->wide && m->KP > 32) {
+            const int nw = std::min(m->stats_waves, 4);
+            const size_t lds = sizeof(double) * ((size_t)nw * m->KP * MMM_WAVE + m->KP + (size_t)nw * m->KP);
+            if (!m->attr_bigs) { if ((rc = set_lds(ctx, k_lda_stats_big, lds))) return rc; m->attr_bigs = true; }
+            hipLaunchKernelGGL(k_lda_stats_big, dim3(m->V + 1), dim3(nw * MMM_WAVE), lds, ctx->stream, m->V, m->K, m->KP, m->term_ptr.p, m->tpost.p, m->aexp.p,
+                               m->expElnbeta[(t + 2) % 3].p, r);
+        } else if (m->wide) {
             MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_stats_terms<KPV>, dim3(m->V + 1), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, m->V, m->K,
                                                   m->term_ptr.p, m->tpost.p, m->aexp.p, m->expElnbeta[(t + 2) % 3].p, r); })
         } else if (r.n_ll > 0) {
@@ -2387,7 +2552,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     MMM_CHECK(ctx, D >= 0 && V >= 1 && K >= 1, "mmm_lda_create: bad sizes D=%d V=%d K=%d", D, V, K);
     *out = nullptr;
     const int KP = pick_kp(K);
-    if (KP < 0) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K=%d not supported (max 32)", K);
+    if (KP < 0) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K=%d not supported (max 64: the per-document kernels keep one topic per lane)", K);
     const int64_t nnz = doc_ptr[D];
     MMM_CHECK(ctx, doc_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (term && count)), "mmm_lda_create: bad CSR");
     std::vector<int2> tc((size_t)nnz);
@@ -2439,7 +2604,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     // tables + one slab beyond LDS: the wide path (k_lda_estep_wide).  It also takes K > 24: the LDS kernel's 32-topic build
     // spills (10k x 96-term documents, K = 32: 264 us per iteration against 189).  MMM_LDA_WIDE=1 / 0 forces / avoids it (tests, A/B).
     const char* wide_env = getenv("MMM_LDA_WIDE");
-    const bool wide = lds_for(waves) > 160 * 1024 || (wide_env ? atoi(wide_env) != 0 : KP >= 32);
+    const bool wide = lds_for(waves) > 160 * 1024 || KP > 32 || (wide_env ? atoi(wide_env) != 0 : KP >= 32);
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<mmm_lda> guard(new mmm_lda());      // every early return below (MMM_HIP, ...) destroys the model and its buffers

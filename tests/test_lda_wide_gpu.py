@@ -124,3 +124,35 @@ def test_wide_degenerate_shapes(mmm, oracle, monkeypatch):
     o = oracle.LdaOracle(2, 0.1, 0.1, X, V=3, lambda0=lam0)
     np.testing.assert_allclose(mmm.fit(g, maxiter=5, tol=0.0, verbose=False), o.fit(maxiter=5, tol=0.0), rtol=1e-11)
     np.testing.assert_allclose(g.λ, o.lam.reshape(3, 2, order="F"), rtol=1e-11)
+
+
+@pytest.mark.parametrize("D,V,K,mean_n", [(300, 96, 48, 3000), (150, 50, 33, 400), (120, 200, 64, 2500), (90, 1536, 40, 3000)])
+def test_more_than_32_topics(mmm, oracle, D, V, K, mean_n):
+    """The reference has no limit on K (LDA.jl:24-54).  33..64 topics run the two sweeps of the wide path with rolled topic loops
+    (k_lda_estep_big, k_lda_stats_big): stage sequence and whole fits against the oracle, early stop included; K = 64 leaves no lane for psi(sum gamma)."""
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=70 + K, mean_n=mean_n, empty=(2, D - 1))
+    assert g.geometry()["wide"] == 1
+    mmm.update_γ(g); o.update_gamma()
+    mmm.update_ϕ(g); o.update_phi()
+    mmm.update_λ(g); o.update_lambda()
+    mmm.update_β(g); o.update_beta()
+    mmm.update_θ(g); o.update_theta()
+    _cmp_state(g, o, 1e-11)
+    assert mmm.calculate_loglikelihood(g) == pytest.approx(o.loglik(), rel=1e-11)
+    X, g, o = _pair(mmm, oracle, D, V, K, seed=70 + K, mean_n=mean_n, empty=(2, D - 1))
+    ll_g = mmm.fit(g, maxiter=40, tol=1e-4, verbose=False)
+    ll_o = o.fit(maxiter=40, tol=1e-4)
+    assert len(ll_g) == len(ll_o) and g.converged == o.converged
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    np.testing.assert_allclose(g.phi_flat(), o.phi.reshape(-1, K), rtol=1e-5, atol=1e-12)       # north-star bar
+    np.testing.assert_allclose(g.θ, o.theta.reshape(D, K).T, rtol=1e-5)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(V, K, order="F"), rtol=1e-7)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-7)
+    N = np.array([x[:, 1].sum() for x in X], dtype=np.float64)
+    np.testing.assert_allclose(g.γ.sum(axis=0), K * 0.1 + N, rtol=1e-12)                         # mass conservation
+
+
+def test_more_than_64_topics_is_refused(mmm):
+    X, lam0 = np_ref.synth_lda(20, 30, 8, seed=1, mean_n=100)
+    with pytest.raises(mmm.MmmError, match="max 64"):
+        mmm.LDA(65, 0.1, 0.1, 30, X, λ0=np.ones((30, 65)))
