@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int kMaxM = 8;
-constexpr int kKmax = 32;          // topics per modality (the theta loop is unrolled to 16, or to 32 when a modality has more than 16)
+constexpr int kKmax = 64;          // topics per modality (the theta loop is unrolled to 8 / 10 / 16 / 32; 33..64: the 64-topic build of the wide-table path)
 constexpr int kWavesS = 4;         // stage / auxiliary kernels
 constexpr int kBlockS = kWavesS * MMM_WAVE;
 
@@ -1867,6 +1867,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
             if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
             if (!m->split && m->dm.MK == 28 && m->Ls == 16) return go(k_ctm_solve_cpl<28, 16, 3, false>);
+            if (!m->split && m->dm.MK == 14 && m->Ls == 8) return go(k_ctm_solve_cpl<14, 8, 4, false>);
             if (m->split && m->dm.MK == 28 && m->Ls == 16) {
                 if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 16, 2, false, 2>);
                 if (m->lam_occ == 3) return go(k_ctm_solve_cpl<28, 16, 3, false, 2>);
@@ -1900,6 +1901,9 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
         int kmax = 0;
         for (int i = 0; i < m->dm.M; ++i) kmax = std::max(kmax, m->dm.K[i]);
         if (m->wide) {
+            // 33..64 topics in one modality (sum K <= 64, so L = 64): the 64-topic build -- correct, far from tuned (its four 64-entry
+            // register arrays live in scratch); the reference has no limit (MMCTM.jl:29-91)
+            if (kmax > 32) return launch_estep_L<64, PH, 0, 64, 4, true>(m, a, lds, grid, waves, nrep);
             if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32, 4, true>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32, 4, true>(m, a, lds, grid, waves, nrep);
             if (m->L == 16) return launch_estep_L<16, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
             if (m->L == 32) return launch_estep_L<32, PH, 0, 16, 4, true>(m, a, lds, grid, waves, nrep);
@@ -2159,7 +2163,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     if (m->wide) {   // gamma sums by the term-major sweep, moments reduced on their own
         int kmax = 0;
         for (int i = 0; i < dm.M; ++i) kmax = std::max(kmax, dm.K[i]);
-        auto ks = kmax > 16 ? k_ctm_stats_terms<32> : k_ctm_stats_terms<16>;
+        auto ks = kmax > 32 ? k_ctm_stats_terms<64> : (kmax > 16 ? k_ctm_stats_terms<32> : k_ctm_stats_terms<16>);
         hipLaunchKernelGGL(ks, dim3(m->nterms, sc.nrep), dim3(m->stats_waves * MMM_WAVE), 0, ctx->stream, dm, m->term_ptr.p, m->tpost.p,
                            m->aexp.p + r0 * dm.D * dm.MK, m->expEeff.p + r0 * dm.GT, m->stats.p + r0 * m->s_stats + m->nmom, m->s_stats, sc.active);
         MMM_LAUNCH_CHECK(ctx);
@@ -2330,7 +2334,9 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     while (m->waves_e > 1 && estep_lds(m, F_SLAB) > 150 * 1024) m->waves_e >>= 1;
     // table + one slab beyond LDS: the wide path (theta phase through L2, gamma statistics by k_ctm_stats_terms).  MMM_CTM_WIDE=1
     // forces it for any shape (tests, A/B)
-    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr) { m->wide = true; m->waves_e = 8; }
+    int kmax_all = 0;
+    for (int i = 0; i < dm.M; ++i) kmax_all = std::max(kmax_all, dm.K[i]);
+    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr || kmax_all > 32) { m->wide = true; m->waves_e = 8; }
     const int dpb = m->waves_e * G;
     const int per_cu = m->wide ? 2 : std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
@@ -2357,7 +2363,8 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
             else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
-            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }         // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
+            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }
+            else if (cmode == 4 && dm.MK == 14) { m->Ls = 8; m->cpl = 2; m->lam_occ = 4; }                // 7 of 8 lanes x 2 coordinates         // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
             if (m->cpl > 1) m->persist = true;
         }
         // MMM_CTM_SPLIT="nuLanes:nuWaves:lamLanes:lamWaves" (sum K = 28): the two solves as two launches with their own layouts
@@ -2373,7 +2380,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
     // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
     // slots work through (a finished slot takes the range's next document)
-    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * ((m->split || m->Ls == 16) ? m->lam_occ : (m->cpl > 1 ? 2 : 4))));
+    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * ((m->split || m->Ls == 16 || (m->Ls == 8 && m->cpl == 2)) ? m->lam_occ : (m->cpl > 1 ? 2 : 4))));
     if (m->split) { const int Gn = MMM_WAVE / m->nu_Ls; m->grid_nu = std::max(1, std::min((D + m->waves_s * Gn - 1) / (m->waves_s * Gn), ctx->num_cu * m->nu_occ)); }
     if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
     // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks

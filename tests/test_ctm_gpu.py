@@ -396,7 +396,7 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
 
 
 @pytest.mark.parametrize("env,case,expect", [({"MMM_CTM_CPL": "0", "MMM_CTM_PACK": "0"}, "imm10", (16, 1)), ({"MMM_CTM_CPL": "0"}, "imm10", (10, 1)),
-                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)), ({"MMM_CTM_CPL": "3"}, "cfg4_shape", (32, 1)),
+                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "4"}, "cfg3_shape", (8, 2)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)), ({"MMM_CTM_CPL": "3"}, "cfg4_shape", (32, 1)),
                                              ({}, "cfg4_shape", (16, 2)), ({"MMM_CTM_CPL": "0"}, "cfg4_shape", (32, 1)),
                                              ({"MMM_CTM_SPLIT": "16:3:16:3"}, "cfg4_shape", (16, 2)), ({"MMM_CTM_SPLIT": "16:4:16:4", "MMM_CTM_CLAIM": "0"}, "cfg4_shape", (16, 2)),
                                              ({"MMM_CTM_SPLIT": "16:3:32:4"}, "cfg4_shape", (32, 1)),
@@ -468,12 +468,12 @@ def test_lane_group_widths(mmm, oracle, K, V):
 
 def test_unsupported_shapes_are_reported(mmm):
     X = [[np.array([[1, 3]]), np.array([[1, 2]])]]
-    with pytest.raises(mmm.MmmError, match="must be in 1..32"):
-        mmm.MMCTM([33, 2], [0.1, 0.1], [4, 4], X, seed=0)
+    with pytest.raises(mmm.MmmError, match="must be in 1..64"):
+        mmm.MMCTM([65, 2], [0.1, 0.1], [4, 4], X, seed=0)
     with pytest.raises(mmm.MmmError, match="<= 64"):
         mmm.MMCTM([16] * 5, [0.1] * 5, [4] * 5, [[np.array([[1, 3]])] * 5], seed=0)
     with pytest.raises(mmm.MmmError, match="not supported"):
-        mmm.LDA(40, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)
+        mmm.LDA(70, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)
 
 
 # ------------------------------------------------------------------------------------------ update_α! / autoα

@@ -103,3 +103,35 @@ def test_wide_batch_is_bitwise_the_single_fit(mmm, monkeypatch):
             assert np.array_equal(batch._get(f), single._get(f)), "restart %d field %s" % (r, f)
         single.close()
     monkeypatch.delenv("MMM_CTM_WIDE")
+
+
+@pytest.mark.parametrize("case", ["mm40", "mm36_20", "imm40"])
+def test_more_than_32_topics_in_a_modality(mmm, oracle, case):
+    """The reference puts no limit on K[m] (MMCTM.jl:29-91).  A modality with 33..64 topics (sum K <= 64 still: one lane per coordinate)
+    runs the wide-table data flow with the 64-topic build of the theta phase and of the posting sweep: two passes stage by stage against
+    the oracle, then ll / ELBO."""
+    D, K, V, means, feats = {"mm40": (48, [40], [96], [3000], None), "mm36_20": (40, [36, 20], [60, 30], [900, 300], None),
+                             "imm40": (40, [40], [96], [2500], SNV3)}[case]
+    X, g, o = _pair(mmm, oracle, D, K, V, seed=91, means=means, imm_features=feats)
+    assert g.geometry()["wide"] == 1 and g.geometry()["L"] == 64
+    MK, M = sum(K), len(K)
+    check = mmm._lib.check
+    for it in range(2):
+        check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        o.estep_range(0, D); o.update_mu(); o.update_Sigma(); o.update_gamma()
+        if feats is None:
+            o.update_props(); o.update_phi()
+        _cmp_docs(g, o, D, MK, M)
+        np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=1e-5)
+        np.testing.assert_allclose(g.μ, o.mu, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(g._get("theta"), o.theta, rtol=1e-5, atol=1e-12)
+    ll = np.zeros(2 * M); n = mmm._lib.C.c_int()
+    check(mmm.lib().mmm_ctm_ll_history(g._h, ll.ctypes.data, 2, mmm._lib.C.byref(n)), g.ctx.h)
+    np.testing.assert_allclose(ll.reshape(2, M)[-1], o.loglik(), rtol=1e-6)
+    assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
+
+
+def test_sum_of_topics_beyond_64_is_refused(mmm):
+    X, g0 = np_ref.synth_mm(10, [30, 30], [40, 40], seed=2, means=[100, 100])
+    with pytest.raises(mmm.MmmError):
+        mmm.MMCTM([40, 40], [0.1, 0.1], [30, 30], X, γ0=g0)

@@ -96,7 +96,7 @@ def test_stage_sequence_against_oracle(mmm, oracle):
     np.testing.assert_allclose(t, to, rtol=1e-10)
 
 
-@pytest.mark.parametrize("K", [5, 10])
+@pytest.mark.parametrize("K", [5, 10, 40])
 def test_fit_matches_oracle(mmm, oracle, K):
     X, g, o = _pair(mmm, oracle, 150, K, seed=23)
     ll_g = mmm.fit(g, maxiter=80, tol=1e-4, verbose=False)
