@@ -441,7 +441,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             geo = model.geometry()
             row_bytes = geo.get("row_bytes", 0)
             impl_bytes = (float(row_bytes) * D if row_bytes else 8.0 * nnz) + 24.0 * K * D
-            kname = ("k_lda_estep_dense<%d,%d> (rows of counts)" % (geo["KP"], geo["SL"])) if geo["dense"] else \
+            kname = ("k_lda_estep_dense%s<%d,%d> (rows of counts)" % ("32" if geo["dense"] == 2 else "", geo["KP"], geo["SL"] // (2 if geo["dense"] == 2 else 1))) if geo["dense"] else \
                     ("k_lda_estep<%d,%d,..,%s>" % (geo["KP"], geo["L"], "single step" if geo["single_step"] else "grid stride"))
             achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             achieved_impl = impl_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -486,15 +486,24 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             res["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch_gfx950_corrected"] / algo_bytes
             res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + tfile
             cnt = tr.get("counters_per_launch", {})
-            if cfg["model"] == "lda" and cnt.get("SQ_INSTS_VALU") and avg_s > 0:
-                # the ceiling that binds a cache-resident 11-MB working set: vector instruction issue.  A wave's VALU instruction occupies its
-                # SIMD for 4 cycles (64 lanes over 16-lane f64 pipes: f64 FMA / DPP moves take longer, so this is a lower bound of the busy time)
+            if cnt.get("SQ_INSTS_VALU") and avg_s > 0:
+                # the ceiling that binds these kernels (a cache-resident working set in LDA, a compute-heavy solve in the CTMs): vector
+                # instruction ISSUE.  A wave's VALU instruction holds its SIMD for 4 cycles, a v_rcp / v_rsq / v_sqrt_f64 for 16 (measured:
+                # profiles/experiments/r03_f64_rates.txt); SQ_ACTIVE_INST_VALU counts exactly those 4-cycle units.  The floor is that time
+                # spread evenly over every SIMD at the nominal clock (under a chip-wide f64 load the clock itself drops to ~2.1 GHz,
+                # profiles/experiments/r03_f64_clock.txt, so the true floor is ~12 % higher).
                 inst = float(cnt["SQ_INSTS_VALU"])
-                floor_us = inst * 4.0 / N_SIMD / SCLK_HZ * 1e6
-                res["roofline"]["f64_valu"] = {"valu_wave_instructions_per_launch": inst, "issue_floor_us": floor_us, "frac": floor_us / avg_us,
-                                               "unit": "fraction of the kernel's duration that the vector pipes need at 4 cycles per wave instruction, "
-                                                       "evenly spread over %d SIMDs at %.1f GHz" % (N_SIMD, SCLK_HZ / 1e9),
-                                               "source": "SQ_INSTS_VALU of profiles/" + tfile}
+                quads = float(cnt.get("SQ_ACTIVE_INST_VALU") or inst)
+                floor_us = quads * 4.0 / N_SIMD / SCLK_HZ * 1e6
+                blk = {"valu_wave_instructions_per_launch": inst, "valu_issue_quad_cycles_per_launch": quads, "issue_floor_us": floor_us,
+                       "frac": floor_us / avg_us,
+                       "unit": "fraction of the kernel's duration that the vector pipes need (4 cycles per wave instruction, 16 per f64 rcp / rsq / sqrt), "
+                               "evenly spread over %d SIMDs at %.1f GHz" % (N_SIMD, SCLK_HZ / 1e9),
+                       "source": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU of profiles/" + tfile}
+                if cfg["model"] == "lda":
+                    res["roofline"]["f64_valu"] = blk
+                else:
+                    res["roofline"]["f64_valu"]["issue"] = blk
         if world == 1:
             if cfg["model"] == "lda":
                 res.update(parity_probe_lda(pkg, K, 0.1, 0.1, V, seed + 7))

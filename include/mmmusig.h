@@ -154,7 +154,7 @@ int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n);
 /* Which E-step build the handle uses and its launch geometry (diagnostics, tests): out[0] = lanes per document, [1] = blocks,
  * [2] = waves per block, [3] = 1 for the single-step build (small corpora: the grid covers every document at once), [4] = 1 for
  * the wide-table path (tables beyond LDS), [5] = 1 for the dense-row build (dense corpus over <= 128 terms: rows of counts,
- * statistics accumulated in registers), [6] = its term slots per lane, [7] = topics padded to. */
+ * statistics accumulated in registers; 2: its 32-lane variant), [6] = its term slots per lane, [7] = topics padded to. */
 int mmm_lda_geometry(const mmm_lda* m, int out[8]);
 /* Bytes of corpus the E-step build reads per document when the handle keeps rows (rows of 16- or 32-bit counts: 2 or 4 bytes x 16 x
  * slots per lane; padded (term,count) rows: 8 x V); 0 when it sweeps the CSR arrays (8 bytes per nonzero + offsets).  bench.py's

@@ -2949,7 +2949,7 @@ int mmm_lda_geometry(const mmm_lda* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
     out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->single_step ? 1 : 0; out[4] = m->wide ? 1 : 0;
-    out[5] = m->dense ? 1 : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
+    out[5] = m->dense ? (m->dense32 ? 2 : 1) : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
     return MMM_OK;
 }
 

@@ -210,7 +210,9 @@ def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_
     monkeypatch.setenv("MMM_LDA_DENSE32", lanes32)
     X, g, o = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
     geo = g.geometry()
-    assert geo["dense"] == 1 and geo["SL"] * 16 >= V and geo["single_step"] == 0
+    assert geo["dense"] in (1, 2) and geo["SL"] * 16 >= V and geo["single_step"] == 0
+    if lanes32 == "1" and (D, V, K) == (500, 96, 10):
+        assert geo["dense"] == 2
     ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=12, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
