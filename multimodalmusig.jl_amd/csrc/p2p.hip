@@ -136,7 +136,11 @@ static int p2p_selftest(mmm_ctx* ctx, bool* ok)
     MMM_HIP(ctx, buf.alloc(kP2PCap));
     std::vector<double> h(kP2PCap);
     bool good = true;
+    // the first call may wait for a peer that is still attaching (full time limit); once every rank has answered one call, a healthy
+    // exchange takes microseconds -- the later calls get 2 s, so that a node where the mailboxes do not work falls back to RCCL quickly
+    const unsigned long long full_ticks = ctx->p2p->args.timeout_ticks;
     for (int it = 0; it < rounds && good; ++it) {
+        if (it == 1) ctx->p2p->args.timeout_ticks = std::min<unsigned long long>(full_ticks, 200000000ull);
         const int count = sizes[it % 8];
         for (int e = 0; e < count; ++e) h[e] = (double)((me + 1) * (e % 7 + 1) + it);
         MMM_HIP(ctx, hipMemcpyAsync(buf.p, h.data(), sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
@@ -149,6 +153,7 @@ static int p2p_selftest(mmm_ctx* ctx, bool* ok)
             if (h[e] != want) { good = false; break; }
         }
     }
+    ctx->p2p->args.timeout_ticks = full_ticks;
     int herr = 0;
     MMM_HIP(ctx, hipMemcpy(&herr, ctx->p2p->err, sizeof herr, hipMemcpyDeviceToHost));
     if (herr) { good = false; MMM_HIP(ctx, hipMemset(ctx->p2p->err, 0, sizeof(int))); }
