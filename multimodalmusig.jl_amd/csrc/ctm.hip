@@ -952,6 +952,8 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     }
 }
 
+#include "ctm_big.cuh"
+
 // objective values / gradients of one document at its stored (lambda, nu), in the reference's MAXIMISATION form
 // (common.jl:11-36), evaluated by the same device functors the solvers use.  One wave.
 __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const double* invSigma, const double* mu, const double* lam,
@@ -1145,6 +1147,7 @@ struct MstepArgs {
     int do_mu, do_sigma, do_gamma, gamma_from_stats;
     size_t stats_stride; int GM; const int* active;      // batched launches
     int nalpha;
+    double* big_scratch;    // sum K > 64: [R][2 MK^2] doubles in device memory for the inversion (block_inverse_big); else NULL
 };
 
 // the per-replica pointers of a batched M-step launch.  They are formed in locals (registers); the argument struct itself
@@ -1243,7 +1246,8 @@ __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* 
     __syncthreads();
     // update_Σ! (MMCTM.jl:204-212) from raw moments: (diag Σν + Σ (λ-μ)(λ-μ)') / D with the NEW μ
     if (a.do_sigma) {
-        double* A = smem; double* Ai = smem + MK * MK;
+        double* A = a.big_scratch ? a.big_scratch + (size_t)blockIdx.y * 2 * MK * MK : smem;
+        double* Ai = A + MK * MK;
         for (int e = tid; e < MK * MK; e += nt) {
             const int i = e % MK, j = e / MK;
             // Σ_d (λ_i-μ_i)(λ_j-μ_j) = Σλλ' - μ_i Σλ_j - μ_j Σλ_i + D μ_i μ_j
@@ -1254,7 +1258,9 @@ __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* 
             q.Sigma[e] = v; A[i * MK + j] = v;
         }
         __syncthreads();
-        block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+        if (a.big_scratch) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
+        else block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+        __syncthreads();
         for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; q.invSigma[e] = Ai[i * MK + j]; }
         if (tid == 0 && s_sing) *q.status = 1;
         __syncthreads();
@@ -1657,15 +1663,18 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_elbo_docs(CtmDev c, const doubl
 }
 
 // topic-side ELBO pieces (MMCTM.jl:271-284,338-350; IMMCTM.jl:247-262,316-330) and logdet(invSigma): out = {ElnPphi, ElnQphi, logdet}
-__global__ __launch_bounds__(256) void k_ctm_elbo_topics(CtmDims dm, CtmTopics tp, const double* gamma, const double* Elnphi, const double* invSigma, double* out)
+__global__ __launch_bounds__(256) void k_ctm_elbo_topics(CtmDims dm, CtmTopics tp, const double* gamma, const double* Elnphi, const double* invSigma, double* out,
+                                                         double* big_scratch)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv; __shared__ double sh[4];
     const int MK = dm.MK, M = dm.M, tid = threadIdx.x, nt = blockDim.x;
-    double* A = smem; double* Ai = smem + MK * MK;
+    double* A = big_scratch ? big_scratch : smem; double* Ai = A + MK * MK;
     for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; A[i * MK + j] = invSigma[e]; }
     __syncthreads();
-    block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+    if (big_scratch) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
+    else block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+    __syncthreads();
     // one (m,k[,i]) Dirichlet per loop trip, handled by the whole block
     double P = 0.0, Q = 0.0;
     for (int m = 0; m < M; ++m) {
@@ -1758,6 +1767,8 @@ struct mmm_ctm {
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
     DevBuf<int> nev_nu, nev_lam, status, active, npass;
     DevBuf<int> claim;             // [2][R][32]: document counters of the split nu / lambda launches
+    bool big = false;              // 64 < sum K <= 256: the generic kernels of ctm_big.cuh (one wave per document, several coordinates per lane)
+    DevBuf<double> big_scratch;    // [R][2 MK^2]: Sigma and its inverse during the Gaussian M-step / the ELBO's logdet
     int stop_enable = 0; double stop_tol = 0.0;     // set by fit_scope around a pass: the ll kernels apply the stopping rule
     int* pin_flags = nullptr;                       // pinned [2][2R]: snapshots of (active | status) the host reads one pass late
     std::vector<int> h_active, n_hist;        // per replica
@@ -1850,6 +1861,20 @@ int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
 template <int PH>
 int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
+    if (m->big) {      // sum K > 64: the generic kernels (ctm_big.cuh), one wave per document
+        mmm_ctx* ctx = m->ctx;
+        const int nblk = std::max(1, std::min((m->dm.D + 3) / 4, ctx->num_cu * 4));
+        if constexpr (PH == 0) {
+            const size_t l = sizeof(double) * 4 * (64 + 64 * 64);
+            MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_theta_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+            hipLaunchKernelGGL(k_ctm_theta_big, dim3(nblk, nrep), dim3(256), l, ctx->stream, a);
+        } else {
+            const size_t l = sizeof(double) * 4 * (size_t)m->dm.MK;
+            hipLaunchKernelGGL(k_ctm_solve_big, dim3(nblk, nrep), dim3(256), l, ctx->stream, a);
+        }
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
         const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
         if (m->persist) {          // persistent waves with refilled document slots (several coordinates per lane, or one)
@@ -1975,7 +2000,8 @@ MstepArgs mstep_args(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma
     const size_t r0 = sc.rep0, MK = m->dm.MK, GT = m->dm.GT, GM = m->GM;
     MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
                 m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
-                m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha};
+                m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha,
+                m->big ? m->big_scratch.p + r0 * 2 * MK * MK : nullptr};
     a.tp.alpha += r0 * m->nalpha;      // host-side copy of the argument struct: fine
     return a;
 }
@@ -1985,7 +2011,7 @@ int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int g
     mmm_ctx* ctx = m->ctx;
     const size_t MK = m->dm.MK;
     const MstepArgs a = mstep_args(m, sc, do_mu, do_sigma, do_gamma, gamma_from_stats);
-    const size_t lds = sizeof(double) * 2 * MK * MK;
+    const size_t lds = m->big ? 0 : sizeof(double) * 2 * MK * MK;
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_ctm_mstep, dim3(1, sc.nrep), dim3(256), lds, ctx->stream, a);
@@ -2056,12 +2082,18 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
     const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64 + 1 + MMM_LOGTAB_N,      // table | props | log table
                                                  gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
-    auto kll = m->wide ? (m->L == 16 ? k_ctm_loglik<false, 16> : (m->L == 32 ? k_ctm_loglik<false, 32> : k_ctm_loglik<false, 64>))
-                       : (m->L == 16 ? k_ctm_loglik<true, 16> : (m->L == 32 ? k_ctm_loglik<true, 32> : k_ctm_loglik<true, 64>));
-    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kll, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
-                       m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
-                       mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
+    if (m->big) {      // sum K > 64: the Gaussian M-step as its own launch (device-memory inversion), then the generic props / ll sweep
+        if (gauss) { int rc = run_mstep(m, sc, gauss_mu, gauss_sigma, 0, 0); if (rc) return rc; }
+        hipLaunchKernelGGL(k_ctm_loglik_big, dim3(m->grid_s, sc.nrep), dim3(kBlockS), sizeof(double) * kWavesS * 64, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
+                           m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active);
+    } else {
+        auto kll = m->wide ? (m->L == 16 ? k_ctm_loglik<false, 16> : (m->L == 32 ? k_ctm_loglik<false, 32> : k_ctm_loglik<false, 64>))
+                           : (m->L == 16 ? k_ctm_loglik<true, 16> : (m->L == 32 ? k_ctm_loglik<true, 32> : k_ctm_loglik<true, 64>));
+        if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kll, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), lds, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
+                           m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
+                           mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss);
+    }
     MMM_LAUNCH_CHECK(ctx);
     if (!compute_ll) return MMM_OK;
     // inside a fit (fit_scope sets stop_enable / sc.active): the stopping rule and the pass counter ride on the row's last kernel
@@ -2157,6 +2189,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     const size_t r0 = sc.rep0;
     ProfSpan* mid_span = new ProfSpan(ctx, 2);      // mmm_ctx_profile_select(2): moments, reduction, all-reduce, topic M-step
     struct SpanGuard { ProfSpan*& p; ~SpanGuard() { delete p; } } mid_guard{mid_span};
+    if (sizeof(double) * 64 * dm.MK > 48 * 1024) MMM_HIP(m->ctx, hipFuncSetAttribute((const void*)k_ctm_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * dm.MK)));
     hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                        m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
     MMM_LAUNCH_CHECK(ctx);
@@ -2217,6 +2250,7 @@ int frozen_pass(mmm_ctm* m, Scope sc, int flags)
     if (rc) return rc;
     if (flags & MMM_INFER_FIT_GAUSSIAN) {
         const size_t r0 = sc.rep0;
+        if (sizeof(double) * 64 * dm.MK > 48 * 1024) MMM_HIP(m->ctx, hipFuncSetAttribute((const void*)k_ctm_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * dm.MK)));
         hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, sc.nrep), dim3(256), sizeof(double) * 64 * dm.MK, ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                            m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, sc.active);
         MMM_LAUNCH_CHECK(ctx);
@@ -2270,8 +2304,9 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         toff += m->nnzm[i] * K[i];
     }
     dm.MK = dm.koff[M]; dm.GT = dm.goff[M];
-    if (dm.MK > 64) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: sum(K)=%d must be <= 64", dm.MK); delete m; return rc; }
+    if (dm.MK > 64 * kBigSlots) { int rc = mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_create: sum(K)=%d must be <= %d", dm.MK, 64 * kBigSlots); delete m; return rc; }
     m->L = dm.MK <= 16 ? 16 : (dm.MK <= 32 ? 32 : 64);
+    m->big = dm.MK > 64;      // more coordinates than lanes: the generic kernels of ctm_big.cuh (and the wide-table data flow)
     const int64_t nnz = doc_ptr[(size_t)(M - 1) * (D + 1) + D];
     m->nnz = nnz; m->theta_n = toff;
     // validate + pack the corpus
@@ -2336,7 +2371,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     // forces it for any shape (tests, A/B)
     int kmax_all = 0;
     for (int i = 0; i < dm.M; ++i) kmax_all = std::max(kmax_all, dm.K[i]);
-    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr || kmax_all > 32) { m->wide = true; m->waves_e = 8; }
+    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr || kmax_all > 32 || m->big) { m->wide = true; m->waves_e = 8; }
     const int dpb = m->waves_e * G;
     const int per_cu = m->wide ? 2 : std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
@@ -2363,8 +2398,8 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
             else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
-            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }
-            else if (cmode == 4 && dm.MK == 14) { m->Ls = 8; m->cpl = 2; m->lam_occ = 4; }                // 7 of 8 lanes x 2 coordinates         // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
+            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
+            else if (cmode == 4 && dm.MK == 14) { m->Ls = 8; m->cpl = 2; m->lam_occ = 4; }                // 7 of 8 lanes x 2 coordinates
             if (m->cpl > 1) m->persist = true;
         }
         // MMM_CTM_SPLIT="nuLanes:nuWaves:lamLanes:lamWaves" (sum K = 28): the two solves as two launches with their own layouts
@@ -2376,6 +2411,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             }
         }
     }
+    if (m->big) { m->Ls = 64; m->cpl = kBigSlots; m->persist = false; m->split = false; }      // ctm_big.cuh: lane l holds coordinates l + 64 q
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
     // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
@@ -2402,6 +2438,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     A(partial, m->wide ? 1 : Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
     A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
     A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz); A(claim, 2 * Rz * 32);
+    A(big_scratch, m->big ? Rz * 2 * (size_t)dm.MK * dm.MK : 1);
 #undef A
     hipStream_t st = ctx->stream;
     MMM_HIP(ctx, hipMemcpyAsync(m->doc_ptr.p, doc_ptr, sizeof(int64_t) * M * (D + 1), hipMemcpyHostToDevice, st));
@@ -2637,6 +2674,7 @@ static int moments_to_stats(mmm_ctm* m)
     const CtmDims& dm = m->dm;
     const Scope sc = one(m);
     const size_t r0 = sc.rep0;
+    if (sizeof(double) * 64 * dm.MK > 48 * 1024) MMM_HIP(m->ctx, hipFuncSetAttribute((const void*)k_ctm_moments, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * dm.MK)));
     hipLaunchKernelGGL(k_ctm_moments, dim3(m->grid_m, 1), dim3(256), sizeof(double) * 64 * dm.MK, m->ctx->stream, dm.D, dm.MK, m->lambda.p + r0 * m->sDMK(),
                        m->nu.p + r0 * m->sDMK(), m->mompart.p + r0 * m->grid_m * m->nmom, (const int*)nullptr);
     MMM_LAUNCH_CHECK(m->ctx);
@@ -2730,6 +2768,7 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
     int rc = prep(m);
     if (rc || (rc = materialise_theta(m))) return rc;
     MMM_CHECK(ctx, d >= 0 && d < m->dm.D, "mmm_ctm_objectives: document %d out of range", d);
+    if (m->big) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_ctm_objectives: not available for sum K > 64 (diagnostic entry point)");
     const size_t MK = m->dm.MK, r = m->sel;
     DevBuf<double> tmp;
     MMM_HIP(ctx, tmp.alloc(2 + 2 * MK));
@@ -2848,17 +2887,22 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     const size_t MKz = dm.MK, r = m->sel;
     const size_t lds = sizeof(double) * (MKz * MKz + (m->wide ? 0 : dm.GT) + kWavesS * 64);
     auto kel = m->wide ? k_ctm_elbo_docs<false> : k_ctm_elbo_docs<true>;
-    if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024 && !m->big) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double* acc = m->elbopart.p + (size_t)m->grid_s * 5;     // [0..4] doc sums, [5..7] topic side
+    if (m->big)
+        hipLaunchKernelGGL(k_ctm_elbo_docs_big, dim3(m->grid_s), dim3(kBlockS), sizeof(double) * kWavesS * MKz, ctx->stream, m->dev(), m->invSigma.p + r * MKz * MKz,
+                           m->mu.p + r * MKz, m->lambda.p + r * m->sDMK(), m->nu.p + r * m->sDMK(), m->zeta.p + r * dm.D * dm.M, m->theta.p, m->Eeff.p + r * dm.GT,
+                           m->elbopart.p);
+    else
     hipLaunchKernelGGL(kel, dim3(m->grid_s), dim3(kBlockS), lds, ctx->stream, m->dev(), m->invSigma.p + r * MKz * MKz, m->mu.p + r * MKz,
                        m->lambda.p + r * m->sDMK(), m->nu.p + r * m->sDMK(), m->zeta.p + r * dm.D * dm.M, m->theta.p, m->Eeff.p + r * dm.GT, m->elbopart.p);
     hipLaunchKernelGGL(k_sum_columns, dim3(5, 1), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc, (size_t)0, (const int*)nullptr);
-    const size_t lds2 = sizeof(double) * 2 * MKz * MKz;
+    const size_t lds2 = m->big ? 0 : sizeof(double) * 2 * MKz * MKz;
     if (lds2 > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_elbo_topics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     CtmTopics tpr = m->tp;
     tpr.alpha += r * m->nalpha;
     hipLaunchKernelGGL(k_ctm_elbo_topics, dim3(1), dim3(256), lds2, ctx->stream, dm, tpr, m->gamma.p + r * m->GM, m->Elnphi.p + r * m->GM,
-                       m->invSigma.p + r * MKz * MKz, acc + 5);
+                       m->invSigma.p + r * MKz * MKz, acc + 5, m->big ? m->big_scratch.p + r * 2 * MKz * MKz : (double*)nullptr);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
     double h[8];

@@ -96,8 +96,10 @@ def test_transform_reference_test(mmm, kats):                 # test/mmctm.jl:39
     assert np.any(new.Σ != model.Σ)
 
 
-def _ctm_trained(mmm, oracle, feats=None, seed=21):
-    if feats is None:
+def _ctm_trained(mmm, oracle, feats=None, seed=21, shape=None):
+    if shape is not None:
+        K, V, means = shape
+    elif feats is None:
         K, V, means = [5, 4], [40, 24], [600, 80]
     else:
         K, V, means = [6], [96], [1200]
@@ -281,3 +283,20 @@ def test_predict_modality_eta(mmm, oracle, case):
     eta_o = np.stack([μ[un] + A @ (lam_o[d] - μ[ob]) for d in range(len(Xobs))])
     err = np.abs(np.stack(eta) - eta_o) / np.maximum(1.0, np.abs(eta_o))
     assert np.median(err) < 1e-3 and err.max() < 5e-2
+
+
+def test_fit_heldout_with_more_than_64_coordinates(mmm, oracle):
+    """Frozen-topic inference through the generic kernels of csrc/ctm_big.cuh (sum K = 80): the first pass of fit_heldout from the trained
+    globals against the index-order oracle -- zeta / theta exactly (they precede the solves), ll at the solver's x-tolerance level."""
+    g, o, Xn, K, V, alpha = _ctm_trained(mmm, oracle, shape=([40, 40], [96, 48], [2500, 400]))
+    assert g.geometry()["cpl"] == 4
+    gn = mmm.fit_heldout(Xn, g, maxiter=1)
+    on = _fresh_oracle(oracle, o, Xn, K, V, alpha)
+    on.mu[:] = o.mu; on.Sigma[:] = o.Sigma; on.invSigma[:] = o.invSigma; on.gamma[:] = o.gamma; on.Elnphi[:] = o.Elnphi; on.phi[:] = o.phi
+    ll_o = on.infer(0, 1, 1e-4)
+    assert gn.ll_history.shape == ll_o.shape
+    np.testing.assert_allclose(gn.ll_history, ll_o, rtol=1e-5)
+    D, M = on.D, on.M
+    np.testing.assert_allclose(gn._get("zeta").reshape(D, M), on.zeta.reshape(D, M), rtol=1e-9)
+    np.testing.assert_allclose(gn._get("theta"), on.theta, rtol=1e-9, atol=1e-300)
+    gn.close()
