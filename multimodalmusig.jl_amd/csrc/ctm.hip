@@ -29,7 +29,8 @@
 namespace {
 
 constexpr int kMaxM = 8;
-constexpr int kKmax = 64;          // topics per modality (the theta loop is unrolled to 8 / 10 / 16 / 32; 33..64: the 64-topic build of the wide-table path)
+constexpr int kKmax = 64;          // topics per modality (the theta loop is unrolled to 8 / 10 / 16 / 32; 33..64: the 64-topic build of the wide-table path;
+                                   // sum K > 64: ctm_big.cuh)
 constexpr int kWavesS = 4;         // stage / auxiliary kernels
 constexpr int kBlockS = kWavesS * MMM_WAVE;
 

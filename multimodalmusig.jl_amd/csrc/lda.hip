@@ -1603,12 +1603,15 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_wide(EstepArgs a, double* 
     }
 }
 
-// ---- more than 32 topics (round 3): the two sweeps of the wide path with the topic loops ROLLED -- runtime K <= 64, KP = K rounded up to
+// ---- more than 32 topics (round 3): the two sweeps of the wide path with the topic loops ROLLED -- runtime K <= 256, KP = K rounded up to
 // even -- so that no build per K is needed and nothing goes to scratch: a_k / theta_k of the wave's document sit in LDS (broadcast reads),
 // and the sums over a document's nonzeros (gamma_{t+1,k}) resp. over a term's postings (the lambda statistics) are kept as one LDS column
-// per lane and topic and added up across the lanes at the end.  The reference has no limit on K (LDA.jl:24-54); beyond 64 the per-document
-// kernels' "one topic per lane" prologues would have to be strided as well -- not built.
+// per lane and topic and added up across the lanes at the end.  Where a document's topics are spread over the lanes (the Elntheta
+// prologue, the final sums) lane l holds topics l, l + 64, l + 128, l + 192 (kLdaSlots).  The reference has no limit on K (LDA.jl:24-54);
+// here it is the LDS column block: 512 K bytes per wave, one wave per block from K = 129.
 // LDS per wave: [KP][64] column sums | [KP] a_k | [KP] theta_k.
+constexpr int kLdaSlots = 4;
+
 __global__ __launch_bounds__(kBlock) void k_lda_estep_big(EstepArgs a, double* __restrict__ aexp, const double* __restrict__ eBT,
                                                           const double* __restrict__ betaT, int KP)
 {
@@ -1621,27 +1624,34 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_big(EstepArgs a, double* _
     double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
     double* __restrict__ Eln = a.Elntheta.s[t % 3];
     const int K = a.c.K, D = a.c.D;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, NW = blockDim.x >> 6;
     double* wacc = smem + (size_t)wid * ((size_t)KP * MMM_WAVE + 2 * KP);
     double* wav = wacc + (size_t)KP * MMM_WAVE;
     double* wtv = wav + KP;
     double wave_ll = 0.0;
-    for (int d = blockIdx.x * kWavesPerBlock + wid; d < D; d += gridDim.x * kWavesPerBlock) {
-        const double gk = (lane < K) ? gam[(size_t)d * K + lane] : 0.0;
-        const double S = wave_sum(gk);
-        const double ps = dev_digamma_pos(lane < K ? gk : S);          // lanes >= K hold psi(S); with K = 64 no lane does
-        const double psS = (K < MMM_WAVE) ? wave_bcast(ps, K) : dev_digamma_pos(S);
-        const double el = ps - psS;
-        const double ak = (lane < K) ? exp(el) : 0.0;
-        if (lane < K) Eln[(size_t)d * K + lane] = el;
-        if (lane < KP) aexp[(size_t)d * KP + lane] = ak;      // D x KP rows, zero-padded
-        double th = 0.0;
-        if (a.do_ll) {
-            const double gp = (lane < K) ? gprev[(size_t)d * K + lane] : 0.0;
-            th = gp / wave_sum(gp);
+    for (int d = blockIdx.x * NW + wid; d < D; d += gridDim.x * NW) {
+        double gk[kLdaSlots], gp[kLdaSlots], gsum = 0.0, psum = 0.0;
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {
+            const int k = lane + 64 * s;
+            gk[s] = (k < K) ? gam[(size_t)d * K + k] : 0.0;
+            gp[s] = (a.do_ll && k < K) ? gprev[(size_t)d * K + k] : 0.0;
+            gsum += gk[s]; psum += gp[s];
         }
+        const double psS = dev_digamma_pos(wave_sum(gsum));             // Elntheta (LDA.jl:78-80)
+        const double Sp = a.do_ll ? wave_sum(psum) : 1.0;
         lds_wave_sync();
-        if (lane < KP) { wav[lane] = ak; wtv[lane] = th; }
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {
+            const int k = lane + 64 * s;
+            if (k < KP) {
+                const double el = (k < K) ? dev_digamma_pos(gk[s]) - psS : 0.0;
+                const double ak = (k < K) ? exp(el) : 0.0;
+                if (k < K) Eln[(size_t)d * K + k] = el;
+                aexp[(size_t)d * KP + k] = ak;      // D x KP rows, zero-padded
+                wav[k] = ak; wtv[k] = gp[s] / Sp;
+            }
+        }
         for (int k = 0; k < KP; ++k) wacc[(size_t)k * MMM_WAVE + lane] = 0.0;
         lds_wave_sync();
         const int64_t start = a.c.doc_ptr[d];
@@ -1671,25 +1681,30 @@ __global__ __launch_bounds__(kBlock) void k_lda_estep_big(EstepArgs a, double* _
             }
         }
         lds_wave_sync();
-        if (lane < K) {       // lane k adds its topic's 64 column sums, starting at column k (rotated: the lanes stay on different LDS banks)
-            const double* row = wacc + (size_t)lane * MMM_WAVE;
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-            for (int j = 0; j < MMM_WAVE; j += 4) {
-                r0 += row[(j + lane) & 63]; r1 += row[(j + 1 + lane) & 63]; r2 += row[(j + 2 + lane) & 63]; r3 += row[(j + 3 + lane) & 63];
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {       // lane l adds the 64 column sums of its topics, starting at column l (rotated: the lanes stay on different LDS banks)
+            const int k = lane + 64 * s;
+            if (k < K) {
+                const double* row = wacc + (size_t)k * MMM_WAVE;
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+                for (int j = 0; j < MMM_WAVE; j += 4) {
+                    r0 += row[(j + lane) & 63]; r1 += row[(j + 1 + lane) & 63]; r2 += row[(j + 2 + lane) & 63]; r3 += row[(j + 3 + lane) & 63];
+                }
+                gnext[(size_t)d * K + k] = a.c.alpha + ((r0 + r1) + (r2 + r3));
             }
-            gnext[(size_t)d * K + lane] = a.c.alpha + ((r0 + r1) + (r2 + r3));
         }
         if (a.do_ll) wave_ll += wave_sum(ll);
     }
     if (a.do_ll) {
         if (lane == 0) shw[wid] = wave_ll;
         __syncthreads();
-        if (threadIdx.x == 0) a.llpart[blockIdx.x] = shw[0] + shw[1] + shw[2] + shw[3];
+        if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < NW; ++w) s += shw[w]; a.llpart[blockIdx.x] = s; }
     }
 }
 
-// the term-major sweep (k_lda_stats_terms) with rolled topic loops: block v < V = term v, at most 4 waves, each over a contiguous segment of
-// the term's postings; LDS: [waves][KP][64] column sums | [KP] the term's table column | [waves][KP] segment sums.  Block V: the ll partials.
+// the term-major sweep (k_lda_stats_terms) with rolled topic loops: block v < V = term v, at most 4 waves (one from K = 129), each over a
+// contiguous segment of the term's postings; LDS: [waves][KP][64] column sums | [KP] the term's table column | [waves][KP] segment sums.
+// Block V: the ll partials.
 __global__ __launch_bounds__(256) void k_lda_stats_big(int V, int K, int KP, const int64_t* __restrict__ term_ptr, const int2* __restrict__ tpost,
                                                        const double* __restrict__ aexp, const double* __restrict__ eB, ReduceArgs r)
 {
@@ -1729,19 +1744,129 @@ __global__ __launch_bounds__(256) void k_lda_stats_big(int V, int K, int KP, con
         }
     }
     lds_wave_sync();
-    if (lane < KP) {
-        const double* row = wacc + (size_t)lane * MMM_WAVE;
+    for (int k = lane; k < KP; k += MMM_WAVE) {
+        const double* row = wacc + (size_t)k * MMM_WAVE;
         double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
         for (int j = 0; j < MMM_WAVE; j += 4) {
             r0 += row[(j + lane) & 63]; r1 += row[(j + 1 + lane) & 63]; r2 += row[(j + 2 + lane) & 63]; r3 += row[(j + 3 + lane) & 63];
         }
-        sh[(size_t)wid * KP + lane] = (r0 + r1) + (r2 + r3);
+        sh[(size_t)wid * KP + k] = (r0 + r1) + (r2 + r3);
     }
     __syncthreads();
-    if ((int)threadIdx.x < K) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
         double tot = 0.0;
-        for (int w = 0; w < nw; ++w) tot += sh[(size_t)w * KP + threadIdx.x];
-        r.stats[(size_t)threadIdx.x * V + v] = tot;
+        for (int w = 0; w < nw; ++w) tot += sh[(size_t)w * KP + k];
+        r.stats[(size_t)k * V + v] = tot;
+    }
+}
+
+// ---- more than 64 topics: the per-document kernels that give every topic a lane, with lane l holding topics l + 64 s -------------------
+// gamma[:,d] = alpha + phi[d] * n_d (LDA.jl:83-87) from a resident phi, then Elntheta (if asked)
+__global__ __launch_bounds__(kBlock) void k_lda_gamma_from_phi_big(LdaDev c, const double* phi, double* gamma, double* Elntheta)
+{
+    const int K = c.K;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        const int64_t start = c.doc_ptr[d];
+        const int W = (int)(c.doc_ptr[d + 1] - start);
+        double mine[kLdaSlots] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < K; ++k) {
+            double acc = 0.0;
+            for (int w = lane; w < W; w += MMM_WAVE) acc += phi[(size_t)(start + w) * K + k] * (double)c.tc[start + w].y;
+            acc = wave_sum(acc);
+#pragma unroll
+            for (int s = 0; s < kLdaSlots; ++s) if (k == lane + 64 * s) mine[s] = acc;
+        }
+        double g[kLdaSlots], gs = 0.0;
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {
+            const int k = lane + 64 * s;
+            g[s] = (k < K) ? c.alpha + mine[s] : 0.0;
+            if (k < K) gamma[(size_t)d * K + k] = g[s];
+            gs += g[s];
+        }
+        if (Elntheta) {
+            const double psS = dev_digamma(wave_sum(gs));
+#pragma unroll
+            for (int s = 0; s < kLdaSlots; ++s) { const int k = lane + 64 * s; if (k < K) Elntheta[(size_t)d * K + k] = dev_digamma(g[s]) - psS; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lda_Elntheta_big(LdaDev c, const double* gamma, double* Elntheta)
+{
+    const int K = c.K;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        double g[kLdaSlots], gs = 0.0;
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) { const int k = lane + 64 * s; g[s] = (k < K) ? gamma[(size_t)d * K + k] : 0.0; gs += g[s]; }
+        const double psS = dev_digamma(wave_sum(gs));
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) { const int k = lane + 64 * s; if (k < K) Elntheta[(size_t)d * K + k] = dev_digamma(g[s]) - psS; }
+    }
+}
+
+// phi (LDA.jl:69-76) with a_k in LDS and rolled topic loops; dynamic LDS: [waves][K]
+__global__ __launch_bounds__(kBlock) void k_lda_phi_big(LdaDev c, const double* Elntheta, const double* expElnbeta, double* phi)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int K = c.K, V = c.V;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double* wav = smem + (size_t)wid * K;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        lds_wave_sync();
+        for (int k = lane; k < K; k += MMM_WAVE) wav[k] = exp(Elntheta[(size_t)d * K + k]);
+        lds_wave_sync();
+        const int64_t start = c.doc_ptr[d];
+        const int W = (int)(c.doc_ptr[d + 1] - start);
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int v = c.tc[start + w].x;
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += wav[k] * expElnbeta[(size_t)k * V + v];
+            double* ph = phi + (size_t)(start + w) * K;
+            for (int k = 0; k < K; ++k) ph[k] = wav[k] * expElnbeta[(size_t)k * V + v] / s;
+        }
+    }
+}
+
+// theta = gamma / sum gamma (LDA.jl:92-94) and the log-likelihood numerator (LDA.jl:174-188); dynamic LDS: [waves][K]
+__global__ __launch_bounds__(kBlock) void k_lda_loglik_big(LdaDev c, const double* gamma, const double* beta, double* theta, double* llpart, int compute_ll)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double shw[kWavesPerBlock];
+    const int K = c.K, V = c.V;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double* wth = smem + (size_t)wid * K;
+    double wave_ll = 0.0;
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        double g[kLdaSlots], gs = 0.0;
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) { const int k = lane + 64 * s; g[s] = (k < K) ? gamma[(size_t)d * K + k] : 0.0; gs += g[s]; }
+        const double S = wave_sum(gs);
+        lds_wave_sync();
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {
+            const int k = lane + 64 * s;
+            if (k < K) { const double th = g[s] / S; wth[k] = th; if (theta) theta[(size_t)d * K + k] = th; }
+        }
+        lds_wave_sync();
+        if (!compute_ll) continue;
+        const int64_t start = c.doc_ptr[d];
+        const int W = (int)(c.doc_ptr[d + 1] - start);
+        double acc = 0.0;
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int2 t = c.tc[start + w];
+            double p = 0.0;
+            for (int k = 0; k < K; ++k) p = fma(wth[k], beta[(size_t)k * V + t.x], p);
+            acc += (double)t.y * log(p);
+        }
+        wave_ll += wave_sum(acc);
+    }
+    if (compute_ll) {
+        if (lane == 0) shw[wid] = wave_ll;
+        __syncthreads();
+        if (tid == 0) llpart[blockIdx.x] = shw[0] + shw[1] + shw[2] + shw[3];
     }
 }
 
@@ -1898,6 +2023,51 @@ __global__ __launch_bounds__(kBlock) void k_lda_elbo_docs(LdaDev c, const double
     }
 }
 
+// the same for more than 64 topics: lane l holds topics l + 64 s
+__global__ __launch_bounds__(kBlock) void k_lda_elbo_docs_big(LdaDev c, const double* phi, const double* gamma, const double* Elntheta,
+                                                              const double* Elnbeta, double* out)
+{
+    __shared__ double shw[kWavesPerBlock][5];
+    const int K = c.K, V = c.V;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int d = blockIdx.x * kWavesPerBlock + wid; d < c.D; d += gridDim.x * kWavesPerBlock) {
+        double gs = 0.0, es = 0.0, qs = 0.0;
+#pragma unroll
+        for (int s = 0; s < kLdaSlots; ++s) {
+            const int k = lane + 64 * s;
+            if (k < K) {
+                const double g = gamma[(size_t)d * K + k], el = Elntheta[(size_t)d * K + k];
+                gs += g; es += el; qs += lgamma(g) - (g - 1.0) * el;
+            }
+        }
+        const double S = wave_sum(gs);
+        t[0] += wave_sum(es);
+        t[4] += wave_sum(qs) - lgamma(S);
+        const int64_t start = c.doc_ptr[d];
+        const int W = (int)(c.doc_ptr[d + 1] - start);
+        double pz = 0.0, px = 0.0, qz = 0.0;
+        for (int w = lane; w < W; w += MMM_WAVE) {
+            const int2 tc = c.tc[start + w];
+            const double n = (double)tc.y;
+            for (int k = 0; k < K; ++k) {
+                const double p = phi[(size_t)(start + w) * K + k];
+                pz += p * Elntheta[(size_t)d * K + k] * n;
+                px += p * Elnbeta[(size_t)k * V + tc.x] * n;
+                qz += dev_xlogx(p);
+            }
+        }
+        t[1] += wave_sum(pz); t[2] += wave_sum(px); t[3] += wave_sum(qz);
+    }
+    if (lane == 0) for (int j = 0; j < 5; ++j) shw[wid][j] = t[j];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double s = 0.0;
+        for (int w = 0; w < kWavesPerBlock; ++w) s += shw[w][threadIdx.x];
+        out[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+    }
+}
+
 // topic-side ELBO pieces (LDA.jl:114-118,142-146): out = {sum Elnbeta, ElnQbeta}
 __global__ __launch_bounds__(256) void k_lda_elbo_topics(int V, int K, const double* lambda, const double* Elnbeta, double* out)
 {
@@ -2018,7 +2188,7 @@ int pick_kp(int K)
 {
     static const int opts[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
     for (int o : opts) if (K <= o) return o;
-    if (K <= 64) return (K + 1) & ~1;      // 33..64 topics: the rolled-loop kernels (k_lda_estep_big, k_lda_stats_big), wide path only
+    if (K <= 64 * kLdaSlots) return (K + 1) & ~1;      // 33..256 topics: the rolled-loop kernels (k_lda_estep_big, k_lda_stats_big), wide path only
     return -1;
 }
 
@@ -2150,9 +2320,12 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
         hipLaunchKernelGGL(k_lda_tables_by_term, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->V, m->K, m->KP,
                            (const double*)a.expElnbeta.s[slot], a.do_ll ? (const double*)a.beta.s[slot] : (const double*)nullptr, m->tabT.p, m->tabT.p + n);
         if (m->KP > 32) {
-            const size_t lds = sizeof(double) * kWavesPerBlock * ((size_t)m->KP * MMM_WAVE + 2 * m->KP);
+            const size_t per = sizeof(double) * ((size_t)m->KP * MMM_WAVE + 2 * m->KP);
+            const int nw = (int)std::max<size_t>(1, std::min<size_t>(kWavesPerBlock, (150 * 1024) / per));
+            const size_t lds = per * nw;
             if (!m->attr_big) { if ((rc = set_lds(ctx, k_lda_estep_big, lds))) return rc; m->attr_big = true; }
-            hipLaunchKernelGGL(k_lda_estep_big, dim3(m->grid_e), dim3(kBlock), lds, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n, m->KP);
+            // (the grid stays m->grid_e: the ll partials are summed over that many blocks; the blocks stride over the documents)
+            hipLaunchKernelGGL(k_lda_estep_big, dim3(m->grid_e), dim3(nw * MMM_WAVE), lds, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n, m->KP);
         } else
         MMM_KP_SWITCH(m, { hipLaunchKernelGGL(k_lda_estep_wide<KPV>, dim3(m->grid_e), dim3(kBlock), 0, ctx->stream, a, m->aexp.p, m->tabT.p, m->tabT.p + n); })
         MMM_LAUNCH_CHECK(ctx);
@@ -2171,6 +2344,11 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
 int launch_phi(mmm_lda* m, const double* Elntheta, const double* expElnbeta)
 {
     mmm_ctx* ctx = m->ctx;
+    if (m->K > 64) {        // 65..256 topics: a_k in LDS, rolled loops
+        hipLaunchKernelGGL(k_lda_phi_big, dim3(m->grid_s), dim3(kBlock), sizeof(double) * kWavesPerBlock * m->K, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     if (m->KP > 32) {       // 33..64 topics (off the iteration path): the 64-topic build, topics >= K skipped
         hipLaunchKernelGGL((k_lda_phi<64, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), Elntheta, expElnbeta, m->phi.p);
         MMM_LAUNCH_CHECK(ctx);
@@ -2192,6 +2370,11 @@ int launch_loglik(mmm_lda* m, const double* gamma, const double* beta, double* t
 {
     mmm_ctx* ctx = m->ctx;
     const size_t lds = compute_ll ? m->lds_tab : 0;
+    if (m->K > 64) {
+        hipLaunchKernelGGL(k_lda_loglik_big, dim3(m->grid_s), dim3(kBlock), sizeof(double) * kWavesPerBlock * m->K, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
+        MMM_LAUNCH_CHECK(ctx);
+        return MMM_OK;
+    }
     if (m->KP > 32) {
         hipLaunchKernelGGL((k_lda_loglik<64, false>), dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), gamma, beta, theta, m->llpart.p, compute_ll);
         MMM_LAUNCH_CHECK(ctx);
@@ -2303,7 +2486,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
     if (!m->gnext_valid) {
         // update_γ! for the first pass (LDA.jl:82-90) from the resident phi
         if ((rc = materialise_phi(m))) return rc;
-        hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
+        hipLaunchKernelGGL(m->K > 64 ? k_lda_gamma_from_phi_big : k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
         MMM_LAUNCH_CHECK(ctx);
         m->gnext_valid = true;
     }
@@ -2397,7 +2580,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             continue;
         }
         if (m->wide && m->KP > 32) {
-            const int nw = std::min(m->stats_waves, 4);
+            const int nw = std::min(m->stats_waves, m->KP > 128 ? 1 : (m->KP > 64 ? 2 : 4));
             const size_t lds = sizeof(double) * ((size_t)nw * m->KP * MMM_WAVE + m->KP + (size_t)nw * m->KP);
             if (!m->attr_bigs) { if ((rc = set_lds(ctx, k_lda_stats_big, lds))) return rc; m->attr_bigs = true; }
             hipLaunchKernelGGL(k_lda_stats_big, dim3(m->V + 1), dim3(nw * MMM_WAVE), lds, ctx->stream, m->V, m->K, m->KP, m->term_ptr.p, m->tpost.p, m->aexp.p,
@@ -2448,7 +2631,7 @@ int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_b
     if ((rc = ensure_hist(m, n_iter))) return rc;
     if (!m->gnext_valid) {
         if ((rc = materialise_phi(m))) return rc;
-        hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
+        hipLaunchKernelGGL(m->K > 64 ? k_lda_gamma_from_phi_big : k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[(m->t + 1) % 3].p, (double*)nullptr);
         MMM_LAUNCH_CHECK(ctx);
         m->gnext_valid = true;
     }
@@ -2552,7 +2735,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     MMM_CHECK(ctx, D >= 0 && V >= 1 && K >= 1, "mmm_lda_create: bad sizes D=%d V=%d K=%d", D, V, K);
     *out = nullptr;
     const int KP = pick_kp(K);
-    if (KP < 0) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K=%d not supported (max 64: the per-document kernels keep one topic per lane)", K);
+    if (KP < 0) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "mmm_lda_create: K=%d not supported (max 256: an LDS column block of 512 K bytes per wave)", K);
     const int64_t nnz = doc_ptr[D];
     MMM_CHECK(ctx, doc_ptr[0] == 0 && nnz >= 0 && (nnz == 0 || (term && count)), "mmm_lda_create: bad CSR");
     std::vector<int2> tc((size_t)nnz);
@@ -2735,7 +2918,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
                             m->Elnbeta[0].p, m->expElnbeta[0].p, m->beta[0].p, (const int*)nullptr, 0, ReduceArgs{}, 0);      // ILDA.jl:36-40 (+ tables)
     if (KD) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((KD + 255) / 256)), dim3(256), 0, st, m->gamma[0].p, KD, 1.0);
-        hipLaunchKernelGGL(k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
+        hipLaunchKernelGGL(m->K > 64 ? k_lda_Elntheta_big : k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, st, m->dev(), m->gamma[0].p, m->Elntheta[0].p);
     }
     if (nnz) hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)K * nnz + 255) / 256)), dim3(256), 0, st, m->phi.p, (size_t)K * nnz, 1.0 / K);
     MMM_HIP(ctx, hipMemsetAsync(m->scratch.p, 0, sizeof(double) * (VK + 16), st));
@@ -2860,7 +3043,7 @@ int mmm_lda_update_gamma(mmm_lda* m)
     int rc = prepare_call(m);
     if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
     const int c = m->cur();
-    hipLaunchKernelGGL(k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p);
+    hipLaunchKernelGGL(m->K > 64 ? k_lda_gamma_from_phi_big : k_lda_gamma_from_phi, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p);
     MMM_LAUNCH_CHECK(m->ctx);
     m->gnext_valid = false; m->phi_from_prev = false; m->theta_valid = false;
     return MMM_OK;
@@ -2982,7 +3165,7 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7])
     if (rc || (rc = materialise_phi(m))) return rc;
     const int c = m->cur();
     double* acc = m->elbopart.p + (size_t)m->grid_s * 5;      // [0..4] doc sums, [5..6] topic sums
-    hipLaunchKernelGGL(k_lda_elbo_docs, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p, m->Elnbeta[c].p, m->elbopart.p);
+    hipLaunchKernelGGL(m->K > 64 ? k_lda_elbo_docs_big : k_lda_elbo_docs, dim3(m->grid_s), dim3(kBlock), 0, ctx->stream, m->dev(), m->phi.p, m->gamma[c].p, m->Elntheta[c].p, m->Elnbeta[c].p, m->elbopart.p);
     hipLaunchKernelGGL(k_sum_columns, dim3(5), dim3(64), 0, ctx->stream, m->elbopart.p, m->grid_s, 5, acc);
     if (m->ilda) hipLaunchKernelGGL(k_ilda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->ids, m->ilam[c].p, m->iEln[c].p, acc + 5);
     else hipLaunchKernelGGL(k_lda_elbo_topics, dim3(1), dim3(256), 0, ctx->stream, m->V, m->K, m->lambda[c].p, m->Elnbeta[c].p, acc + 5);

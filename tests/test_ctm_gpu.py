@@ -473,7 +473,7 @@ def test_unsupported_shapes_are_reported(mmm):
     with pytest.raises(mmm.MmmError, match="<= 256"):
         mmm.MMCTM([60] * 5, [0.1] * 5, [4] * 5, [[np.array([[1, 3]])] * 5], seed=0)
     with pytest.raises(mmm.MmmError, match="not supported"):
-        mmm.LDA(70, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)
+        mmm.LDA(300, 0.1, 0.1, 4, [np.array([[1, 3]])], seed=0)
 
 
 # ------------------------------------------------------------------------------------------ update_α! / autoα

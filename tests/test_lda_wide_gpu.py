@@ -126,10 +126,12 @@ def test_wide_degenerate_shapes(mmm, oracle, monkeypatch):
     np.testing.assert_allclose(g.λ, o.lam.reshape(3, 2, order="F"), rtol=1e-11)
 
 
-@pytest.mark.parametrize("D,V,K,mean_n", [(300, 96, 48, 3000), (150, 50, 33, 400), (120, 200, 64, 2500), (90, 1536, 40, 3000)])
+@pytest.mark.parametrize("D,V,K,mean_n", [(300, 96, 48, 3000), (150, 50, 33, 400), (120, 200, 64, 2500), (90, 1536, 40, 3000), (100, 96, 65, 3000), (80, 120, 100, 2000),
+                                           (60, 300, 129, 4000), (40, 96, 256, 3000)])
 def test_more_than_32_topics(mmm, oracle, D, V, K, mean_n):
-    """The reference has no limit on K (LDA.jl:24-54).  33..64 topics run the two sweeps of the wide path with rolled topic loops
-    (k_lda_estep_big, k_lda_stats_big): stage sequence and whole fits against the oracle, early stop included; K = 64 leaves no lane for psi(sum gamma)."""
+    """The reference has no limit on K (LDA.jl:24-54).  33..256 topics run the two sweeps of the wide path with rolled topic loops
+    (k_lda_estep_big, k_lda_stats_big; beyond 64 topics a lane holds topics l, l + 64, ... in the per-document kernels): stage sequence and
+    whole fits against the oracle, early stop included."""
     X, g, o = _pair(mmm, oracle, D, V, K, seed=70 + K, mean_n=mean_n, empty=(2, D - 1))
     assert g.geometry()["wide"] == 1
     mmm.update_γ(g); o.update_gamma()
@@ -152,7 +154,7 @@ def test_more_than_32_topics(mmm, oracle, D, V, K, mean_n):
     np.testing.assert_allclose(g.γ.sum(axis=0), K * 0.1 + N, rtol=1e-12)                         # mass conservation
 
 
-def test_more_than_64_topics_is_refused(mmm):
+def test_more_than_256_topics_is_refused(mmm):
     X, lam0 = np_ref.synth_lda(20, 30, 8, seed=1, mean_n=100)
-    with pytest.raises(mmm.MmmError, match="max 64"):
-        mmm.LDA(65, 0.1, 0.1, 30, X, λ0=np.ones((30, 65)))
+    with pytest.raises(mmm.MmmError, match="max 256"):
+        mmm.LDA(257, 0.1, 0.1, 30, X, λ0=np.ones((30, 257)))
