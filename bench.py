@@ -193,15 +193,23 @@ def launch_ranks(n, argv, timeout_s):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     deadline = time.time() + timeout_s
-    out0 = ""
     rc = 0
+    # rank 0's stdout is drained by a thread (its JSON line can exceed a pipe buffer); the parent polls: the moment one rank fails, the
+    # others -- which would sit in a collective until its own time-out -- are ended too
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
-        for p in procs:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
-        rc = 124
-        print("bench.py: the %d-rank job did not finish within %d s" % (n, timeout_s), file=sys.stderr)
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                print("bench.py: the %d-rank job did not finish within %d s" % (n, timeout_s), file=sys.stderr)
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:       # exactly the processes started above, by handle
@@ -211,6 +219,8 @@ def launch_ranks(n, argv, timeout_s):
                 p.wait(timeout=30)
             except subprocess.TimeoutExpired:
                 pass
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
     bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
     line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
     if bad or rc or not line:
