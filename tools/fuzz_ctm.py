@@ -13,9 +13,10 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n):
     M = int(rng.choice([1, 2, 3, 4]))
+    big = bool(rng.integers(0, 4) == 0)       # a quarter of the cases: beyond 32 topics in a modality / beyond 64 coordinates (round 3)
     while True:
-        K = [int(rng.choice([1, 2, 3, 5, 7, 10, 14, 17, 20, 32])) for _ in range(M)]
-        if sum(K) <= 64: break
+        K = [int(rng.choice([1, 2, 3, 5, 7, 10, 14, 17, 20, 32] + ([33, 40, 50, 64] if big else []))) for _ in range(M)]
+        if sum(K) <= (256 if big else 64): break
     V = [int(rng.choice([2, 5, 16, 38, 48, 96, 200, 700])) for _ in range(M)]
     D = int(rng.choice([1, 3, 40, 130, 300]))
     means = [int(rng.choice([5, 60, 800, 4000])) for _ in range(M)]
@@ -27,7 +28,7 @@ for case in range(n):
         MK = sum(K)
         mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
         o.estep_range(0, D); o.update_mu(); so = o.update_Sigma(); o.update_gamma(); o.update_props(); o.update_phi()
-        T._cmp_docs(g, o, D, MK, M)
+        T._cmp_docs(g, o, D, MK, M, frac=0.95 if MK <= 64 or D < 20 else 0.8)
         np.testing.assert_allclose(g._get("gamma"), o.gamma, rtol=1e-4)
         np.testing.assert_allclose(g.μ, o.mu, rtol=1e-4, atol=1e-6)
         ll = np.zeros(M); nn = mmm._lib.C.c_int()

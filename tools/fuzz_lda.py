@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for case in range(n):
-    K = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 11, 12, 13, 16, 20, 24, 25, 32]))
+    K = int(rng.choice([1, 2, 3, 5, 7, 8, 10, 11, 12, 13, 16, 20, 24, 25, 32, 33, 47, 64, 65, 90, 128, 129, 200, 256]))
     V = int(rng.choice([1, 3, 16, 17, 32, 48, 78, 83, 96, 100, 128, 130, 200, 256, 257, 400, 1536]))
     D = int(rng.choice([1, 2, 5, 37, 64, 150, 401, 1500]))
     mean_n = int(rng.choice([5, 50, 500, 5000]))
