@@ -513,6 +513,9 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                 if cfg["model"] == "lda":
                     res["roofline"]["f64_valu"] = blk
                 else:
+                    blk["note"] = ("the counters are averages over the full-size launches of the profiled command (its first ~40 passes, whose solves need "
+                                   "more evaluations than the later passes timed here), so this fraction overstates the busy share of the timed launches; "
+                                   "at equal passes the pipes are ~80 % busy (DESIGN.md section 4.2)")
                     res["roofline"]["f64_valu"]["issue"] = blk
         if world == 1:
             if cfg["model"] == "lda":
