@@ -560,7 +560,9 @@ def main():
             t0 = time.perf_counter()
             try:
                 r = run_config(env, c, args.scaling, 10, 2, 5, 0, not args.no_cpu_baseline, cpu_target_s=8.0)
-            except Exception as e:       # noqa: BLE001 -- the headline stands on its own
+            except Exception as e:       # noqa: BLE001 -- one GPU: the headline stands on its own; several ranks: a rank that carried on
+                if env.world > 1:        # alone would leave the others inside a collective -- fail the job instead
+                    raise
                 r = {"error": "%s: %s" % (type(e).__name__, e)}
             if env.rank == 0:
                 r["wall_s_including_corpus_generation_and_cpu_baseline"] = time.perf_counter() - t0
