@@ -596,7 +596,7 @@ template <int MKT, int LPD, bool SB>
 struct NuObjC {
     using Gm = CplGeom<MKT, LPD>;
     double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
-    int mod[Gm::CPL], l;
+    int modpack, l;       // the modality of coordinate q of this lane in bits [4q, 4q + 4)
     bool lane_on, on;      // lane_on: the lane holds coordinates (l < ACT); on: ... of a document
     // start point and constants of document d (d < 0: an empty slot).  Lanes that are not `on` keep x = 0 and contribute exact zeros.
     __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
@@ -608,7 +608,7 @@ struct NuObjC {
         for (int q = 0; q < Gm::CPL; ++q) {
             x[q] = d < 0 ? 0.0 : dc.nu[row + q];
             lam[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
-            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + mod[q]], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + mod[q]];
+            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)];
             c[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
         }
     }
@@ -640,8 +640,9 @@ struct NuObjC {
 template <int MKT, int LPD, bool SB>
 struct LamObjC {
     using Gm = CplGeom<MKT, LPD>;
-    double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL], mu[Gm::CPL];
-    int mod[Gm::CPL], l;
+    double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL];
+    const double* smu;    // mu in LDS, [LPD * CPL] in the lane layout (0 for lanes without coordinates): CPL registers fewer than a copy per lane
+    int modpack, l;       // the modality of coordinate q of this lane in bits [4q, 4q + 4)
     bool lane_on, on;
     const double* sS;     // padded layout above
     double* scr;          // group-private LDS, MKT doubles (+ pad): the differences x - mu of the whole document
@@ -655,7 +656,7 @@ struct LamObjC {
             x[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
             nu[q] = d < 0 ? 1.0 : dc.nu[row + q];
             sumth[q] = d < 0 ? 0.0 : dc.sumth[row + q];
-            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + mod[q]], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + mod[q]];
+            const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)];
             c[q] = Nl / zl;
         }
     }
@@ -672,7 +673,7 @@ struct LamObjC {
         double diff[Gm::CPL];
         lds_wave_sync();
 #pragma unroll
-        for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - mu[q]; if (lane_on) scr[l * Gm::CPL + q] = diff[q]; }
+        for (int q = 0; q < Gm::CPL; ++q) { diff[q] = x[q] - smu[l * Gm::CPL + q]; if (lane_on) scr[l * Gm::CPL + q] = diff[q]; }
         lds_wave_sync();
         // Sd_i = sum_j S_ij diff_j with four chains over j, combined pairwise (the association of LamObj::eval)
         double s0[Gm::CPL], s1[Gm::CPL], s2[Gm::CPL], s3[Gm::CPL];
@@ -764,12 +765,16 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
         d = __shfl(d, g * LPD, MMM_WAVE);
     }
     bool have = d < r1, fresh = true;
-    double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL], xprevprev[CPL];
+    double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL];
+    // NLopt's sigma update looks at the SIGN of (xcur - xprev) (xprev - xprevprev).  Only the sign of the older step is kept (+1 / 0 / -1 as a
+    // float): the product of two nonzero steps can neither underflow (steps are >= 1e-23 in magnitude here) nor overflow, so
+    // sign(a b) = sign(a) sign(b) exactly -- same decisions, CPL registers fewer than carrying xprevprev
+    float sprev[CPL];
     double rho = 1.0, fbest = 0.0;
     int k = 1, nev = 0;
     obj.load(dc, have ? d : -1, x);
 #pragma unroll
-    for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
+    for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; sprev[q] = 0.f; }
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
     while (__any(have)) {
         double gls = 0.0, wls = 0.0;
@@ -836,10 +841,12 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
             rho = nxt ? fmax(0.1 * rho, 1e-5) : rho;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
-                const double sgn = (xcur[q] - xprev[q]) * (xprev[q] - xprevprev[q]);
-                const double fac = (nxt && k > 1) ? (sgn < 0 ? 0.7 : (sgn > 0 ? 1.2 : 1.0)) : 1.0;
+                const double dcur = xcur[q] - xprev[q];
+                const float scur = dcur > 0.0 ? 1.f : (dcur < 0.0 ? -1.f : 0.f);
+                const float sgn = scur * sprev[q];
+                const double fac = (nxt && k > 1) ? (sgn < 0.f ? 0.7 : (sgn > 0.f ? 1.2 : 1.0)) : 1.0;
                 sigma[q] *= fac;
-                xprevprev[q] = nxt ? xprev[q] : xprevprev[q];
+                sprev[q] = nxt ? scur : sprev[q];
                 xprev[q] = nxt ? xcur[q] : xprev[q];
             }
             k += nxt ? 1 : 0;
@@ -863,7 +870,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
                 obj.load(dc, have ? d : -1, x);
                 rho = 1.0; k = 1; nev = 0; fresh = true;
 #pragma unroll
-                for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
+                for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; sprev[q] = 0.f; }
             }
         }
     }
@@ -893,7 +900,9 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     // LDS: [MK rows][ROW] invSigma (padded) | [NW][G][MK + 2] difference vectors
     double* sS = smem;
     double* sScr = sS + MK * Gm::ROW;
+    double* sMu = sScr + (size_t)NW * G * (MK + 2);      // [LPD * CPL]
     if constexpr ((WHICH & 2) != 0) {
+        for (int e = tid; e < LPD * CPL; e += blockDim.x) sMu[e] = e < MK ? p_mu[e] : 0.0;
         for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
             const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
             sS[e] = (q < CPL && ll < Gm::ACT) ? p_invSigma[(size_t)j * MK + ll * CPL + q] : 0.0;       // sS[j][i] = invSigma(i, j), column-major source
@@ -921,20 +930,22 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
             r0 = 0; r1 = D;
         }
     }
-    int mod_q[CPL];
+    static_assert(CPL <= 7, "modality indices are packed 4 bits each into one int");
+    int modpack = 0;
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         const int i = l * CPL + q;
         int mm = 0;
         for (int m = 0; m < M; ++m) if (i >= dm.koff[m] && i < dm.koff[m + 1]) mm = m;
-        mod_q[q] = mm;
+        modpack |= mm << (4 * q);
     }
     const SolveOpts o = a.opt;
     // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ -- for every document of the range
     if constexpr ((WHICH & 1) != 0) if (a.flags & F_NU) {
         NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0; }
+        for (int q = 0; q < CPL; ++q) obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0;
+        obj.modpack = modpack;
         obj.l = l; obj.lane_on = lane_on;
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, pool, gcnt);
     }
@@ -946,8 +957,8 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
     if constexpr ((WHICH & 2) != 0) if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) { obj.mod[q] = mod_q[q]; obj.mu[q] = lane_on ? p_mu[l * CPL + q] : 0.0; }
+        obj.modpack = modpack;
+        obj.smu = sMu;
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam, pool, gcnt);
     }
@@ -1235,7 +1246,10 @@ __device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logde
     }
 }
 
-// update_μ! / update_Σ! of one replica by the calling block (>= 128 threads); smem: 2 MK^2 doubles
+// update_μ! / update_Σ! of one replica by the calling block (>= 128 threads); smem: 2 MK^2 doubles.  BIG (sum K > 64): the matrices live
+// in device memory -- a compile-time switch, so that the LDS build keeps LDS addressing (a run-time choice of the base pointer turned every
+// access of the inversion into a flat one: 54 -> 84 us for the Gaussian block at sum K = 28)
+template <bool BIG>
 __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* smem)
 {
     __shared__ double s_logdet; __shared__ int s_sing, s_piv;
@@ -1247,7 +1261,7 @@ __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* 
     __syncthreads();
     // update_Σ! (MMCTM.jl:204-212) from raw moments: (diag Σν + Σ (λ-μ)(λ-μ)') / D with the NEW μ
     if (a.do_sigma) {
-        double* A = a.big_scratch ? a.big_scratch + (size_t)blockIdx.y * 2 * MK * MK : smem;
+        double* A = BIG ? a.big_scratch + (size_t)blockIdx.y * 2 * MK * MK : smem;
         double* Ai = A + MK * MK;
         for (int e = tid; e < MK * MK; e += nt) {
             const int i = e % MK, j = e / MK;
@@ -1259,7 +1273,7 @@ __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* 
             q.Sigma[e] = v; A[i * MK + j] = v;
         }
         __syncthreads();
-        if (a.big_scratch) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
+        if constexpr (BIG) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
         else block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
         __syncthreads();
         for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; q.invSigma[e] = Ai[i * MK + j]; }
@@ -1273,7 +1287,8 @@ __global__ __launch_bounds__(256) void k_ctm_mstep(MstepArgs a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     MstepPtrs q;
     if (!mstep_replica(a, q)) return;
-    ctm_gauss_mstep(a, q, smem);
+    if (a.big_scratch) ctm_gauss_mstep<true>(a, q, smem);
+    else ctm_gauss_mstep<false>(a, q, smem);
 }
 
 // update_γ! / update_Elnϕ! / update_ϕ! (MMCTM.jl:214-250; IMMCTM.jl:188-223): one block per topic (m,k) -- topics are
@@ -1490,7 +1505,7 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     const int ndoc_blocks = gauss ? gridDim.x - 1 : gridDim.x;
     if (gauss && blockIdx.x == 0) {      // block 0: dispatched first, so the serial inversion starts with the sweep, not after it
         MstepPtrs q;
-        if (mstep_replica(ga, q)) ctm_gauss_mstep(ga, q, smem);
+        if (mstep_replica(ga, q)) ctm_gauss_mstep<false>(ga, q, smem);
         return;
     }
     const int bx = (int)blockIdx.x - gauss;
@@ -1670,11 +1685,17 @@ __global__ __launch_bounds__(256) void k_ctm_elbo_topics(CtmDims dm, CtmTopics t
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double s_logdet; __shared__ int s_sing, s_piv; __shared__ double sh[4];
     const int MK = dm.MK, M = dm.M, tid = threadIdx.x, nt = blockDim.x;
-    double* A = big_scratch ? big_scratch : smem; double* Ai = A + MK * MK;
-    for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; A[i * MK + j] = invSigma[e]; }
-    __syncthreads();
-    if (big_scratch) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
-    else block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+    if (big_scratch) {       // sum K > 64: device memory (separate code paths keep the LDS addressing of the other)
+        double* A = big_scratch; double* Ai = A + MK * MK;
+        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; A[i * MK + j] = invSigma[e]; }
+        __syncthreads();
+        block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
+    } else {
+        double* A = smem; double* Ai = smem + MK * MK;
+        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; A[i * MK + j] = invSigma[e]; }
+        __syncthreads();
+        block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
+    }
     __syncthreads();
     // one (m,k[,i]) Dirichlet per loop trip, handled by the whole block
     double P = 0.0, Q = 0.0;
@@ -1826,7 +1847,7 @@ size_t solve_lds(const mmm_ctm* m)
 {
     if (m->persist) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
         const int cplp = m->cpl == 1 ? 1 : (m->cpl + 1) & ~1;
-        return sizeof(double) * ((size_t)m->dm.MK * m->Ls * cplp + (size_t)m->waves_s * (MMM_WAVE / m->Ls) * (m->dm.MK + 2));
+        return sizeof(double) * ((size_t)m->dm.MK * m->Ls * cplp + (size_t)m->waves_s * (MMM_WAVE / m->Ls) * (m->dm.MK + 2) + (size_t)m->Ls * m->cpl);
     }
     const int scrw = m->Ls != m->L ? (MMM_WAVE / m->Ls + 1) * 2 * m->Ls : 2 * MMM_WAVE;
     return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * scrw);
@@ -1892,7 +1913,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             if (m->dm.MK == 28 && m->Ls == 8 && !m->split) return go(k_ctm_solve_cpl<28, 8, 2, false>);
             if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
             if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
-            if (!m->split && m->dm.MK == 28 && m->Ls == 16) return go(k_ctm_solve_cpl<28, 16, 3, false>);
+            if (!m->split && m->dm.MK == 28 && m->Ls == 16) return m->lam_occ == 4 ? go(k_ctm_solve_cpl<28, 16, 4, false>) : go(k_ctm_solve_cpl<28, 16, 3, false>);
             if (!m->split && m->dm.MK == 14 && m->Ls == 8) return go(k_ctm_solve_cpl<14, 8, 4, false>);
             if (m->split && m->dm.MK == 28 && m->Ls == 16) {
                 if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 16, 2, false, 2>);
@@ -2399,7 +2420,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
             else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
             else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
-            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
+            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = getenv("MMM_CTM_OCC28") ? std::max(3, std::min(4, atoi(getenv("MMM_CTM_OCC28")))) : 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
             else if (cmode == 4 && dm.MK == 14) { m->Ls = 8; m->cpl = 2; m->lam_occ = 4; }                // 7 of 8 lanes x 2 coordinates
             if (m->cpl > 1) m->persist = true;
         }
