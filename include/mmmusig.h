@@ -124,7 +124,8 @@ enum { /* field ids for mmm_lda_get / mmm_lda_set; sizes in doubles */
 };
 /* Constructor LDA(k, alpha, eta, V, X) -- LDA.jl:24-54.  lambda0 (V*K) is the random init the shim draws with
  * rand(1:100, V, K) (LDA.jl:36); the ctor state gamma=1, phi=1/K, Elnbeta, Elntheta is built on the GPU.
- * With an RCCL communicator on ctx, (D, doc_ptr, term, count) is THIS RANK'S shard of the documents. */
+ * With an RCCL communicator on ctx, (D, doc_ptr, term, count) is THIS RANK'S shard of the documents.
+ * Shapes: any V; K <= 256 (tuned builds to 32 topics, rolled-loop kernels beyond); MMM_ERR_UNSUPPORTED otherwise -- the reference has no limit. */
 int mmm_lda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr,
                    const int32_t* term, const int32_t* count, const double* lambda0, mmm_lda** out);
 /* Constructor ILDA(k, alpha, eta::Vector, features, X) -- ILDA.jl:25-56: the topic-term distribution factorises over the I
@@ -188,7 +189,9 @@ enum { /* field ids for mmm_ctm_get / mmm_ctm_set */
 };
 /* Constructor MMCTM(k, alpha, V, X) -- MMCTM.jl:29-91 (init = :random; gamma0 is the rand(1:100, V[m]) draw per
  * topic, MMCTM.jl:60-63).  n_feat/J/features == NULL: MMCTM.  Otherwise IMMCTM(k, alpha, features, X) --
- * IMMCTM.jl:29-78 with alpha of length sum_m I[m] and gamma0 in the IMMCTM layout. */
+ * IMMCTM.jl:29-78 with alpha of length sum_m I[m] and gamma0 in the IMMCTM layout.
+ * Shapes: any V[m]; M <= 8; K[m] <= 64; sum K <= 256 (tuned kernels to sum K = 64 with K[m] <= 32, generic ones beyond);
+ * MMM_ERR_UNSUPPORTED otherwise -- the reference has no limit. */
 int mmm_ctm_create(mmm_ctx* ctx, int D, int M, const int* K, const int* V, const double* alpha,
                    const int64_t* doc_ptr, const int32_t* term, const int32_t* count, const int* n_feat,
                    const int* J, const int32_t* features, const double* gamma0, const mmm_solver_opts* opts,
