@@ -222,7 +222,8 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
                          int* per_doc_nu, int* per_doc_lambda);
 /* Launch geometry that fixes the ORDER of the sums across documents (and so their bits): out[0] = lanes per document L,
  * [1] = theta-phase blocks, [2] = waves per theta-phase block, [3] = blocks of the moment sums, [4] = 1 when the handle
- * takes the wide-table path (term-major posting sweep instead of LDS slabs), [5] = lanes per document in the solve phase (L, sum K for the packed
+ * takes the wide-table path (term-major posting sweep instead of LDS slabs), 2 when the fused pass's theta phase runs over rows of counts
+ * (dense corpora: 16 lanes per document, statistics in registers), [5] = lanes per document in the solve phase (L, sum K for the packed
  * builds, or 2 / 4), [6] = coordinates per lane in the solve phase, [7] = 0.  The parity tests hand it to the
  * order-matched CPU restatement (oracle/mmm_twin.c), which then reproduces a whole fit bit for bit. */
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8]);

@@ -551,6 +551,145 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Theta phase of the fused pass over ROWS OF COUNTS (round 3; dense corpora -- the shipped BRCA tables and the synthetic configurations
+// are 85-100 % dense): one launch per modality; a document takes 16 lanes whatever sum K is (a modality has at most 16 topics here),
+// four documents per wave step; lane l owns the terms l, 16 + l, ... of EVERY document it meets, so the gamma statistics sum_d theta_kv n_dv
+// of its terms stay in registers for the whole launch (SL KMX doubles) and reach the wave's slab once, at the end -- no LDS atomics, no
+// (term, count) loads: 2 bytes per term slot.  The scheme of k_lda_estep_dense (lda.hip) with the CTM's prologue (zeta, exp(lambda -
+// max)); same formulas and the same per-element operations as the theta phase of k_ctm_estep (MMCTM.jl:172-198, 110-117), other
+// association of the sums (the order-matched oracle mirrors it: oracle/mmm_twin.c, orc_twin_estep).
+// LDS: [16 SL][KMX] table, term-major | [NW][Km Vm] slabs | [NW][4][KMX] a_k | [NW][64][KMX] sum-theta scratch
+template <int KMX, int SL>
+__global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, const unsigned short* __restrict__ rows)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int L = 16, G = MMM_WAVE / L, Vp = L * SL;
+    const CtmDims& dm = a.c.dm;
+    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    const size_t rep = blockIdx.y;
+    if (a.active && !a.active[rep]) return;
+    const double* p_lam_in = a.lam_in + rep * D * MK;
+    const double* p_nu = a.nu + rep * D * MK;
+    double* p_zeta = a.zeta + rep * D * M;
+    double* p_sumth = a.sumth + rep * D * MK;
+    const double* __restrict__ p_expE = a.expE + rep * GT;
+    double* p_partial = a.partial + rep * gridDim.x * GT;
+    const int Km = dm.K[m], Vm = dm.V[m], off = dm.koff[m];
+    const int NW = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
+    const int KV = Km * Vm;
+    double* sT = smem;                                   // [Vp][KMX]; rows v >= Vm hold 1 (their counts are 0), topics k >= Km hold 0
+    double* sSlab = sT + (size_t)Vp * KMX;               // [NW][Km][Vm]
+    double* sA = sSlab + (size_t)NW * KV;                // [NW][G][KMX]
+    double* sR = sA + (size_t)NW * G * KMX;              // [NW][64][KMX]
+    double* slab = sSlab + (size_t)wid * KV;
+    double* myA = sA + ((size_t)wid * G + g) * KMX;
+    double* myR = sR + (size_t)wid * MMM_WAVE * KMX;
+    const double* __restrict__ tbg = p_expE + dm.goff[m];
+    for (int i = tid; i < Vp * KMX; i += blockDim.x) {
+        const int v = i / KMX, k = i % KMX;
+        sT[i] = (k < Km) ? (v < Vm ? tbg[(size_t)k * Vm + v] : 1.0) : 0.0;
+    }
+    for (int i = tid; i < NW * KV; i += blockDim.x) sSlab[i] = 0.0;
+    if (a.expE_keep && blockIdx.x == 0 && m == 0) for (int i = tid; i < GT; i += blockDim.x) a.expE_keep[rep * GT + i] = p_expE[i];
+    __syncthreads();
+    double st[SL][KMX];
+#pragma unroll
+    for (int q = 0; q < SL; ++q)
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) st[q][k] = 0.0;
+    const int flags = a.flags;
+    const int stride = gridDim.x * NW * G;
+    int base = (blockIdx.x * NW + wid) * G;
+    // the first step's lambda row and counts
+    int d = base + g;
+    bool valid = d < D;
+    double lam = (valid && l < Km) ? p_lam_in[(size_t)d * MK + off + l] : 0.0;
+    double nu = ((flags & F_ZETA) && valid && l < Km) ? p_nu[(size_t)d * MK + off + l] : 1.0;
+    int c[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) c[q] = valid ? (int)rows[(size_t)d * Vp + q * L + l] : 0;
+    for (; base < D; base += stride) {
+        // the next step's loads go out before this step computes
+        const int dn = d + stride;
+        const bool validn = base + stride < D && dn < D;
+        double lamn = 0.0, nun = 1.0;
+        int cn[SL];
+        if (validn && l < Km) { lamn = p_lam_in[(size_t)dn * MK + off + l]; if (flags & F_ZETA) nun = p_nu[(size_t)dn * MK + off + l]; }
+#pragma unroll
+        for (int q = 0; q < SL; ++q) cn[q] = validn ? (int)rows[(size_t)dn * Vp + q * L + l] : 0;
+        const bool act = valid && l < Km;
+        if (a.lam_keep && act) a.lam_keep[(rep * D + d) * MK + off + l] = lam;
+        if (flags & F_ZETA) {       // update_ζ! (MMCTM.jl:172-181)
+            const double zm = group_sum<L>(act ? ar_exp(lam + 0.5 * nu) : 0.0);
+            if (valid && l == 0) p_zeta[(size_t)d * M + m] = zm;
+        }
+        const double mx = group_max<L>(act ? lam : -1e300);
+        lds_wave_sync();
+        if (l < KMX) myA[l] = act ? ar_exp(lam - mx) : 0.0;
+        lds_wave_sync();
+        double av[KMX], acc[KMX];
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
+        // theta_kv n_v (MMCTM.jl:183-198) for the lane's SL terms: e_k = a_k B_kv, s = sum_k e_k, 1/s correctly rounded, the sums by fma
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const double* tb = sT + (size_t)(q * L + l) * KMX;
+            // (s in topic order, as the slab kernel and the on-demand rebuild of theta form it: theta_kv = e_k / s must be the same bits
+            // wherever it is evaluated; two interleaved chains were 3 us faster at cfg 5 and broke exactly that)
+            double e[KMX], s = 0.0;
+#pragma unroll
+            for (int k = 0; k < KMX; ++k) { e[k] = av[k] * tb[k]; s += e[k]; }
+            const double r = (double)c[q] * dev_div(1.0, s);
+#pragma unroll
+            for (int k = 0; k < KMX; ++k) { acc[k] = fma(e[k], r, acc[k]); st[q][k] = fma(e[k], r, st[q][k]); }
+#pragma unroll
+            for (int k = 0; k < KMX; ++k) asm volatile("" : "+v"(st[q][k]));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // sumθ_k (MMCTM.jl:110-117): the lanes' sums meet in LDS, lane k of the group adds its column of the 16 lanes' values
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) myR[(size_t)lane * KMX + k] = acc[k];
+        lds_wave_sync();
+        if (l < Km) {
+            const double* col = myR + (size_t)(g * L) * KMX + l;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; j += 4) { r0 += col[j * KMX]; r1 += col[(j + 1) * KMX]; r2 += col[(j + 2) * KMX]; r3 += col[(j + 3) * KMX]; }
+            if (valid) p_sumth[(size_t)d * MK + off + l] = (r0 + r1) + (r2 + r3);
+        }
+        d = dn; valid = validn; lam = lamn; nu = nun;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) c[q] = cn[q];
+        lds_wave_sync();
+    }
+    // the lane's statistics reach the wave's slab, one document group at a time (groups 0..3), then the block's waves in order
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+        if (g == gg) {
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                const int v = q * L + l;
+                if (v < Vm) {
+#pragma unroll
+                    for (int k = 0; k < KMX; ++k) if (k < Km) slab[(size_t)k * Vm + v] += st[q][k];
+                }
+            }
+        }
+        lds_wave_sync();
+    }
+    __syncthreads();
+    double* out = p_partial + (size_t)blockIdx.x * GT + dm.goff[m];
+    for (int i = tid; i < KV; i += blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * KV + i];
+        out[i] = s;
+    }
+}
+
 // =====================================================================================================================
 // Solve phase, several coordinates per lane.  The solve phase is f64-VALU bound (PMC: the vector pipes are ~100 % busy), and with
 // one coordinate per lane most of a trip's instructions are not arithmetic on coordinates: five lane-butterfly sums, the scalars of
@@ -1789,6 +1928,9 @@ struct mmm_ctm {
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
     DevBuf<int> nev_nu, nev_lam, status, active, npass;
     DevBuf<int> claim;             // [2][R][32]: document counters of the split nu / lambda launches
+    // dense corpora: the fused pass's theta phase over rows of 16-bit counts, one launch per modality (k_ctm_theta_dense)
+    bool tdense = false; int tSL[kMaxM] = {0};
+    DevBuf<unsigned short> trows[kMaxM];      // [D][16 SL_m]
     bool big = false;              // 64 < sum K <= 256: the generic kernels of ctm_big.cuh (one wave per document, several coordinates per lane)
     DevBuf<double> big_scratch;    // [R][2 MK^2]: Sigma and its inverse during the Gaussian M-step / the ELBO's logdet
     int stop_enable = 0; double stop_tol = 0.0;     // set by fit_scope around a pass: the ll kernels apply the stopping rule
@@ -1878,6 +2020,40 @@ int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
         case 100024: return go(k_ctm_solve_cpl<10, 2, 4, false, 1>);
     }
     return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no split nu-solve build for sum K = %d, %d lanes, %d waves per SIMD", m->dm.MK, m->nu_Ls, m->nu_occ);
+}
+
+size_t theta_dense_lds(const mmm_ctm* m, int i, int kmx)
+{
+    const int NW = m->waves_e, Km = m->dm.K[i], Vm = m->dm.V[i];
+    return sizeof(double) * ((size_t)16 * m->tSL[i] * kmx + (size_t)NW * Km * Vm + (size_t)NW * 4 * kmx + (size_t)NW * MMM_WAVE * kmx);
+}
+
+inline int theta_dense_kmx(int Km) { return Km <= 8 ? 8 : (Km <= 10 ? 10 : 16); }
+
+// the theta phase of the fused pass over rows of counts: one launch per modality (k_ctm_theta_dense)
+int launch_theta_dense(mmm_ctm* m, const CtmEArgs& a, int nrep)
+{
+    mmm_ctx* ctx = m->ctx;
+    for (int i = 0; i < m->dm.M; ++i) {
+        const int kmx = theta_dense_kmx(m->dm.K[i]);
+        const size_t lds = theta_dense_lds(m, i, kmx);
+        auto go = [&](auto kern) -> int {
+            if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(m->grid_e, nrep), dim3(m->waves_e * MMM_WAVE), lds, ctx->stream, a, i, (const unsigned short*)m->trows[i].p);
+            MMM_LAUNCH_CHECK(ctx);
+            return MMM_OK;
+        };
+        int rc = MMM_ERR_UNSUPPORTED;
+        switch (kmx * 10 + m->tSL[i]) {
+            case 82: rc = go(k_ctm_theta_dense<8, 2>); break;    case 83: rc = go(k_ctm_theta_dense<8, 3>); break;
+            case 86: rc = go(k_ctm_theta_dense<8, 6>); break;    case 88: rc = go(k_ctm_theta_dense<8, 8>); break;
+            case 102: rc = go(k_ctm_theta_dense<10, 2>); break;  case 103: rc = go(k_ctm_theta_dense<10, 3>); break;
+            case 106: rc = go(k_ctm_theta_dense<10, 6>); break;
+            case 162: rc = go(k_ctm_theta_dense<16, 2>); break;  case 163: rc = go(k_ctm_theta_dense<16, 3>); break;
+        }
+        if (rc) return rc == MMM_ERR_UNSUPPORTED ? mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no dense theta build for K = %d, %d slots", m->dm.K[i], m->tSL[i]) : rc;
+    }
+    return MMM_OK;
 }
 
 template <int PH>
@@ -1986,7 +2162,9 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
         const size_t lds = estep_lds(m, flags);
         if (lds > 160 * 1024) return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "CTM theta phase needs %zu B of LDS (> 160 KiB)", lds);
         ProfSpan span(m->ctx, 1);   // mmm_ctx_profile_select(1): theta phase
-        if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
+        if (m->tdense && (flags & F_SLAB) && (flags & F_THETA_COMPUTE) && !(flags & (F_THETA_STORE | F_THETA_STORED))) {
+            if ((rc = launch_theta_dense(m, a, sc.nrep))) return rc;
+        } else if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
     }
     if (flags & (F_NU | F_LAMBDA)) {
         ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
@@ -2397,6 +2575,52 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     const int dpb = m->waves_e * G;
     const int per_cu = m->wide ? 2 : std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
     m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
+    // Dense corpora: the fused pass's theta phase over rows of 16-bit counts (k_ctm_theta_dense), when every modality has at most 16 topics
+    // and 128 terms, no document lists a term twice, every count fits 16 bits and at least half of the D x V_m entries are present.
+    // MMM_CTM_DENSE=1 / 0 forces / forbids it (tests, A/B); by default corpora of at least 32 documents per CU take it (below, a block of
+    // the 16-lane layout has less than one wave step and the slab kernel is as fast).
+    {
+        const char* de = getenv("MMM_CTM_DENSE");
+        const int dmode = de ? atoi(de) : -1;
+        bool ok = !m->wide && !m->big && dmode != 0 && D > 0;
+        int64_t present = 0, cells = 0;
+        for (int i = 0; i < M && ok; ++i) {
+            const int sl = dm.V[i] <= 32 ? 2 : (dm.V[i] <= 48 ? 3 : (dm.V[i] <= 96 ? 6 : (dm.V[i] <= 128 ? 8 : 0)));
+            if (sl == 0 || dm.K[i] > 16 || theta_dense_kmx(dm.K[i]) * sl > 64) { ok = false; break; }      // (the statistics must stay in registers)
+            m->tSL[i] = sl;
+            present += m->nnzm[i]; cells += (int64_t)D * dm.V[i];
+        }
+        if (ok && 2 * present < cells) ok = false;
+        if (ok && dmode < 0 && D < 32 * ctx->num_cu) ok = false;
+        std::vector<std::vector<unsigned short>> rows((size_t)M);
+        for (int i = 0; i < M && ok; ++i) {
+            const int Vp = 16 * m->tSL[i];
+            rows[i].assign((size_t)D * Vp, 0);
+            std::vector<int> seen((size_t)dm.V[i], -1);
+            const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
+            for (int d = 0; d < D && ok; ++d)
+                for (int64_t e = dp[d]; e < dp[d + 1]; ++e) {
+                    if (seen[(size_t)term[e]] == d || count[e] >= 65536) { ok = false; break; }
+                    seen[(size_t)term[e]] = d;
+                    rows[i][(size_t)d * Vp + term[e]] = (unsigned short)count[e];
+                }
+        }
+        if (ok) {
+            m->waves_e = 8;
+            for (int i = 0; i < M; ++i) if (theta_dense_lds(m, i, theta_dense_kmx(dm.K[i])) > 160 * 1024) ok = false;
+        }
+        if (ok) {
+            m->tdense = true;
+            m->grid_e = std::max(1, std::min((D + 31) / 32, ctx->num_cu));
+            for (int i = 0; i < M; ++i) {
+                hipError_t e_ = m->trows[i].alloc(rows[i].size());
+                if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(trows): %s", hipGetErrorString(e_)); delete m; return rc; }
+                if (hipMemcpy(m->trows[i].p, rows[i].data(), sizeof(unsigned short) * rows[i].size(), hipMemcpyHostToDevice) != hipSuccess) {
+                    int rc = mmm_fail(ctx, MMM_ERR_HIP, "upload of the rows of counts failed"); delete m; return rc;
+                }
+            }
+        }
+    }
     if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
     m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
     if (const char* gs = getenv("MMM_CTM_GRID_S")) m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * std::max(1, atoi(gs))));
@@ -2833,7 +3057,7 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : 0; out[5] = m->Ls; out[6] = m->cpl; out[7] = m->split ? m->nu_cpl : 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : (m->tdense ? 2 : 0); out[5] = m->Ls; out[6] = m->cpl; out[7] = m->split ? m->nu_cpl : 0;
     return MMM_OK;
 }
 

@@ -147,6 +147,7 @@ typedef struct {
     double* expE;                   /* arith = 1: exp(Elnphi) in the effective [m][k][v] layout, sum_m K_m V_m doubles */
     int Ls;                         /* lanes per document in the solve phase: L, or sum K for the packed device builds (0: = L) */
     int cpl;                        /* coordinates per lane in the solve phase (device builds with Ls * cpl = sum K; 0 / 1: one) */
+    int tdense;                     /* 1: the fused pass's theta phase runs over rows of counts on the device (k_ctm_theta_dense) */
 } orc_ctm;
 
 /* the pieces of one pass in device order (mmm_twin.c) */

@@ -303,13 +303,93 @@ void orc_twin_topics(orc_ctm* m, const double* sG)
 /* ---- fitdoc! for every document, in the order of k_ctm_estep: theta phase (zeta, theta, sumtheta, gamma slabs), then
  * the two LD_MMA solves (MMCTM.jl:450-455 -> :172-198, :156-170, :127-143; IMMCTM.jl:430-435) ------------------------- */
 /* sG: [GT] gamma statistics out.  theta (normalised) is stored into m->theta. */
-void orc_twin_estep(orc_ctm* m, double* sG)
+/* The theta phase of the fused pass over ROWS OF COUNTS (k_ctm_theta_dense of ctm.hip; dense corpora): one launch per modality, 16 lanes
+ * per document whatever sum K is, four documents per wave step, lane l owns the terms l, 16 + l, ... of every document it meets -- the
+ * gamma statistics of its terms are summed per lane over the documents of the wave (in step order), reach the wave's slab one document
+ * group at a time, the block's waves in order; sum theta: per lane over its slots in order, then lane k adds the 16 lanes' values in four
+ * interleaved chains; zeta: the 16-lane tree with the modality's topics in lanes 0..K_m-1.  Same per-element operations as the slab
+ * version below (MMCTM.jl:172-198, 110-117). */
+static void tw_theta_dense(orc_ctm* m, double* sumth, double* partial)
+{
+    const int D = m->D, M = m->M, MK = m->MK, NW = m->waves_e, grid = m->grid_e, GT = tw_GT(m);
+    for (int mod = 0; mod < M; ++mod) {
+        const int Km = m->K[mod], Vm = m->V[mod], off = tw_koff(m, mod), go = tw_goff(m, mod);
+        const int SL = Vm <= 32 ? 2 : (Vm <= 48 ? 3 : (Vm <= 96 ? 6 : 8)), Vp = 16 * SL;
+        const int64_t* dp = m->doc_ptr + (size_t)mod * (D + 1);
+        const int64_t estart = dp[0];
+        const double* tb = m->expE + go;
+        double* slabs = (double*)malloc(sizeof(double) * (size_t)NW * Km * Vm);
+        double* st = (double*)malloc(sizeof(double) * 64 * (size_t)SL * Km);            /* [lane][slot][k]: the registers of a wave */
+        double* cnt = (double*)malloc(sizeof(double) * (size_t)Vp);
+        int64_t* pos = (int64_t*)malloc(sizeof(int64_t) * (size_t)Vp);
+        for (int b = 0; b < grid; ++b) {
+            for (size_t i = 0; i < (size_t)NW * Km * Vm; ++i) slabs[i] = 0.0;
+            for (int w = 0; w < NW; ++w) {
+                for (size_t i = 0; i < 64 * (size_t)SL * Km; ++i) st[i] = 0.0;
+                for (int base = (b * NW + w) * 4; base < D; base += grid * NW * 4) {
+                    for (int g = 0; g < 4; ++g) {
+                        const int d = base + g;
+                        if (d >= D) continue;
+                        const double* lam = m->lambda + (size_t)MK * d + off; const double* nu = m->nu + (size_t)MK * d + off;
+                        double t[16], a[16], mx = -1e300;
+                        for (int l = 0; l < 16; ++l) t[l] = l < Km ? ar_exp(lam[l] + 0.5 * nu[l]) : 0.0;
+                        m->zeta[mod + (size_t)M * d] = tw_group_sum(t, 16);
+                        for (int kk = 0; kk < Km; ++kk) mx = fmax(mx, lam[kk]);
+                        for (int kk = 0; kk < Km; ++kk) a[kk] = ar_exp(lam[kk] - mx);
+                        for (int v = 0; v < Vp; ++v) { cnt[v] = 0.0; pos[v] = -1; }
+                        for (int64_t e = dp[d]; e < dp[d + 1]; ++e) { cnt[m->term[e]] = (double)m->count[e]; pos[m->term[e]] = e; }
+                        double acc[16][16];
+                        for (int l = 0; l < 16; ++l) {
+                            for (int kk = 0; kk < Km; ++kk) acc[l][kk] = 0.0;
+                            for (int q = 0; q < SL; ++q) {
+                                const int v = q * 16 + l;
+                                double ek[16], s = 0.0;
+                                for (int kk = 0; kk < Km; ++kk) { ek[kk] = a[kk] * (v < Vm ? tb[kk * Vm + v] : 1.0); s += ek[kk]; }
+                                const double inv = 1.0 / s, r = cnt[v] * inv;
+                                double* stq = st + ((size_t)(g * 16 + l) * SL + q) * Km;
+                                for (int kk = 0; kk < Km; ++kk) { acc[l][kk] = fma(ek[kk], r, acc[l][kk]); stq[kk] = fma(ek[kk], r, stq[kk]); }
+                                if (pos[v] >= 0) {
+                                    double* th = m->theta + tw_toff(m, mod) + (size_t)(pos[v] - estart) * Km;
+                                    for (int kk = 0; kk < Km; ++kk) th[kk] = ek[kk] * inv;
+                                }
+                            }
+                        }
+                        for (int kk = 0; kk < Km; ++kk) {
+                            double r4[4] = {0.0, 0.0, 0.0, 0.0};
+                            for (int j = 0; j < 16; j += 4) for (int c = 0; c < 4; ++c) r4[c] += acc[j + c][kk];
+                            sumth[(size_t)d * MK + off + kk] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+                        }
+                    }
+                }
+                double* slab = slabs + (size_t)w * Km * Vm;
+                for (int g = 0; g < 4; ++g)
+                    for (int l = 0; l < 16; ++l)
+                        for (int q = 0; q < SL; ++q) {
+                            const int v = q * 16 + l;
+                            if (v >= Vm) continue;
+                            const double* stq = st + ((size_t)(g * 16 + l) * SL + q) * Km;
+                            for (int kk = 0; kk < Km; ++kk) slab[(size_t)kk * Vm + v] += stq[kk];
+                        }
+            }
+            for (int i = 0; i < Km * Vm; ++i) {
+                double s = 0.0;
+                for (int w = 0; w < NW; ++w) s += slabs[(size_t)w * Km * Vm + i];
+                partial[(size_t)b * GT + go + i] = s;
+            }
+        }
+        free(slabs); free(st); free(cnt); free(pos);
+    }
+}
+
+static void tw_estep(orc_ctm* m, double* sG, int dense)
 {
     const int D = m->D, M = m->M, MK = m->MK, L = m->L, G = 64 / L, NW = m->waves_e, grid = m->grid_e, GT = tw_GT(m);
     double* sumth = (double*)calloc((size_t)D * MK + 1, sizeof(double));
     double* slabs = (double*)malloc(sizeof(double) * (size_t)NW * GT);
     double* partial = (double*)malloc(sizeof(double) * (size_t)grid * GT);
     double* pn = (double*)malloc(sizeof(double) * 64 * 32);        /* [lane][k] */
+    if (dense) tw_theta_dense(m, sumth, partial);
+    else
     for (int b = 0; b < grid; ++b) {
         for (size_t i = 0; i < (size_t)NW * GT; ++i) slabs[i] = 0.0;
         for (int w = 0; w < NW; ++w) {
@@ -415,6 +495,8 @@ void orc_twin_estep(orc_ctm* m, double* sG)
     }
     free(sumth); free(slabs); free(partial); free(pn);
 }
+
+void orc_twin_estep(orc_ctm* m, double* sG) { tw_estep(m, sG, 0); }      /* the theta phase by slabs: stage calls, frozen-topic passes */
 
 /* ---- sum lambda, sum nu, sum lambda lambda' : k_ctm_moments + k_reduce_partials ------------------------------------ */
 /* mom: [MK | MK | MK*MK] */
@@ -545,7 +627,7 @@ int orc_twin_pass(orc_ctm* m, int update_sigma)
     const int GT = tw_GT(m), n = m->MK;
     double* sG = (double*)malloc(sizeof(double) * ((size_t)GT + 2 * n + (size_t)n * n));
     double* mom = sG + GT;
-    orc_twin_estep(m, sG);
+    tw_estep(m, sG, m->tdense);          /* the fused pass: over rows of counts when the device handle says so (geometry) */
     orc_twin_moments(m, mom);
     const int rc = orc_twin_gauss(m, mom, update_sigma);
     orc_twin_topics(m, sG);

@@ -43,7 +43,7 @@ class OrcCtm(C.Structure):
         ("xtol_rule", C.c_int), ("max_eval", C.c_int),
         ("n_eval_lambda", C.c_int64), ("n_eval_nu", C.c_int64), ("n_solver_cap", C.c_int64),
         ("arith", C.c_int), ("L", C.c_int), ("grid_e", C.c_int), ("waves_e", C.c_int), ("grid_m", C.c_int),
-        ("nev_nu", C.c_void_p), ("nev_lambda", C.c_void_p), ("expE", C.c_void_p), ("Ls", C.c_int), ("cpl", C.c_int),
+        ("nev_nu", C.c_void_p), ("nev_lambda", C.c_void_p), ("expE", C.c_void_p), ("Ls", C.c_int), ("cpl", C.c_int), ("tdense", C.c_int),
     ]
 
 
@@ -509,6 +509,7 @@ class CtmOracle:
             s.L, s.grid_e, s.waves_e, s.grid_m = (int(geometry[k]) for k in ("L", "grid_e", "waves_e", "grid_m"))
             s.Ls = int(geometry.get("Ls", 0) or s.L)
             s.cpl = int(geometry.get("cpl", 1) or 1)
+            s.tdense = int(geometry.get("tdense", 0) or 0)
             assert s.L in (16, 32, 64) and s.L >= self.MK and s.grid_e >= 1 and s.waves_e >= 1 and s.grid_m >= 1
             assert (s.cpl == 1 and self.MK <= s.Ls <= 64) or (s.cpl > 1 and self.MK % s.cpl == 0 and s.Ls * s.cpl >= self.MK and s.Ls in (2, 4, 8, 16))
         self.s = s

@@ -430,6 +430,54 @@ def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, e
         _same_state(g, o, D, MK)
 
 
+@pytest.mark.parametrize("case", ["cfg4_shape", "cfg3_shape", "imm10", "mm16_12", "mm"])
+def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, monkeypatch, case):
+    """The fused pass's theta phase over rows of counts (k_ctm_theta_dense, round 3: dense corpora -- by default from 32 documents per CU,
+    forced here): 16 lanes per document, the gamma statistics in registers, one launch per modality.  The oracle mirrors its association
+    (geometry tdense); the fit must stay bit-identical -- state and per-document evaluation counts -- and whole fits stop in the same pass.
+    Empty documents (10 %) and a 48-term / 38-term / 24-term modality (3 / 3 / 2 slots per lane) included."""
+    monkeypatch.setenv("MMM_CTM_DENSE", "1")
+    if case == "imm10":
+        kw = dict(D=300, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
+    elif case == "mm16_12":
+        kw = dict(D=200, K=[16, 12], V=[40, 24], seed=64, means=[600, 200])
+    else:
+        kw = dict(_fit_case(case)); kw["D"] = min(kw["D"], 400)
+    D, MK = kw["D"], sum(kw["K"])
+    X, g, o = _pair(mmm, oracle, order="device", **kw)
+    assert g.geometry()["tdense"] == 1 and g.geometry()["wide"] == 0
+    for it in range(5):
+        mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 1, 1), g.ctx.h, "iterate")
+        assert o.twin_pass(True) == 0
+        st = g.solver_stats(per_doc=True)
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+        _same_state(g, o, D, MK)
+    # theta on demand (rebuilt by the slab-less kernel from lambda_{t-1} and the kept table) equals the oracle's stored theta
+    np.testing.assert_array_equal(g._get("theta"), o.theta)
+    X, g2, o2 = _pair(mmm, oracle, order="device", **kw)
+    ll_g = mmm.fit(g2, maxiter=30, tol=1e-4, verbose=False)
+    ll_o = o2.fit(maxiter=30, tol=1e-4)
+    assert len(ll_g) == len(ll_o) and g2.converged == o2.converged
+    _same_state(g2, o2, D, MK)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-10)
+    assert g2.elbo == pytest.approx(o2.elbo_value, rel=1e-9)
+
+
+def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(mmm, monkeypatch):
+    monkeypatch.setenv("MMM_CTM_DENSE", "1")
+    X, g0 = np_ref.synth_mm(60, [40, 24], [5, 4], seed=4, means=[600, 80])
+    X[3][0] = np.vstack([X[3][0], X[3][0][:1]])                   # a term listed twice: the reference treats the rows separately
+    g = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], X, γ0=g0)
+    assert g.geometry()["tdense"] == 0
+    Xs, g0s = np_ref.synth_mm(60, [400, 24], [5, 4], seed=4, means=[60, 80])      # 400 terms: beyond the rows; and sparse
+    gs = mmm.MMCTM([5, 4], [0.1, 0.1], [400, 24], Xs, γ0=g0s)
+    assert gs.geometry()["tdense"] == 0
+    monkeypatch.delenv("MMM_CTM_DENSE")
+    Xd, g0d = np_ref.synth_mm(60, [40, 24], [5, 4], seed=4, means=[600, 80])
+    gd = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], Xd, γ0=g0d)
+    assert gd.geometry()["tdense"] == 0                            # small corpora keep the slab kernel by default
+
+
 @pytest.mark.parametrize("case", ["mm", "mm_k20"])
 def test_fit_against_index_order_oracle(mmm, oracle, case):
     """The same fits against the index-order variant (libm exp, sequential sums).  The two CPU variants themselves drift apart by

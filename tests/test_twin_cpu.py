@@ -185,3 +185,21 @@ def test_geometry_changes_only_rounding(oracle):
         np.testing.assert_allclose(g, res[0][0], rtol=1e-12)
         np.testing.assert_allclose(z, res[0][2], rtol=1e-13)
         np.testing.assert_allclose(m, res[0][1], rtol=1e-6, atol=1e-9)
+
+
+def test_rows_of_counts_theta_phase_changes_only_rounding(oracle):
+    """tdense = 1 (the device's k_ctm_theta_dense: 16 lanes per document, statistics per lane over the documents, one sweep per
+    modality) is the slab version with its sums associated differently: one pass from the same state agrees to rounding -- zeta and
+    theta (no sums across documents) to 1e-13, the gamma statistics to 1e-12."""
+    K, V = [10, 10, 8], [96, 38, 32]
+    X, g0 = np_ref.synth_mm(150, V, K, seed=8, means=[2000, 150, 100], empty_frac=0.1)
+    g0f = np.concatenate([x.ravel() for x in g0])
+    res = []
+    for td in (0, 1):
+        o = oracle.CtmOracle(K, [0.1] * 3, X, V=V, gamma0=g0f, geometry=dict(L=32, waves_e=8, grid_e=3, grid_m=2, Ls=32, cpl=1, tdense=td))
+        assert o.twin_pass(True) == 0
+        res.append((o.gamma.copy(), o.zeta.copy(), o.theta.copy(), o.lam.copy()))
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-13)
+    np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-12)
+    assert not np.array_equal(res[1][0], res[0][0])          # ... and it IS another association

@@ -41,11 +41,11 @@ python3 tools/pmc_summary.py $P lda160k k_lda_estep_dense > $E/pmc_lda160k_estep
 python3 tools/pmc_summary.py $P lda640k k_lda_estep_dense > $E/pmc_lda640k_estep_dense.txt
 python3 tools/pmc_summary.py $P lda640k k_lda_reduce_ll_mstep > $E/pmc_lda640k_merged.txt
 python3 tools/pmc_summary.py $P cfg4 "k_ctm_solve_cpl<28" --json $E/traffic_ctm_solve_cfg4.json > $E/pmc_cfg4_solve.txt
-python3 tools/pmc_summary.py $P cfg4 "k_ctm_estep<32, 0" > $E/pmc_cfg4_theta.txt
+python3 tools/pmc_summary.py $P cfg4 "k_ctm_theta_dense<10, 6>" > $E/pmc_cfg4_theta.txt
 python3 tools/pmc_summary.py $P cfg4 k_ctm_loglik > $E/pmc_cfg4_loglik.txt
 python3 tools/pmc_summary.py $P cfg4 k_ctm_moments > $E/pmc_cfg4_moments.txt
 python3 tools/pmc_summary.py $P cfg5 k_ctm_solve_cpl --json $E/traffic_ctm_solve_cfg5.json > $E/pmc_cfg5_solve.txt
-python3 tools/pmc_summary.py $P cfg5 "k_ctm_estep<16, 0" > $E/pmc_cfg5_theta.txt
+python3 tools/pmc_summary.py $P cfg5 "k_ctm_theta_dense<10, 6>" > $E/pmc_cfg5_theta.txt
 python3 tools/pmc_summary.py $P cfg5 k_ctm_loglik > $E/pmc_cfg5_loglik.txt
 fi
 # the raw counter tables are large: only the summaries travel back
