@@ -642,7 +642,9 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
             double e[KMX], s = 0.0;
 #pragma unroll
             for (int k = 0; k < KMX; ++k) { e[k] = av[k] * tb[k]; s += e[k]; }
-            const double r = (double)c[q] * dev_div(1.0, s);
+            // (a document group beyond the corpus has a = 0, hence s = 0: 0 x (1 / 0) must not reach the statistics -- v_max with the
+            // smallest normal leaves every real s as it is)
+            const double r = (double)c[q] * dev_div(1.0, dev_max_raw(s, 2.2250738585072014e-308));
 #pragma unroll
             for (int k = 0; k < KMX; ++k) { acc[k] = fma(e[k], r, acc[k]); st[q][k] = fma(e[k], r, st[q][k]); }
 #pragma unroll

@@ -488,9 +488,6 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
 // whole launch (SL * KP doubles per lane) and reach the slab once, at the end.  Per term slot: a conflict-free 16-byte-per-lane read
 // of the term-major table and 2 KP + 16 f64 instructions; no atomics in the loop.  HBM per document: 4 Vp bytes of counts instead of
 // 8 bytes per nonzero.  Same formulas as k_lda_estep (LDA.jl:69-108); the sums are associated per lane, then lanes, waves, blocks.
-// v_max_f64 without the canonicalising v_max(x, x) the compiler puts before fmax()
-__device__ __forceinline__ double dev_max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
 template <int KP, int SL>
 __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
 {

@@ -153,6 +153,7 @@ typedef struct {
 /* the pieces of one pass in device order (mmm_twin.c) */
 void orc_twin_topics(orc_ctm* m, const double* sG);
 void orc_twin_estep(orc_ctm* m, double* sG);
+void orc_twin_estep_fused(orc_ctm* m, double* sG);     /* the E-step of a fused pass: over rows of counts when m->tdense */
 void orc_twin_moments(const orc_ctm* m, double* mom);
 int  orc_twin_gauss(orc_ctm* m, const double* mom, int do_sigma);
 int  orc_twin_pass(orc_ctm* m, int update_sigma);

@@ -497,6 +497,7 @@ static void tw_estep(orc_ctm* m, double* sG, int dense)
 }
 
 void orc_twin_estep(orc_ctm* m, double* sG) { tw_estep(m, sG, 0); }      /* the theta phase by slabs: stage calls, frozen-topic passes */
+void orc_twin_estep_fused(orc_ctm* m, double* sG) { tw_estep(m, sG, m->tdense); }      /* ... as the fused pass of the device handle runs it */
 
 /* ---- sum lambda, sum nu, sum lambda lambda' : k_ctm_moments + k_reduce_partials ------------------------------------ */
 /* mom: [MK | MK | MK*MK] */

@@ -119,6 +119,7 @@ def lib():
     L.orc_ctm_infer.argtypes = [P, C.c_int, C.c_int, C.c_double, f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_twin_topics.argtypes = [P, C.c_void_p]
     L.orc_twin_estep.argtypes = [P, f64p]
+    L.orc_twin_estep_fused.argtypes = [P, f64p]
     L.orc_twin_moments.argtypes = [P, f64p]
     L.orc_twin_gauss.argtypes = [P, f64p, C.c_int]; L.orc_twin_gauss.restype = C.c_int
     L.orc_twin_pass.argtypes = [P, C.c_int]; L.orc_twin_pass.restype = C.c_int
@@ -551,6 +552,10 @@ class CtmOracle:
     def twin_estep(self):
         assert self.s.arith
         sG = np.zeros(self.expE.size); lib().orc_twin_estep(C.byref(self.s), sG); return sG
+
+    def twin_estep_fused(self):
+        """the E-step as the device's FUSED pass runs it (theta phase over rows of counts when the geometry says tdense)"""
+        sG = np.zeros(self.expE.size); lib().orc_twin_estep_fused(C.byref(self.s), sG); return sG
 
     def fit(self, maxiter=100, tol=1e-4, update_sigma=True, auto_alpha=False):
         ll = np.zeros(self.M * maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()

@@ -110,7 +110,7 @@ def test_full_size_properties_and_slice(mmm, oracle, cfg, D):
     oracle.lib().orc_twin_topics(oracle.C.byref(o.s), None)          # Elnphi / exp table from the device's gamma
     o.mu[:] = mu_S; o.invSigma[:] = iS_S
     o.lam[:] = lam_S[d0:d0 + n].ravel(); o.nu[:] = nu_S[d0:d0 + n].ravel()
-    o.twin_estep()
+    o.twin_estep_fused()           # (the device's fused pass: theta phase over rows of counts at these sizes; per-document results do not depend on the grid)
     assert _bits(g.lam_matrix()[d0:d0 + n], o.lam) == 0 and _bits(g.nu_matrix()[d0:d0 + n], o.nu) == 0
     assert _bits(g._get("zeta").reshape(D, M)[d0:d0 + n], o.zeta) == 0
     th = g._get("theta")
