@@ -558,7 +558,7 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
 // of its terms stay in registers for the whole launch (SL KMX doubles) and reach the wave's slab once, at the end -- no LDS atomics, no
 // (term, count) loads: 2 bytes per term slot.  The scheme of k_lda_estep_dense (lda.hip) with the CTM's prologue (zeta, exp(lambda -
 // max)); same formulas and the same per-element operations as the theta phase of k_ctm_estep (MMCTM.jl:172-198, 110-117), other
-// association of the sums (the order-matched oracle mirrors it: oracle/mmm_twin.c, orc_twin_estep).
+// association of the sums (the order-matched CPU restatement of the parity tests mirrors it: tw_theta_dense).
 // LDS: [16 SL][KMX] table, term-major | [NW][Km Vm] slabs | [NW][4][KMX] a_k | [NW][64][KMX] sum-theta scratch
 template <int KMX, int SL>
 __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, const unsigned short* __restrict__ rows)

@@ -12,7 +12,7 @@
 //     of k_lda_estep_big); gamma statistics come from the posting sweep of the wide-table path (k_ctm_stats_terms<64>);
 //   * the Gaussian M-step inverts Sigma in device memory (block_inverse_big).
 // Same formulas, same operation order per coordinate as ctm.hip (MMCTM.jl:110-250, common.jl:11-36; LD_MMA as in mma_group); sums over a
-// document are wave butterflies, so results agree with the tuned path / the oracles to rounding, not bit for bit.  The kernels honour the
+// document are wave butterflies, so results agree with the tuned path / the CPU restatements to rounding, not bit for bit.  The kernels honour the
 // flags, the replica index (blockIdx.y) and the activity flags of CtmEArgs, so fit, the stage API, inference and restart batches all work.
 #pragma once
 
