@@ -1705,6 +1705,94 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     }
 }
 
+// The same sweep over ROWS OF COUNTS (round 3; handles whose theta phase runs over them, k_ctm_theta_dense): 16 lanes per document
+// whatever sum K is, four documents per wave step, one modality after the other; a lane reads its term slots' 16-bit counts (no
+// doc_ptr -> (term, count) round trip), its term's phi column as 16-byte pairs from a term-major copy in LDS, and keeps the document's
+// props in registers.  props and the ll numerators are outside the feedback loop of the fit (the next pass reads lambda, not props),
+// so their sums may be associated as this layout likes: they agree with k_ctm_loglik to rounding.
+struct DenseRows { const unsigned short* rows[kMaxM]; int SL[kMaxM]; int tpoff[kMaxM + 1]; };      // tpoff: prefix sums of 16 SL_m
+
+template <int KMX>
+__global__ __launch_bounds__(kBlockS) void k_ctm_loglik_dense(CtmDev c, const double* lam, const double* phieff, double* props, double* llpart,
+                                                              int compute_ll, const int* active, MstepArgs ga, int gauss, DenseRows dr)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double shw[kWavesS][kMaxM];
+    constexpr int L = 16, G = MMM_WAVE / L;
+    const CtmDims& dm = c.dm;
+    const int MK = dm.MK, M = dm.M, D = dm.D, GT = dm.GT;
+    if (active && !active[blockIdx.y]) return;
+    const int ndoc_blocks = gauss ? gridDim.x - 1 : gridDim.x;
+    if (gauss && blockIdx.x == 0) {      // block 0: update_μ! / update_Σ! of the same pass beside the sweep (see k_ctm_loglik)
+        MstepPtrs q;
+        if (mstep_replica(ga, q)) ctm_gauss_mstep<false>(ga, q, smem);
+        return;
+    }
+    const int bx = (int)blockIdx.x - gauss;
+    lam += (size_t)blockIdx.y * D * MK; phieff += (size_t)blockIdx.y * GT; llpart += (size_t)blockIdx.y * ndoc_blocks * M;
+    if (props) props += (size_t)blockIdx.y * D * MK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane / L, l = lane % L;
+    const int VT = dr.tpoff[M];                                     // term slots of all modalities
+    double* sPhi = smem;                                            // [VT][KMX] phi, term-major; slots beyond V_m hold 1, topics beyond K_m hold 0
+    double* sPr = sPhi + (size_t)VT * KMX + ((size_t)wid * G + g) * KMX;      // the group's props
+    const double* sLog = smem + (((size_t)VT * KMX + (size_t)kWavesS * G * KMX + 1) & ~(size_t)1);      // [256] log table, 16-byte aligned
+    if (compute_ll) {
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], Vm = dm.V[m], Vp = 16 * dr.SL[m];
+            const double* src = phieff + dm.goff[m];
+            for (int i = tid; i < Vp * KMX; i += kBlockS) {
+                const int v = i / KMX, k = i % KMX;
+                sPhi[(size_t)dr.tpoff[m] * KMX + i] = (k < Km) ? (v < Vm ? src[(size_t)k * Vm + v] : 1.0) : 0.0;
+            }
+        }
+        if (tid < MMM_LOGTAB_N) smem[(((size_t)VT * KMX + (size_t)kWavesS * G * KMX + 1) & ~(size_t)1) + tid] = g_mmm_logtab[tid];
+    }
+    __syncthreads();
+    double acc[kMaxM];
+    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.0;
+    for (int base = (bx * kWavesS + wid) * G; base < D; base += ndoc_blocks * kWavesS * G) {
+        const int d = base + g;
+        const bool valid = d < D;
+        for (int m = 0; m < M; ++m) {
+            const int Km = dm.K[m], off = dm.koff[m];
+            const bool in = l < Km;
+            const double x = (valid && in) ? lam[(size_t)d * MK + off + l] : 0.0;
+            // props = softmax(lambda block) (MMCTM.jl:145-154)
+            const double mx = group_max<L>(in ? x : -1e300);
+            const double e = in ? exp(x - mx) : 0.0;
+            const double pr = e / group_sum<L>(e);
+            if (valid && in && props) props[(size_t)d * MK + off + l] = pr;
+            if (!compute_ll) continue;
+            lds_wave_sync();
+            if (l < KMX) sPr[l] = pr;
+            lds_wave_sync();
+            double tv[KMX];
+#pragma unroll
+            for (int k = 0; k < KMX; ++k) tv[k] = sPr[k];
+            const int SLm = dr.SL[m], Vp = 16 * SLm;
+            const unsigned short* __restrict__ row = dr.rows[m] + (size_t)(valid ? d : 0) * Vp;
+            const double* tbm = sPhi + ((size_t)dr.tpoff[m] + l) * KMX;
+            double a = 0.0;
+            for (int q = 0; q < SLm; ++q) {
+                const double cnt = valid ? (double)row[q * L + l] : 0.0;
+                const double* tb = tbm + (size_t)q * L * KMX;
+                double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int k = 0; k + 1 < KMX; k += 2) { p0 = fma(tv[k], tb[k], p0); p1 = fma(tv[k + 1], tb[k + 1], p1); }
+                if (KMX & 1) p0 = fma(tv[KMX - 1], tb[KMX - 1], p0);
+                a = fma(cnt, dev_log_tab(p0 + p1, sLog), a);       // a slot without count: 0 x log(p), p > 0
+            }
+            acc[m] += a;
+        }
+    }
+    if (compute_ll) {
+        for (int m = 0; m < M; ++m) { const double tot = wave_sum(acc[m]); if (lane == 0) shw[wid][m] = tot; }
+        __syncthreads();
+        if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)bx * M + tid] = s; }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_sum_columns(const double* part, int n, int stride, double* out, size_t out_stride, const int* active)
 {
     const int j = blockIdx.x;
@@ -2274,6 +2362,8 @@ int materialise_theta(mmm_ctm* m)
     return MMM_OK;
 }
 
+inline bool getenv_ll_dense() { static const bool on = getenv("MMM_CTM_LL_DENSE") == nullptr || atoi(getenv("MMM_CTM_LL_DENSE")) != 0; return on; }
+
 // props (+ ll written to dst + r*dst_stride for every replica of the scope)
 // gauss_mu / gauss_sigma: also run update_μ! / update_Σ! of the pass in an extra block of the same launch (see k_ctm_loglik)
 int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool compute_ll, int gauss_mu = 0, int gauss_sigma = 0)
@@ -2288,6 +2378,21 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
         if (gauss) { int rc = run_mstep(m, sc, gauss_mu, gauss_sigma, 0, 0); if (rc) return rc; }
         hipLaunchKernelGGL(k_ctm_loglik_big, dim3(m->grid_s, sc.nrep), dim3(kBlockS), sizeof(double) * kWavesS * 64, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
                            m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active);
+    } else if (m->tdense && getenv_ll_dense()) {      // dense corpora: the sweep over rows of counts
+        DenseRows dr{};
+        int kmx = 8, vt = 0;
+        for (int i = 0; i < M; ++i) { dr.rows[i] = m->trows[i].p; dr.SL[i] = m->tSL[i]; dr.tpoff[i] = vt; vt += 16 * m->tSL[i]; kmx = std::max(kmx, theta_dense_kmx(m->dm.K[i])); }
+        dr.tpoff[M] = vt;
+        const size_t ldsd = sizeof(double) * std::max((size_t)vt * kmx + (size_t)kWavesS * 4 * kmx + 2 + MMM_LOGTAB_N, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
+        auto go = [&](auto kern) -> int {
+            if (ldsd > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
+            hipLaunchKernelGGL(kern, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), ldsd, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
+                               m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active,
+                               mstep_args(m, sc, gauss_mu, gauss_sigma, 0, 0), gauss, dr);
+            return MMM_OK;
+        };
+        int rc = kmx == 8 ? go(k_ctm_loglik_dense<8>) : (kmx == 10 ? go(k_ctm_loglik_dense<10>) : go(k_ctm_loglik_dense<16>));
+        if (rc) return rc;
     } else {
         auto kll = m->wide ? (m->L == 16 ? k_ctm_loglik<false, 16> : (m->L == 32 ? k_ctm_loglik<false, 32> : k_ctm_loglik<false, 64>))
                            : (m->L == 16 ? k_ctm_loglik<true, 16> : (m->L == 32 ? k_ctm_loglik<true, 32> : k_ctm_loglik<true, 64>));
