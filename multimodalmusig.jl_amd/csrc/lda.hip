@@ -51,10 +51,14 @@ struct LdaDev {
     double alpha, eta;
     const int2* ell;      // [D][V] rows padded with (-1, 0), or NULL: lets the ll blocks fetch a document's terms without first
                           // waiting for doc_ptr (built when V <= 128 and no document lists a term twice)
-    const int* dense;     // [D][Vp] rows of counts (the dense-row E-step's corpus), or NULL; the ll blocks then read these instead of ell
-    int Vp;
+    const int* dense;     // [D][16][Vp / 16] rows of counts, LANE-major: the Vp / 16 slots of lane l (terms l, 16 + l, ...) are contiguous, so a lane
+                          // requests its part of a row with one load (row_slot()); or NULL.  The ll blocks read these instead of ell
+    int Vp;               // slots per row (16 x slots per lane; 16-bit rows keep an even number of slots per lane)
     const unsigned short* dense16;   // the same rows as 16-bit counts (every count < 65536), or NULL: 2 bytes per term slot
 };
+
+// position of term slot w (lane w % 16, the lane's slot w / 16) in a lane-major row of 16 x slp slots
+__device__ __forceinline__ int row_slot(int w, int slp) { return (w & 15) * slp + (w >> 4); }
 
 struct LdaCtl {
     unsigned int ticket;
@@ -316,12 +320,13 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             const int* __restrict__ row = a.c.dense + (size_t)(valid ? d : 0) * a.c.Vp;
             const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid ? d : 0) * a.c.Vp;
             const bool h16 = a.c.dense16 != nullptr;
+            const int slp = a.c.Vp >> 4;
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= NCHR) c -= NCHR;
                 const int w = c * L + l;
                 const bool in = valid && j < NCHR && w < V;
-                const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
+                const int n = in ? (h16 ? (int)row16[row_slot(w, slp)] : row[row_slot(w, slp)]) : 0;
                 tcp[j] = make_int2(n > 0 ? w : -1, n);
             }
         } else if (rows && !drows && (SINGLE || first)) {
@@ -375,12 +380,13 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
                 const int* __restrict__ row = a.c.dense + (size_t)(valid1 ? d1 : 0) * a.c.Vp;
                 const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid1 ? d1 : 0) * a.c.Vp;
                 const bool h16 = a.c.dense16 != nullptr;
+                const int slp = a.c.Vp >> 4;
 #pragma unroll
                 for (int j = 0; j < PRE; ++j) {
                     int c = j + rot1; if (c >= NCHR) c -= NCHR;
                     const int w = c * L + l;
                     const bool in = valid1 && j < NCHR && w < V;
-                    const int n = in ? (h16 ? (int)row16[w] : row[w]) : 0;
+                    const int n = in ? (h16 ? (int)row16[row_slot(w, slp)] : row[row_slot(w, slp)]) : 0;
                     tcn[j] = make_int2(n > 0 ? w : -1, n);
                 }
             } else if (rows) {
@@ -488,7 +494,10 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
 // whole launch (SL * KP doubles per lane) and reach the slab once, at the end.  Per term slot: a conflict-free 16-byte-per-lane read
 // of the term-major table and 2 KP + 16 f64 instructions; no atomics in the loop.  HBM per document: 4 Vp bytes of counts instead of
 // 8 bytes per nonzero.  Same formulas as k_lda_estep (LDA.jl:69-108); the sums are associated per lane, then lanes, waves, blocks.
-template <int KP, int SL>
+template <class T> __device__ __forceinline__ T* at_byte(T* base, unsigned off) { return (T*)((char*)base + off); }   // uniform base + 32-bit lane offset: one VGPR per address
+typedef unsigned short mmm_us2 __attribute__((ext_vector_type(2)));
+
+template <int KP, int SL, bool C16>
 __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -513,12 +522,32 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
     const int stride = gridDim.x * NW * G;
     int base = (blockIdx.x * NW + wid) * G;
 
+    // The next step's gamma row and counts are requested a step ahead and must stay in flight across the step: nothing between a request and
+    // its use may wait for memory (vmcnt counts in order, so ONE scratch reload in the loop waits for every load before it -- the build
+    // that spilled 12 registers exposed the HBM round trip in every step: 640k documents 280 us at 53 % of its own issue time).  So: loads
+    // are unconditional (a clamped document index; masks are applied when the values are used), 16-bit counts land in register halves
+    // (SL / 2 registers), addresses are a uniform base + one 32-bit offset per lane (D K 8 and D Vp 4 bytes < 4 GB, checked at create).
+    constexpr int NC = C16 ? (SL + 1) / 2 : SL;
     int d = base + g;
     bool valid = d < D;
-    double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
-    int c[SL];
+    const int lk = l < K ? l : K - 1;
+    unsigned dl = valid ? (unsigned)d : 0u;
+    double gk = *at_byte(gam, (dl * (unsigned)K + lk) * 8u);
+    gk = (valid && l < K) ? gk : (l < K ? 1.0 : 0.0);
+    constexpr int SLs = C16 ? 2 * NC : SL;                  // slots a lane owns in a stored row
+    unsigned c[NC], cn[NC];
+    auto request = [&](unsigned* o, unsigned dd) {          // the lane's part of the row: NC consecutive 32-bit words, one load
+        const unsigned* row = C16 ? at_byte((const unsigned*)cnt16, (dd * (unsigned)(16 * SLs) + l * SLs) * 2u)
+                                  : at_byte((const unsigned*)cnt, (dd * (unsigned)(16 * SLs) + l * SLs) * 4u);
 #pragma unroll
-    for (int q = 0; q < SL; ++q) c[q] = valid ? (cnt16 ? (int)cnt16[(size_t)d * Vp + q * L + l] : cnt[(size_t)d * Vp + q * L + l]) : 0;
+        for (int j = 0; j < NC; ++j) o[j] = row[j];
+    };
+    auto take = [&](const unsigned* raw, bool ok) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) c[j] = ok ? raw[j] : 0u;
+    };
+    request(cn, dl);
+    take(cn, valid);
     for (int i = tid; i < Vp * KP; i += blockDim.x) {
         const int v = i / KP, k = i % KP;
         sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
@@ -531,26 +560,26 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         for (int k = 0; k < KP; ++k) st[q][k] = 0.0;
     bool first = true;
     for (;;) {
-        // ---- the next step's gamma row and counts are requested before this step computes
+        // ---- the next step's gamma row and counts are requested before this step's term phase
         const int dn = d + stride;
         const bool more = base + stride < D, validn = more && dn < D;
-        double gkn = l < K ? 1.0 : 0.0;
-        int cn[SL];
-        if (validn && l < K) gkn = gam[(size_t)dn * K + l];
-#pragma unroll
-        for (int q = 0; q < SL; ++q) cn[q] = validn ? (cnt16 ? (int)cnt16[(size_t)dn * Vp + q * L + l] : cnt[(size_t)dn * Vp + q * L + l]) : 0;
+        const unsigned dnl = validn ? (unsigned)dn : dl;
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k)
         const double S = group_sum<L>(gk);
         const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
         const double psS = __shfl(ps, g * L + K, MMM_WAVE);
         const double el = ps - psS;
-        if (l < KP) myA[l] = (l < K) ? ar_exp(el) : 0.0;
+        const double ak = (l < K) ? ar_exp(el) : 0.0;
+        if (l < KP) myA[l] = ak;
+        // (requested here, after the prologue: its polynomial constants overflow the scalar registers and one is reloaded from scratch in there)
+        const double gkn = *at_byte(gam, (dnl * (unsigned)K + lk) * 8u);
+        request(cn, dnl);
         if (first) {
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
             __syncthreads();
             first = false;
         } else lds_wave_sync();
-        if (valid && l < K) Eln[(size_t)d * K + l] = el;
+        if (valid && l < K) *at_byte(Eln, (dl * (unsigned)K + l) * 8u) = el;
         double acc[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[k] = 0.0;
@@ -562,17 +591,21 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             const double* tb = sT + (size_t)(q * L + l) * KP;
+            // three fused multiply-adds per (term slot, topic): the normaliser s = sum_k a_k B_kv, the lane's gamma sums WITHOUT their factor
+            // a_k (it is the document's, applied once after the lanes' sums have met) and the statistics WITHOUT their factor B_kv (it is
+            // the term's, the same for every document, applied once when the registers reach the slab)
             double b[KP], s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < KP; ++k) b[k] = av[k] * tb[k];
+            for (int k = 0; k < KP; ++k) b[k] = tb[k];
 #pragma unroll
-            for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
-            if (KP & 1) s0 += b[KP - 1];
+            for (int k = 0; k + 1 < KP; k += 2) { s0 = fma(av[k], b[k], s0); s1 = fma(av[k + 1], b[k + 1], s1); }
+            if (KP & 1) s0 = fma(av[KP - 1], b[KP - 1], s0);
             // a slot without mass must not see 0 x rcp(0) = NaN: with tiny priors the normaliser of a never-observed term underflows to 0.
             // (v_max with the smallest normal: the bits of every other quotient are unchanged; a select on the count costs 150 spilled registers here)
-            const double r = (double)c[q] * dev_rcp(dev_max_raw(s0 + s1, 2.2250738585072014e-308));
+            const unsigned cq = C16 ? ((q & 1) ? c[q / 2] >> 16 : c[q / 2] & 0xffffu) : c[q];
+            const double r = (double)cq * dev_rcp(dev_max_raw(s0 + s1, 2.2250738585072014e-308));
 #pragma unroll
-            for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
+            for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(av[k], r, st[q][k]); }
             // one slot at a time, its statistics updated here (left alone the compiler sinks the SL KP updates to the end of the step and keeps
             // every slot's products alive until then: 190 spilled registers)
 #pragma unroll
@@ -580,22 +613,35 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- the requested values are taken over HERE, before the step's last store: the compiler prices a wait for loads as if the
+        // (lane-conditional) stores after them had not been issued, i.e. as vmcnt(0) -- placed after the gamma store below it waited for
+        // that store's round trip in every step
+        const bool valid_now = valid;
+        const unsigned dl_now = dl;
+        // (the empty statements are the first use of the loaded registers and cannot move above the term phase's own)
+        double gk_next = gkn;
+        asm volatile("" : "+v"(gk_next) :: "memory");
+#pragma unroll
+        for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(cn[j]) :: "memory");
+        gk_next = (validn && l < K) ? gk_next : (l < K ? 1.0 : 0.0);
+        take(cn, validn);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(c[j]));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- gamma_{t+1} = alpha + sum_v phi_kv n_v: the lanes' sums meet in LDS, lane k of the group adds its column
 #pragma unroll
         for (int k = 0; k < KP; ++k) myR[(size_t)lane * KP + k] = acc[k];
         lds_wave_sync();
         if (l < K) {
             const double* col = myR + (size_t)(g * L) * KP + l;
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+            double r0 = col[0], r1 = col[KP], r2 = col[2 * KP], r3 = col[3 * KP];
 #pragma unroll
-            for (int j = 0; j < L; j += 4) { r0 += col[j * KP]; r1 += col[(j + 1) * KP]; r2 += col[(j + 2) * KP]; r3 += col[(j + 3) * KP]; }
-            if (valid) gnext[(size_t)d * K + l] = a.c.alpha + ((r0 + r1) + (r2 + r3));
+            for (int j = 4; j < L; j += 4) { r0 += col[j * KP]; r1 += col[(j + 1) * KP]; r2 += col[(j + 2) * KP]; r3 += col[(j + 3) * KP]; }
+            if (valid_now) *at_byte(gnext, (dl_now * (unsigned)K + l) * 8u) = fma(ak, (r0 + r1) + (r2 + r3), a.c.alpha);
         }
         base += stride;
         if (base >= D) break;
-        d = dn; valid = validn; gk = gkn;
-#pragma unroll
-        for (int q = 0; q < SL; ++q) c[q] = cn[q];
+        d = dn; valid = validn; dl = dnl; gk = gk_next;
         lds_wave_sync();
     }
     // ---- the lane's statistics reach the wave's slab, one document group at a time (a fixed order: groups 0..G-1)
@@ -607,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
                 const int v = q * L + l;
                 if (v < V) {
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] += st[q][k];
+                    for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] += st[q][k] * sT[(size_t)v * KP + k];
                 }
             }
         }
@@ -659,7 +705,7 @@ __global__ __launch_bounds__(768, 1) void k_lda_estep_dense32(EstepArgs a, const
     for (int sub = 0; sub < 2; ++sub) {
         const int dd = base + 2 * sub + h;
 #pragma unroll
-        for (int q = 0; q < S3; ++q) c[sub][q] = dd < D ? (cnt16 ? (int)cnt16[(size_t)dd * Vp + q * 32 + l32] : cnt[(size_t)dd * Vp + q * 32 + l32]) : 0;
+        for (int q = 0; q < S3; ++q) c[sub][q] = dd < D ? (cnt16 ? (int)cnt16[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)] : cnt[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)]) : 0;
     }
     for (int i = tid; i < Vp * KP; i += blockDim.x) {
         const int v = i / KP, k = i % KP;
@@ -682,7 +728,7 @@ __global__ __launch_bounds__(768, 1) void k_lda_estep_dense32(EstepArgs a, const
         for (int sub = 0; sub < 2; ++sub) {
             const int dd = bn + 2 * sub + h;
 #pragma unroll
-            for (int q = 0; q < S3; ++q) cn[sub][q] = (more && dd < D) ? (cnt16 ? (int)cnt16[(size_t)dd * Vp + q * 32 + l32] : cnt[(size_t)dd * Vp + q * 32 + l32]) : 0;
+            for (int q = 0; q < S3; ++q) cn[sub][q] = (more && dd < D) ? (cnt16 ? (int)cnt16[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)] : cnt[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)]) : 0;
         }
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k): four documents, 16 lanes each
         const double S = group_sum<16>(gk);
@@ -880,7 +926,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
         const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
         const unsigned short* __restrict__ row16 = c.dense16 + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
-        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[j * L + l] : row[j * L + l]) : make_int2(-1, 0);
+        for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[row_slot(j * L + l, c.Vp >> 4)] : row[row_slot(j * L + l, c.Vp >> 4)]) : make_int2(-1, 0);
     } else if (ell) {
         const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
@@ -906,7 +952,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
                     const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
                     const unsigned short* __restrict__ row16 = c.dense16 + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
-                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[j * L + l] : row[j * L + l]) : make_int2(-1, 0);
+                    for (int j = 0; j < PRE; ++j) pre[j] = (valid && j * L + l < V) ? make_int2(j * L + l, h16 ? (int)row16[row_slot(j * L + l, c.Vp >> 4)] : row[row_slot(j * L + l, c.Vp >> 4)]) : make_int2(-1, 0);
                 } else {
                     const int2* __restrict__ row = c.ell + (size_t)(valid ? d : 0) * V;
 #pragma unroll
@@ -2135,7 +2181,7 @@ struct mmm_lda {
     DevBuf<int64_t> doc_ptr; DevBuf<int2> tc, tc_ell;
     DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits (then cnt_dense is not built)
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
-    bool dense = false; int SL = 0; size_t lds_d = 0; bool attr_d = false;
+    bool dense = false; int SL = 0, SLs = 0; size_t lds_d = 0; bool attr_d = false;     // SL: term slots per lane of a 16-lane group; SLs: as stored (LdaDev::Vp / 16)
     bool dense32 = false;       // ... its 32-lane build (k_lda_estep_dense32: 12-wave blocks, three waves per SIMD)
     bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
@@ -2174,7 +2220,7 @@ struct mmm_lda {
     IldaDesc ids{};
     DevBuf<int> features;
     DevBuf<double> ilam[3], iEln[3], ibeta[3];      // model layout, ring like the V x K tables
-    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, (drows && !cnt16.p) ? cnt_dense.p : nullptr, 16 * SL, cnt16.p}; }
+    LdaDev dev() const { return LdaDev{D, V, K, doc_ptr.p, tc.p, alpha, eta, tc_ell.p, (drows && !cnt16.p) ? cnt_dense.p : nullptr, 16 * SLs, cnt16.p}; }
     int cur() const { return t % 3; }
     Ring ring(DevBuf<double>* b) const { return Ring{{b[0].p, b[1].p, b[2].p}}; }
 };
@@ -2256,7 +2302,8 @@ int go_dense(mmm_lda* m, const EstepArgs& a)
 {
     if constexpr (KPV * SLV <= 64) {
         mmm_ctx* ctx = m->ctx;
-        auto k = k_lda_estep_dense<KPV, SLV>;
+        const bool c16 = m->cnt16.p != nullptr;
+        auto k = c16 ? k_lda_estep_dense<KPV, SLV, true> : k_lda_estep_dense<KPV, SLV, false>;
         if (!m->attr_d) { int rc = set_lds(ctx, k, m->lds_d); if (rc) return rc; m->attr_d = true; }
         hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p, (const unsigned short*)m->cnt16.p);
         return MMM_OK;
@@ -2769,7 +2816,8 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) { if (seen[(size_t)term[e]] == d) { dup = true; break; } seen[(size_t)term[e]] = d; }
         }
         const bool big = D >= 192 * ctx->num_cu;      // measured on MI355X (K = 10, V = 96): 40k documents 59.1 vs 58.3 us per iteration for the CSR sweep, 80k 85.6 vs 98.4
-        dense = shape && !dup && dmode != 0 && (dmode > 0 || (big && dense_enough));
+        const bool off32 = (int64_t)D * K * 8 < ((int64_t)1 << 32) && (int64_t)D * 16 * (SL + 1) * 4 < ((int64_t)1 << 32);   // the build's 32-bit byte offsets
+        dense = shape && !dup && off32 && dmode != 0 && (dmode > 0 || (big && dense_enough));
         drows = drows_env && rshape && !dup && dense_enough;
     }
     const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
@@ -2860,19 +2908,21 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     int maxcount = 0;
     for (int64_t e = 0; e < nnz; ++e) maxcount = std::max(maxcount, count[e]);
     if (m->drows && rows16_env && maxcount < 65536) {
-        const int Vp = 16 * SL;
+        m->SLs = (SL + 1) & ~1;          // lane-major rows (LdaDev::dense): an even number of 16-bit slots per lane
+        const int Vp = 16 * m->SLs;
         std::vector<unsigned short> rows((size_t)D * Vp, 0);
         for (int d = 0; d < D; ++d)
-            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + term[e]] = (unsigned short)count[e];
+            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + (term[e] & 15) * m->SLs + (term[e] >> 4)] = (unsigned short)count[e];
         hipError_t e_ = m->cnt16.alloc(rows.size());
         if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(cnt16): %s", hipGetErrorString(e_)); return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(m->cnt16.p, rows.data(), sizeof(unsigned short) * rows.size(), hipMemcpyHostToDevice, st));
         MMM_HIP(ctx, hipStreamSynchronize(st));
     } else if (m->drows) {
+        m->SLs = SL;
         const int Vp = 16 * SL;
         std::vector<int> rows((size_t)D * Vp, 0);
         for (int d = 0; d < D; ++d)
-            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + term[e]] = count[e];
+            for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + (term[e] & 15) * SL + (term[e] >> 4)] = count[e];
         hipError_t e_ = m->cnt_dense.alloc(rows.size());
         if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(cnt_dense): %s", hipGetErrorString(e_)); return rc; }
         MMM_HIP(ctx, hipMemcpyAsync(m->cnt_dense.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
@@ -3136,7 +3186,7 @@ int mmm_lda_geometry(const mmm_lda* m, int out[8])
 int mmm_lda_row_bytes(const mmm_lda* m)
 {
     if (!m || m->wide) return 0;
-    if (m->drows) return (m->cnt16.p ? 2 : 4) * 16 * m->SL;
+    if (m->drows) return (m->cnt16.p ? 2 : 4) * 16 * m->SLs;
     if (m->tc_ell.p && !m->dense) return 8 * m->V;
     return 0;
 }
