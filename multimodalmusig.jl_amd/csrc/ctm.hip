@@ -559,7 +559,9 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
 // (term, count) loads: 2 bytes per term slot.  The scheme of k_lda_estep_dense (lda.hip) with the CTM's prologue (zeta, exp(lambda -
 // max)); same formulas and the same per-element operations as the theta phase of k_ctm_estep (MMCTM.jl:172-198, 110-117), other
 // association of the sums (the order-matched CPU restatement of the parity tests mirrors it: tw_theta_dense).
-// LDS: [16 SL][KMX] table, term-major | [NW][Km Vm] slabs | [NW][4][KMX] a_k | [NW][64][KMX] sum-theta scratch
+// LDS: [16 SL][KMX] table, term-major | [NW][16 SL][KMX] slabs, term-major | [NW][4][KMX] a_k | [NW][64][KMX] sum-theta scratch
+template <class T> __device__ __forceinline__ T* at_byte(T* base, unsigned off) { return (T*)((char*)base + off); }   // uniform base + 32-bit lane offset: one VGPR per address
+
 template <int KMX, int SL>
 __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, const unsigned short* __restrict__ rows)
 {
@@ -581,10 +583,10 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
     const int g = lane / L, l = lane % L;
     const int KV = Km * Vm;
     double* sT = smem;                                   // [Vp][KMX]; rows v >= Vm hold 1 (their counts are 0), topics k >= Km hold 0
-    double* sSlab = sT + (size_t)Vp * KMX;               // [NW][Km][Vm]
-    double* sA = sSlab + (size_t)NW * KV;                // [NW][G][KMX]
+    double* sSlab = sT + (size_t)Vp * KMX;               // [NW][Vp][KMX], term-major like the table (written once, in the epilogue)
+    double* sA = sSlab + (size_t)NW * Vp * KMX;          // [NW][G][KMX]
     double* sR = sA + (size_t)NW * G * KMX;              // [NW][64][KMX]
-    double* slab = sSlab + (size_t)wid * KV;
+    double* slab = sSlab + (size_t)wid * Vp * KMX;
     double* myA = sA + ((size_t)wid * G + g) * KMX;
     double* myR = sR + (size_t)wid * MMM_WAVE * KMX;
     const double* __restrict__ tbg = p_expE + dm.goff[m];
@@ -592,7 +594,6 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
         const int v = i / KMX, k = i % KMX;
         sT[i] = (k < Km) ? (v < Vm ? tbg[(size_t)k * Vm + v] : 1.0) : 0.0;
     }
-    for (int i = tid; i < NW * KV; i += blockDim.x) sSlab[i] = 0.0;
     if (a.expE_keep && blockIdx.x == 0 && m == 0) for (int i = tid; i < GT; i += blockDim.x) a.expE_keep[rep * GT + i] = p_expE[i];
     __syncthreads();
     double st[SL][KMX];
@@ -603,33 +604,51 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
     const int flags = a.flags;
     const int stride = gridDim.x * NW * G;
     int base = (blockIdx.x * NW + wid) * G;
-    // the first step's lambda row and counts
+    // The next step's lambda (nu) row and counts are requested a step ahead and must STAY in flight across the term phase: vmcnt counts in
+    // order, so nothing between a request and its use may wait for memory (k_lda_estep_dense, lda.hip, has the measurements).  Hence: loads
+    // are unconditional (clamped document and topic index; the masks are applied when the values are taken over), a lane's part of a row
+    // of counts is ONE load of NC 32-bit words (lane-major rows), addresses are a uniform base + a 32-bit offset (D sum K 8 bytes < 4 GB,
+    // checked at create), the request follows the prologue, and the values are taken over before the step's last (lane-conditional) store.
+    // (PIN: where the registers allow it the first use of the loaded values is pinned behind the term phase; the 60-statistic builds
+    // would spill the statistics for it -- there the compiler takes the values over early and the block's other wave covers the wait)
+    constexpr int NC = (SL + 1) / 2, SLs = 2 * NC;
+    constexpr bool PIN = KMX * SL <= 32;
+    const int lk = l < Km ? l : Km - 1;
+    const bool zeta = (flags & F_ZETA) != 0;
     int d = base + g;
     bool valid = d < D;
-    double lam = (valid && l < Km) ? p_lam_in[(size_t)d * MK + off + l] : 0.0;
-    double nu = ((flags & F_ZETA) && valid && l < Km) ? p_nu[(size_t)d * MK + off + l] : 1.0;
-    int c[SL];
+    unsigned dl = valid ? (unsigned)d : 0u;
+    unsigned c[NC], cn[NC];
+    auto request = [&](unsigned dd, double& lam_o, double& nu_o, unsigned* o) {
+        const unsigned ob = (dd * (unsigned)MK + (unsigned)(off + lk)) * 8u;
+        lam_o = *at_byte(p_lam_in, ob);
+        if (zeta) nu_o = *at_byte(p_nu, ob);
+        const unsigned* row = at_byte((const unsigned*)rows, (dd * (unsigned)(16 * SLs) + l * SLs) * 2u);
 #pragma unroll
-    for (int q = 0; q < SL; ++q) c[q] = valid ? (int)rows[(size_t)d * Vp + q * L + l] : 0;
+        for (int j = 0; j < NC; ++j) o[j] = row[j];
+    };
+    double lam, nu = 1.0;
+    request(dl, lam, nu, cn);
+    lam = (valid && l < Km) ? lam : 0.0;
+    nu = (zeta && valid && l < Km) ? nu : 1.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) c[j] = valid ? cn[j] : 0u;
     for (; base < D; base += stride) {
-        // the next step's loads go out before this step computes
         const int dn = d + stride;
         const bool validn = base + stride < D && dn < D;
-        double lamn = 0.0, nun = 1.0;
-        int cn[SL];
-        if (validn && l < Km) { lamn = p_lam_in[(size_t)dn * MK + off + l]; if (flags & F_ZETA) nun = p_nu[(size_t)dn * MK + off + l]; }
-#pragma unroll
-        for (int q = 0; q < SL; ++q) cn[q] = validn ? (int)rows[(size_t)dn * Vp + q * L + l] : 0;
+        const unsigned dnl = validn ? (unsigned)dn : dl;
         const bool act = valid && l < Km;
         if (a.lam_keep && act) a.lam_keep[(rep * D + d) * MK + off + l] = lam;
         if (flags & F_ZETA) {       // update_ζ! (MMCTM.jl:172-181)
             const double zm = group_sum<L>(act ? ar_exp(lam + 0.5 * nu) : 0.0);
-            if (valid && l == 0) p_zeta[(size_t)d * M + m] = zm;
+            if (valid && l == 0) *at_byte(p_zeta, (dl * (unsigned)M + (unsigned)m) * 8u) = zm;
         }
         const double mx = group_max<L>(act ? lam : -1e300);
         lds_wave_sync();
         if (l < KMX) myA[l] = act ? ar_exp(lam - mx) : 0.0;
         lds_wave_sync();
+        double lamn, nun = 1.0;
+        request(dnl, lamn, nun, cn);
         double av[KMX], acc[KMX];
 #pragma unroll
         for (int k = 0; k < KMX; ++k) { av[k] = myA[k]; acc[k] = 0.0; }
@@ -644,12 +663,32 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
             for (int k = 0; k < KMX; ++k) { e[k] = av[k] * tb[k]; s += e[k]; }
             // (a document group beyond the corpus has a = 0, hence s = 0: 0 x (1 / 0) must not reach the statistics -- v_max with the
             // smallest normal leaves every real s as it is)
-            const double r = (double)c[q] * dev_div(1.0, dev_max_raw(s, 2.2250738585072014e-308));
+            const unsigned cq = (q & 1) ? c[q / 2] >> 16 : c[q / 2] & 0xffffu;
+            const double r = (double)cq * dev_div(1.0, dev_max_raw(s, 2.2250738585072014e-308));
 #pragma unroll
             for (int k = 0; k < KMX; ++k) { acc[k] = fma(e[k], r, acc[k]); st[q][k] = fma(e[k], r, st[q][k]); }
 #pragma unroll
             for (int k = 0; k < KMX; ++k) asm volatile("" : "+v"(st[q][k]));
             asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the requested values are taken over here (the empty statements are the first use of the loaded registers and stay behind the term
+        // phase's own)
+        if (PIN) {
+            asm volatile("" : "+v"(lamn) :: "memory");
+            if (zeta) asm volatile("" : "+v"(nun) :: "memory");
+#pragma unroll
+            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(cn[j]) :: "memory");
+        }
+        const bool valid_now = valid;
+        const unsigned dl_now = dl;
+        lam = (validn && l < Km) ? lamn : 0.0;
+        nu = (zeta && validn && l < Km) ? nun : 1.0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) c[j] = validn ? cn[j] : 0u;
+        if (PIN) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(c[j]));
             __builtin_amdgcn_sched_barrier(0);
         }
         // sumθ_k (MMCTM.jl:110-117): the lanes' sums meet in LDS, lane k of the group adds its column of the 16 lanes' values
@@ -661,33 +700,32 @@ __global__ __launch_bounds__(512, 2) void k_ctm_theta_dense(CtmEArgs a, int m, c
             double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
 #pragma unroll
             for (int j = 0; j < L; j += 4) { r0 += col[j * KMX]; r1 += col[(j + 1) * KMX]; r2 += col[(j + 2) * KMX]; r3 += col[(j + 3) * KMX]; }
-            if (valid) p_sumth[(size_t)d * MK + off + l] = (r0 + r1) + (r2 + r3);
+            if (valid_now) *at_byte(p_sumth, (dl_now * (unsigned)MK + (unsigned)(off + l)) * 8u) = (r0 + r1) + (r2 + r3);
         }
-        d = dn; valid = validn; lam = lamn; nu = nun;
-#pragma unroll
-        for (int q = 0; q < SL; ++q) c[q] = cn[q];
+        d = dn; valid = validn; dl = dnl;
         lds_wave_sync();
     }
-    // the lane's statistics reach the wave's slab, one document group at a time (groups 0..3), then the block's waves in order
+    // the wave's statistics: the four document groups' registers are added across the rows of the wave (rows_sum4: (g0 + g2) + (g1 + g3), no
+    // LDS) and the first group's lanes store them -- the slab is term-major with padded bounds like the table, written once (no zero
+    // fill, no read-modify-write; 16-byte pairs at compile-time offsets; k_lda_estep_dense has the measurements); then the block's waves
+    // in order
 #pragma unroll
-    for (int gg = 0; gg < G; ++gg) {
-        if (g == gg) {
+    for (int q = 0; q < SL; ++q) {
+        double* sl = slab + (size_t)(q * L + l) * KMX;
+        double t[KMX];
 #pragma unroll
-            for (int q = 0; q < SL; ++q) {
-                const int v = q * L + l;
-                if (v < Vm) {
+        for (int k = 0; k < KMX; ++k) t[k] = rows_sum4(st[q][k]);
+        if (g == 0) {
 #pragma unroll
-                    for (int k = 0; k < KMX; ++k) if (k < Km) slab[(size_t)k * Vm + v] += st[q][k];
-                }
-            }
+            for (int k = 0; k < KMX; ++k) sl[k] = t[k];
         }
-        lds_wave_sync();
     }
     __syncthreads();
     double* out = p_partial + (size_t)blockIdx.x * GT + dm.goff[m];
     for (int i = tid; i < KV; i += blockDim.x) {
+        const int kk = i / Vm, v = i - kk * Vm;
         double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * KV + i];
+        for (int w = 0; w < NW; ++w) s += sSlab[((size_t)w * Vp + v) * KMX + kk];
         out[i] = s;
     }
 }
@@ -1770,12 +1808,12 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik_dense(CtmDev c, const do
             double tv[KMX];
 #pragma unroll
             for (int k = 0; k < KMX; ++k) tv[k] = sPr[k];
-            const int SLm = dr.SL[m], Vp = 16 * SLm;
-            const unsigned short* __restrict__ row = dr.rows[m] + (size_t)(valid ? d : 0) * Vp;
+            const int SLm = dr.SL[m], sls = (SLm + 1) & ~1;
+            const unsigned short* __restrict__ row = dr.rows[m] + ((size_t)(valid ? d : 0) * 16 + l) * sls;     // lane-major rows
             const double* tbm = sPhi + ((size_t)dr.tpoff[m] + l) * KMX;
             double a = 0.0;
             for (int q = 0; q < SLm; ++q) {
-                const double cnt = valid ? (double)row[q * L + l] : 0.0;
+                const double cnt = valid ? (double)row[q] : 0.0;
                 const double* tb = tbm + (size_t)q * L * KMX;
                 double p0 = 0.0, p1 = 0.0;
 #pragma unroll
@@ -2020,7 +2058,7 @@ struct mmm_ctm {
     DevBuf<int> claim;             // [2][R][32]: document counters of the split nu / lambda launches
     // dense corpora: the fused pass's theta phase over rows of 16-bit counts, one launch per modality (k_ctm_theta_dense)
     bool tdense = false; int tSL[kMaxM] = {0};
-    DevBuf<unsigned short> trows[kMaxM];      // [D][16 SL_m]
+    DevBuf<unsigned short> trows[kMaxM];      // [D][16][SL_m rounded up to even]: lane-major rows of counts (a lane's part of a row is one load)
     bool big = false;              // 64 < sum K <= 256: the generic kernels of ctm_big.cuh (one wave per document, several coordinates per lane)
     DevBuf<double> big_scratch;    // [R][2 MK^2]: Sigma and its inverse during the Gaussian M-step / the ELBO's logdet
     int stop_enable = 0; double stop_tol = 0.0;     // set by fit_scope around a pass: the ll kernels apply the stopping rule
@@ -2114,8 +2152,8 @@ int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
 
 size_t theta_dense_lds(const mmm_ctm* m, int i, int kmx)
 {
-    const int NW = m->waves_e, Km = m->dm.K[i], Vm = m->dm.V[i];
-    return sizeof(double) * ((size_t)16 * m->tSL[i] * kmx + (size_t)NW * Km * Vm + (size_t)NW * 4 * kmx + (size_t)NW * MMM_WAVE * kmx);
+    const int NW = m->waves_e;
+    return sizeof(double) * ((size_t)16 * m->tSL[i] * kmx + (size_t)NW * 16 * m->tSL[i] * kmx + (size_t)NW * 4 * kmx + (size_t)NW * MMM_WAVE * kmx);
 }
 
 inline int theta_dense_kmx(int Km) { return Km <= 8 ? 8 : (Km <= 10 ? 10 : 16); }
@@ -2689,7 +2727,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     {
         const char* de = getenv("MMM_CTM_DENSE");
         const int dmode = de ? atoi(de) : -1;
-        bool ok = !m->wide && !m->big && dmode != 0 && D > 0;
+        bool ok = !m->wide && !m->big && dmode != 0 && D > 0 && (int64_t)D * dm.MK * 8 < ((int64_t)1 << 32);      // (k_ctm_theta_dense: 32-bit byte offsets)
         int64_t present = 0, cells = 0;
         for (int i = 0; i < M && ok; ++i) {
             const int sl = dm.V[i] <= 32 ? 2 : (dm.V[i] <= 48 ? 3 : (dm.V[i] <= 96 ? 6 : (dm.V[i] <= 128 ? 8 : 0)));
@@ -2701,7 +2739,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         if (ok && dmode < 0 && D < 32 * ctx->num_cu) ok = false;
         std::vector<std::vector<unsigned short>> rows((size_t)M);
         for (int i = 0; i < M && ok; ++i) {
-            const int Vp = 16 * m->tSL[i];
+            const int sls = (m->tSL[i] + 1) & ~1, Vp = 16 * sls;     // lane-major: the slots of lane l (terms l, 16 + l, ...) are contiguous, an even number
             rows[i].assign((size_t)D * Vp, 0);
             std::vector<int> seen((size_t)dm.V[i], -1);
             const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
@@ -2709,7 +2747,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
                 for (int64_t e = dp[d]; e < dp[d + 1]; ++e) {
                     if (seen[(size_t)term[e]] == d || count[e] >= 65536) { ok = false; break; }
                     seen[(size_t)term[e]] = d;
-                    rows[i][(size_t)d * Vp + term[e]] = (unsigned short)count[e];
+                    rows[i][(size_t)d * Vp + (term[e] & 15) * sls + (term[e] >> 4)] = (unsigned short)count[e];
                 }
         }
         if (ok) {

@@ -169,6 +169,23 @@ __device__ __forceinline__ double dpp_mov_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Sum over the four 16-lane rows of a wave, per row lane, valid in every lane: (row 0 + row 2) + (row 1 + row 3).  gfx950's row swaps
+// (v_permlane32_swap: the upper 32 lanes of one register against the lower 32 of another; v_permlane16_swap: odd against even rows)
+// applied to two copies of the value put lane i + 32 (then i + 16) beside lane i without a trip through LDS: 2 moves, 2 swaps and an
+// add per stage.
+typedef unsigned mmm_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double rows_sum4(double x)
+{
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    mmm_u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    mmm_u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const double s = __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+    lo = (unsigned)__double2loint(s); hi = (unsigned)__double2hiint(s);
+    a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
 // sum over each aligned group of L lanes (L = 16, 32 or 64); every lane of the group ends with the group total.
 // The 16-lane part stays inside a DPP row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
 template <int L>

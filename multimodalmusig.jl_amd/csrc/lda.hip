@@ -502,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int L = 16, G = MMM_WAVE / L, Vp = L * SL;
+    MMM_STAMP(0);
     const int t = a.t;
     const int stop = a.ctl->stop;
     const double* __restrict__ gam = a.gamma.s[t % 3];
@@ -513,10 +514,10 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / L, l = lane % L;
     double* sT = smem;                                   // [Vp][KP] exp(Elnbeta_{t-1}), term-major; rows v >= V hold 1 (their counts are 0)
-    double* sSlab = sT + (size_t)Vp * KP;                // [NW][K][V]
-    double* sA = sSlab + (size_t)NW * K * V;             // [NW][G][KP]
+    double* sSlab = sT + (size_t)Vp * KP;                // [NW][Vp][KP], term-major like the table (written once, in the epilogue)
+    double* sA = sSlab + (size_t)NW * Vp * KP;           // [NW][G][KP]
     double* sR = sA + (size_t)NW * G * KP;               // [NW][64][KP] gamma sums, lane-major
-    double* slab = sSlab + (size_t)wid * K * V;
+    double* slab = sSlab + (size_t)wid * Vp * KP;
     double* myA = sA + ((size_t)wid * G + g) * KP;
     double* myR = sR + (size_t)wid * MMM_WAVE * KP;
     const int stride = gridDim.x * NW * G;
@@ -552,7 +553,6 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         const int v = i / KP, k = i % KP;
         sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
     }
-    for (int i = tid; i < NW * K * V; i += blockDim.x) sSlab[i] = 0.0;
     double st[SL][KP];
 #pragma unroll
     for (int q = 0; q < SL; ++q)
@@ -578,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
             __syncthreads();
             first = false;
+            MMM_STAMP(1);
         } else lds_wave_sync();
         if (valid && l < K) *at_byte(Eln, (dl * (unsigned)K + l) * 8u) = el;
         double acc[KP];
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+        MMM_STAMP(2);
         // ---- the requested values are taken over HERE, before the step's last store: the compiler prices a wait for loads as if the
         // (lane-conditional) stores after them had not been issued, i.e. as vmcnt(0) -- placed after the gamma store below it waited for
         // that store's round trip in every step
@@ -644,28 +646,36 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
         d = dn; valid = validn; dl = dnl; gk = gk_next;
         lds_wave_sync();
     }
-    // ---- the lane's statistics reach the wave's slab, one document group at a time (a fixed order: groups 0..G-1)
+    MMM_STAMP(3);
+    // ---- the wave's statistics: the four document groups' registers are added across the rows of the wave (rows_sum4: (g0 + g2) + (g1 + g3),
+    // no LDS), multiplied by the term's table entry once, and the first group's lanes store them -- the slab is term-major with padded
+    // bounds like the table, written once (no zero fill, no read-modify-write; 16-byte pairs at compile-time offsets).  (One group at a
+    // time through LDS with run-time bounds, every entry its own round trip: 19 of the 27 us of a 15k-document launch,
+    // tools/diag_dense_stamps.py; batched per term slot: 6.4.)
 #pragma unroll
-    for (int gg = 0; gg < G; ++gg) {
-        if (g == gg) {
+    for (int q = 0; q < SL; ++q) {
+        double* sl = slab + (size_t)(q * L + l) * KP;
+        const double* tb = sT + (size_t)(q * L + l) * KP;
+        double t[KP];
 #pragma unroll
-            for (int q = 0; q < SL; ++q) {
-                const int v = q * L + l;
-                if (v < V) {
+        for (int k = 0; k < KP; ++k) t[k] = rows_sum4(st[q][k]) * tb[k];
+        if (g == 0) {
 #pragma unroll
-                    for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] += st[q][k] * sT[(size_t)v * KP + k];
-                }
-            }
+            for (int k = 0; k < KP; ++k) sl[k] = t[k];
         }
-        lds_wave_sync();
     }
+    MMM_STAMP(4);
     __syncthreads();
+    MMM_STAMP(5);
     double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
     for (int i = tid; i < K * V; i += blockDim.x) {
+        const int kk = i / V, v = i - kk * V;
         double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += sSlab[(size_t)w * K * V + i];
-        out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = s;
+        for (int w = 0; w < NW; ++w) s += sSlab[((size_t)w * Vp + v) * KP + kk];
+        out[a.pstride == V ? i : kk * a.pstride + v] = s;
     }
+    MMM_STAMP(6);
+    MMM_STAMP(7);
 }
 
 // The same data flow with 32-lane document groups in the term phase (round 3): a lane owns S3 = Vp / 32 term slots, HALF the statistics
@@ -2850,7 +2860,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     if (m->dense)      // [16 SL][KP] table | [waves][K][V] slabs | [waves][G][KP] a_k | [waves][64][KP] gamma sums
-        m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * K * V + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
+        m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * 16 * SL * KP + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
     {   // the 32-lane build: slots per lane even in the 16-lane count (rows of 32 S3 counts), sum K x slots within its registers, one
         // 12-wave block per CU.  LDS: [32 S3][KP] table | [12][4][KP] a_k | [12][64][KP] gamma sums (later: slabs).  MMM_LDA_DENSE32=0: the 16-lane build
         // Measured (round 3, K = 10, V = 96, 16-bit rows): 160k documents 90.0 vs 80.9 us, 640k 337 vs 280 us -- SLOWER than the 16-lane

@@ -361,15 +361,16 @@ static void tw_theta_dense(orc_ctm* m, double* sumth, double* partial)
                         }
                     }
                 }
+                /* the wave's four document groups meet across its rows: (g0 + g2) + (g1 + g3) */
                 double* slab = slabs + (size_t)w * Km * Vm;
-                for (int g = 0; g < 4; ++g)
-                    for (int l = 0; l < 16; ++l)
-                        for (int q = 0; q < SL; ++q) {
-                            const int v = q * 16 + l;
-                            if (v >= Vm) continue;
-                            const double* stq = st + ((size_t)(g * 16 + l) * SL + q) * Km;
-                            for (int kk = 0; kk < Km; ++kk) slab[(size_t)kk * Vm + v] += stq[kk];
-                        }
+                for (int l = 0; l < 16; ++l)
+                    for (int q = 0; q < SL; ++q) {
+                        const int v = q * 16 + l;
+                        if (v >= Vm) continue;
+                        const double* s0 = st + ((size_t)(0 * 16 + l) * SL + q) * Km, * s1 = st + ((size_t)(1 * 16 + l) * SL + q) * Km;
+                        const double* s2 = st + ((size_t)(2 * 16 + l) * SL + q) * Km, * s3 = st + ((size_t)(3 * 16 + l) * SL + q) * Km;
+                        for (int kk = 0; kk < Km; ++kk) slab[(size_t)kk * Vm + v] = (s0[kk] + s2[kk]) + (s1[kk] + s3[kk]);
+                    }
             }
             for (int i = 0; i < Km * Vm; ++i) {
                 double s = 0.0;
