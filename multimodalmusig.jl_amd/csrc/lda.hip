@@ -2825,7 +2825,10 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
             for (int d = 0; d < D && !dup; ++d)
                 for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) { if (seen[(size_t)term[e]] == d) { dup = true; break; } seen[(size_t)term[e]] = d; }
         }
-        const bool big = D >= 192 * ctx->num_cu;      // measured on MI355X (K = 10, V = 96): 40k documents 59.1 vs 58.3 us per iteration for the CSR sweep, 80k 85.6 vs 98.4
+        // measured on MI355X (K = 10, V = 96; E-step launch, dense rows vs the CSR sweep): 10k documents 12.4 vs 10.9 us (the single-step build),
+        // 15k 12.8 vs 14.1, 20k 16.7 vs 19.3, 40k 20.2 vs 27.7, 640k 190 vs 380 -- every corpus beyond the single-step build's reach
+        // (profiles/experiments/r03_sweeps/dense_crossover.sh; round 2's build only paid from 49k documents: its epilogue cost 19 us)
+        const bool big = D > 12 * G * ctx->num_cu;
         const bool off32 = (int64_t)D * K * 8 < ((int64_t)1 << 32) && (int64_t)D * 16 * (SL + 1) * 4 < ((int64_t)1 << 32);   // the build's 32-bit byte offsets
         dense = shape && !dup && off32 && dmode != 0 && (dmode > 0 || (big && dense_enough));
         drows = drows_env && rshape && !dup && dense_enough;

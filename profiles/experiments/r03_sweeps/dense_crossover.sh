@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r3z
-for d in 15000 20000 30000 40000 60000; do
+for d in 10000 15000 20000 25000 30000 40000; do
   for m in 0 1; do
     MMM_LDA_DENSE=$m python bench.py --config 2 --docs $d --no-cpu-baseline --no-also --steps 50 --warmup 5 --repeats 5 > gpurun_out/r3z/lda_${d}_dense${m}.json 2>/dev/null
   done
