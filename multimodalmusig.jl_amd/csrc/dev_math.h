@@ -169,6 +169,9 @@ __device__ __forceinline__ double dpp_mov_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Largest value of the wave in every lane, without LDS: four DPP stages inside the 16-lane rows, then the rows through the row swaps
+// of rows_sum4 below.
+__device__ __forceinline__ double wave_max_dpp(double v);
 // Sum over the four 16-lane rows of a wave, per row lane, valid in every lane: (row 0 + row 2) + (row 1 + row 3).  gfx950's row swaps
 // (v_permlane32_swap: the upper 32 lanes of one register against the lower 32 of another; v_permlane16_swap: odd against even rows)
 // applied to two copies of the value put lane i + 32 (then i + 16) beside lane i without a trip through LDS: 2 moves, 2 swaps and an
@@ -184,6 +187,22 @@ __device__ __forceinline__ double rows_sum4(double x)
     a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
     b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     return __hiloint2double((int)b.x, (int)a.x) + __hiloint2double((int)b.y, (int)a.y);
+}
+
+__device__ __forceinline__ double wave_max_dpp(double v)
+{
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    mmm_u2 a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    mmm_u2 b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return fmax(__hiloint2double((int)b.x, (int)a.x), __hiloint2double((int)b.y, (int)a.y));
 }
 
 // sum over each aligned group of L lanes (L = 16, 32 or 64); every lane of the group ends with the group total.
