@@ -1787,48 +1787,87 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik_dense(CtmDev c, const do
         }
         if (tid < MMM_LOGTAB_N) smem[(((size_t)VT * KMX + (size_t)kWavesS * G * KMX + 1) & ~(size_t)1) + tid] = g_mmm_logtab[tid];
     }
+    if (tid < kWavesS * kMaxM) (&shw[0][0])[tid] = 0.0;
     __syncthreads();
-    double acc[kMaxM];
-    for (int m = 0; m < kMaxM; ++m) acc[m] = 0.0;
-    for (int base = (bx * kWavesS + wid) * G; base < D; base += ndoc_blocks * kWavesS * G) {
-        const int d = base + g;
-        const bool valid = d < D;
-        for (int m = 0; m < M; ++m) {
-            const int Km = dm.K[m], off = dm.koff[m];
-            const bool in = l < Km;
-            const double x = (valid && in) ? lam[(size_t)d * MK + off + l] : 0.0;
-            // props = softmax(lambda block) (MMCTM.jl:145-154)
-            const double mx = group_max<L>(in ? x : -1e300);
-            const double e = in ? exp(x - mx) : 0.0;
-            const double pr = e / group_sum<L>(e);
-            if (valid && in && props) props[(size_t)d * MK + off + l] = pr;
-            if (!compute_ll) continue;
-            lds_wave_sync();
-            if (l < KMX) sPr[l] = pr;
-            lds_wave_sync();
-            double tv[KMX];
+    // The wave walks its document steps once per modality (modality-major: iteration it = m * nsteps + step), and the NEXT iteration's
+    // lambda values and counts are requested while this one computes -- unconditional loads (clamped indices, masks when the values are
+    // taken over), a lane's part of a row as one load of <= 4 words, uniform base + 32-bit offset, first use pinned behind the slot loop
+    // (the rules of k_lda_estep_dense).  One exposed round trip per wave instead of one per (step, modality).
+    const int wslot = bx * kWavesS + wid, nslots = ndoc_blocks * kWavesS;
+    // (wave-uniform: through readfirstlane, so that the per-modality dimensions below are read with scalar loads)
+    const int nsteps = __builtin_amdgcn_readfirstlane(wslot * G < D ? (D - wslot * G + nslots * G - 1) / (nslots * G) : 0);
+    const int T = nsteps * M;
+    double xq = 0.0;
+    unsigned wq[4] = {0u, 0u, 0u, 0u};
+    auto request = [&](int it, double& x, unsigned* w) {
+        const int mm = it / nsteps, step = it - mm * nsteps;
+        const int dd = (wslot + step * nslots) * G + g;
+        const unsigned dl = dd < D ? (unsigned)dd : 0u;
+        const int Kq = dm.K[mm], lk = l < Kq ? l : Kq - 1;
+        x = *at_byte(lam, (dl * (unsigned)MK + (unsigned)(dm.koff[mm] + lk)) * 8u);
+        const int sls = (dr.SL[mm] + 1) & ~1;
+        // lane-major rows: the lane's <= 8 slots are the first words of one 16-byte load (what lies behind them is not used; the rows are
+        // allocated with 16 bytes to spare)
+        const unsigned* row = at_byte((const unsigned*)dr.rows[mm], (dl * 16u + (unsigned)l) * (unsigned)sls * 2u);
 #pragma unroll
-            for (int k = 0; k < KMX; ++k) tv[k] = sPr[k];
-            const int SLm = dr.SL[m], sls = (SLm + 1) & ~1;
-            const unsigned short* __restrict__ row = dr.rows[m] + ((size_t)(valid ? d : 0) * 16 + l) * sls;     // lane-major rows
-            const double* tbm = sPhi + ((size_t)dr.tpoff[m] + l) * KMX;
-            double a = 0.0;
-            for (int q = 0; q < SLm; ++q) {
-                const double cnt = valid ? (double)row[q] : 0.0;
+        for (int j = 0; j < 4; ++j) w[j] = row[j];
+    };
+    if (T > 0) request(0, xq, wq);
+    double a_mod = 0.0;
+    for (int it = 0; it < T; ++it) {
+        const int m = it / nsteps, step = it - m * nsteps;
+        const int d = (wslot + step * nslots) * G + g;
+        const bool valid = d < D;
+        const int Km = dm.K[m], off = dm.koff[m];
+        const bool in = l < Km;
+        const double x = (valid && in) ? xq : 0.0;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = valid ? wq[j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(w[j]));       // taken over before the props store below (a wait behind it would cover the store)
+        // props = softmax(lambda block) (MMCTM.jl:145-154)
+        const double mx = group_max<L>(in ? x : -1e300);
+        const double e = in ? exp(x - mx) : 0.0;
+        const double pr = e / group_sum<L>(e);
+        if (valid && in && props) *at_byte(props, ((unsigned)d * (unsigned)MK + (unsigned)(off + l)) * 8u) = pr;
+        if (!compute_ll) { if (it + 1 < T) request(it + 1, xq, wq); continue; }
+        lds_wave_sync();
+        if (l < KMX) sPr[l] = pr;
+        lds_wave_sync();
+        double tv[KMX];
+#pragma unroll
+        for (int k = 0; k < KMX; ++k) tv[k] = sPr[k];
+        if (it + 1 < T) request(it + 1, xq, wq);
+        const int SLm = dr.SL[m];
+        const double* tbm = sPhi + ((size_t)dr.tpoff[m] + l) * KMX;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < SLm) {
+                const unsigned cq = (q & 1) ? w[q / 2] >> 16 : w[q / 2] & 0xffffu;
                 const double* tb = tbm + (size_t)q * L * KMX;
                 double p0 = 0.0, p1 = 0.0;
 #pragma unroll
                 for (int k = 0; k + 1 < KMX; k += 2) { p0 = fma(tv[k], tb[k], p0); p1 = fma(tv[k + 1], tb[k + 1], p1); }
                 if (KMX & 1) p0 = fma(tv[KMX - 1], tb[KMX - 1], p0);
-                a = fma(cnt, dev_log_tab(p0 + p1, sLog), a);       // a slot without count: 0 x log(p), p > 0
+                a = fma((double)cq, dev_log_tab(p0 + p1, sLog), a);       // a slot without count: 0 x log(p), p > 0
             }
-            acc[m] += a;
+        }
+        a_mod += a;
+        asm volatile("" : "+v"(a_mod) :: "memory");
+        asm volatile("" : "+v"(xq) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(wq[j]) :: "memory");
+        if (step == nsteps - 1) {
+            const double tot = wave_sum(a_mod);
+            if (lane == 0) shw[wid][m] = tot;
+            a_mod = 0.0;
         }
     }
     if (compute_ll) {
-        for (int m = 0; m < M; ++m) { const double tot = wave_sum(acc[m]); if (lane == 0) shw[wid][m] = tot; }
         __syncthreads();
-        if (tid < M) { double s = 0.0; for (int w = 0; w < kWavesS; ++w) s += shw[w][tid]; llpart[(size_t)bx * M + tid] = s; }
+        if (tid < M) { double sm = 0.0; for (int w = 0; w < kWavesS; ++w) sm += shw[w][tid]; llpart[(size_t)bx * M + tid] = sm; }
     }
 }
 
@@ -2728,7 +2767,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     {
         const char* de = getenv("MMM_CTM_DENSE");
         const int dmode = de ? atoi(de) : -1;
-        bool ok = !m->wide && !m->big && dmode != 0 && D > 0 && (int64_t)D * dm.MK * 8 < ((int64_t)1 << 32);      // (k_ctm_theta_dense: 32-bit byte offsets)
+        bool ok = !m->wide && !m->big && dmode != 0 && D > 0 && (int64_t)D * dm.MK * 8 < ((int64_t)1 << 32) && D < (1 << 24);      // (32-bit byte offsets into lambda and into the rows)
         int64_t present = 0, cells = 0;
         for (int i = 0; i < M && ok; ++i) {
             const int sl = dm.V[i] <= 32 ? 2 : (dm.V[i] <= 48 ? 3 : (dm.V[i] <= 96 ? 6 : (dm.V[i] <= 128 ? 8 : 0)));
@@ -2741,7 +2780,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         std::vector<std::vector<unsigned short>> rows((size_t)M);
         for (int i = 0; i < M && ok; ++i) {
             const int sls = (m->tSL[i] + 1) & ~1, Vp = 16 * sls;     // lane-major: the slots of lane l (terms l, 16 + l, ...) are contiguous, an even number
-            rows[i].assign((size_t)D * Vp, 0);
+            rows[i].assign((size_t)D * Vp + 8, 0);      // (+ 16 bytes: k_ctm_loglik_dense reads 16 bytes from a lane's first slot)
             std::vector<int> seen((size_t)dm.V[i], -1);
             const int64_t* dp = doc_ptr + (size_t)i * (D + 1);
             for (int d = 0; d < D && ok; ++d)
