@@ -932,7 +932,17 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     const bool h16 = c.dense16 != nullptr;
     const bool ell = dense || c.ell != nullptr;
     int2 pre[PRE];
-    if (dense) {
+    // 16-bit lane-major rows: the lane's <= 8 slots are the first words of ONE 16-byte load (the rows are allocated with 16 bytes to spare),
+    // and in the loop below the next step's gamma row and counts are requested while this step computes (the rules of k_lda_estep_dense)
+    const bool fast = L == 16 && dense && h16 && (int64_t)D * K * 8 < ((int64_t)1 << 32) && (int64_t)D * c.Vp * 2 < ((int64_t)1 << 32);
+    unsigned wq[4] = {0u, 0u, 0u, 0u};
+    const int lk = l < K ? l : K - 1;
+    unsigned dl = valid ? (unsigned)d : 0u;
+    if (fast) {
+        const unsigned* row = at_byte((const unsigned*)c.dense16, (dl * 16u + (unsigned)l) * (unsigned)(c.Vp >> 4) * 2u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[j] = row[j];
+    } else if (dense) {
         const int* __restrict__ row = c.dense + (size_t)(valid ? d : 0) * c.Vp;
         const unsigned short* __restrict__ row16 = c.dense16 + (size_t)(valid ? d : 0) * c.Vp;
 #pragma unroll
@@ -952,7 +962,55 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     __syncthreads();
     MMM_RSTAMP(lb == 0 && tid == 0, 21);       // tables staged by all waves
     double acc = 0.0;
-    if (ell) {
+    if (fast) {
+        const int nch = (V + L - 1) / L;
+        const int stride = nslots * G;
+        const unsigned slp2 = (unsigned)(c.Vp >> 4) * 2u;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = valid ? wq[j] : 0u;
+        for (; base < D; base += stride) {
+            const int dn = d + stride;
+            const bool validn = base + stride < D && dn < D;
+            const unsigned dnl = validn ? (unsigned)dn : dl;
+            const double Sp = group_sum<L>(gp);
+            lds_wave_sync();
+            if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+            lds_wave_sync();
+            double tv[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) tv[k] = myT[k];
+            // the next step's values (unconditional loads, clamped indices; taken over after the chunks)
+            double gpn = *at_byte(gprev, (dnl * (unsigned)K + (unsigned)lk) * 8u);
+            {
+                const unsigned* row = at_byte((const unsigned*)c.dense16, (dnl * 16u + (unsigned)l) * slp2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq[j] = row[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < nch) {
+                    const unsigned cq = (j & 1) ? w[j / 2] >> 16 : w[j / 2] & 0xffffu;
+                    const bool act = valid && j * L + l < V;
+                    const double* bc = sBeta + (size_t)(act ? j * L + l : 0) * KP;
+                    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k + 1 < KP; k += 2) { p0 = fma(tv[k], bc[k], p0); p1 = fma(tv[k + 1], bc[k + 1], p1); }
+                    if (KP & 1) p0 = fma(tv[KP - 1], bc[KP - 1], p0);
+                    const double p = act ? p0 + p1 : 1.0;
+                    acc = fma((double)cq, dev_log_tab(p, sLog), acc);
+                }
+            }
+            asm volatile("" : "+v"(acc) :: "memory");
+            asm volatile("" : "+v"(gpn) :: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(wq[j]) :: "memory");
+            d = dn; valid = validn; dl = dnl;
+            gp = (valid && l < K) ? gpn : (l < K ? 1.0 : 0.0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = valid ? wq[j] : 0u;
+        }
+    } else if (ell) {
         const int nch = (V + L - 1) / L;
         for (; base < D; base += nslots * G) {
             if (base != wslot * G) {
@@ -2923,7 +2981,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     if (m->drows && rows16_env && maxcount < 65536) {
         m->SLs = (SL + 1) & ~1;          // lane-major rows (LdaDev::dense): an even number of 16-bit slots per lane
         const int Vp = 16 * m->SLs;
-        std::vector<unsigned short> rows((size_t)D * Vp, 0);
+        std::vector<unsigned short> rows((size_t)D * Vp + 8, 0);       // (+ 16 bytes: the ll blocks read 16 bytes from a lane's first slot)
         for (int d = 0; d < D; ++d)
             for (int64_t e = doc_ptr[d]; e < doc_ptr[d + 1]; ++e) rows[(size_t)d * Vp + (term[e] & 15) * m->SLs + (term[e] >> 4)] = (unsigned short)count[e];
         hipError_t e_ = m->cnt16.alloc(rows.size());
