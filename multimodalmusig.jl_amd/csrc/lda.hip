@@ -59,6 +59,12 @@ struct LdaDev {
 
 // position of term slot w (lane w % 16, the lane's slot w / 16) in a lane-major row of 16 x slp slots
 __device__ __forceinline__ int row_slot(int w, int slp) { return (w & 15) * slp + (w >> 4); }
+// 16-bit lane-major rows: slot c (0..7) of a lane's part, held as four 32-bit words (ONE 16-byte load; the rows are allocated with 16 bytes to spare)
+__device__ __forceinline__ int row16_count(unsigned w0, unsigned w1, unsigned w2, unsigned w3, int c)
+{
+    const unsigned word = c < 4 ? (c < 2 ? w0 : w1) : (c < 6 ? w2 : w3);
+    return (int)((c & 1) ? word >> 16 : word & 0xffffu);
+}
 
 struct LdaCtl {
     unsigned int ticket;
@@ -321,6 +327,18 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid ? d : 0) * a.c.Vp;
             const bool h16 = a.c.dense16 != nullptr;
             const int slp = a.c.Vp >> 4;
+            if (L == 16 && h16) {      // one 16-byte load instead of one 2-byte load per chunk (six loads whose last waited for the first five)
+                const unsigned* __restrict__ r32 = (const unsigned*)(row16 + (size_t)l * slp);
+                const unsigned w0 = r32[0], w1 = r32[1], w2 = r32[2], w3 = r32[3];
+#pragma unroll
+                for (int j = 0; j < PRE; ++j) {
+                    int c = j + rot; if (c >= NCHR) c -= NCHR;
+                    const int w = c * L + l;
+                    const bool in = valid && j < NCHR && w < V;
+                    const int n = in ? row16_count(w0, w1, w2, w3, c) : 0;
+                    tcp[j] = make_int2(n > 0 ? w : -1, n);
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < PRE; ++j) {
                 int c = j + rot; if (c >= NCHR) c -= NCHR;
@@ -381,6 +399,18 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
                 const unsigned short* __restrict__ row16 = a.c.dense16 + (size_t)(valid1 ? d1 : 0) * a.c.Vp;
                 const bool h16 = a.c.dense16 != nullptr;
                 const int slp = a.c.Vp >> 4;
+                if (L == 16 && h16) {
+                    const unsigned* __restrict__ r32 = (const unsigned*)(row16 + (size_t)l * slp);
+                    const unsigned w0 = r32[0], w1 = r32[1], w2 = r32[2], w3 = r32[3];
+#pragma unroll
+                    for (int j = 0; j < PRE; ++j) {
+                        int c = j + rot1; if (c >= NCHR) c -= NCHR;
+                        const int w = c * L + l;
+                        const bool in = valid1 && j < NCHR && w < V;
+                        const int n = in ? row16_count(w0, w1, w2, w3, c) : 0;
+                        tcn[j] = make_int2(n > 0 ? w : -1, n);
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < PRE; ++j) {
                     int c = j + rot1; if (c >= NCHR) c -= NCHR;
