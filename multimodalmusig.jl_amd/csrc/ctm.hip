@@ -2314,8 +2314,31 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
 }
 
 // lam_in / expE: per-replica arrays (base of replica 0); lam_out likewise (may alias lam_in: in-place update)
+// the side stream of the context (created on first use), or NULL if the runtime refuses
+hipStream_t side_stream(mmm_ctx* ctx)
+{
+    if (ctx->side) return ctx->side;
+    hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipEventDestroy(a);
+        (void)hipStreamDestroy(s);
+        return nullptr;
+    }
+    ctx->side = s; ctx->ev_fork = a; ctx->ev_join = b;
+    return s;
+}
+
+// launches on the context go to another stream while this lives
+struct StreamSwap {
+    mmm_ctx* ctx; hipStream_t saved;
+    StreamSwap(mmm_ctx* c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+    ~StreamSwap() { ctx->stream = saved; }
+};
+
 int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam_out, const double* expE, double* lam_keep = nullptr,
-              double* expE_keep = nullptr)
+              double* expE_keep = nullptr, bool fork_after_theta = false)
 {
     const CtmDims& dm = m->dm;
     const size_t r0 = sc.rep0, DMK = m->sDMK(), MK = dm.MK;
@@ -2334,6 +2357,7 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
             if ((rc = launch_theta_dense(m, a, sc.nrep))) return rc;
         } else if ((rc = launch_phase<0>(m, a, lds, m->grid_e, m->waves_e, sc.nrep))) return rc;
     }
+    if (fork_after_theta) MMM_HIP(m->ctx, hipEventRecord(m->ctx->ev_fork, m->ctx->stream));
     if (flags & (F_NU | F_LAMBDA)) {
         ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
         if (m->split) {             // update_ν! and update_λ! as two launches, each in its own lane layout
@@ -2567,9 +2591,29 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     // own reads; the wide-table path has no such hook and copies
     if (m->wide && (rc = copy2_rep(m, sc, m->lambda_prev.p, m->lambda.p, m->sDMK(), m->expEeff_prev.p, m->expEeff.p, (size_t)dm.GT))) return rc;
     // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
+    // One GPU: what only depends on the theta phase -- the reduction of the gamma statistics and the topic M-step -- runs on a side stream
+    // BESIDE the solve phase (which leaves a wave slot per SIMD free) and is joined before the log-likelihood launch: two launches and
+    // their boundaries off the pass's critical path.  Same kernels, same sums; MMM_CTM_OVERLAP=0 / 1: never / whenever possible.
+    // Measured (5 regions x 10 passes each): cfg 5 (IMMCTM, topic M-step 13 us) 0.467 -> 0.458 ms per pass, min 0.407 -> 0.399; cfg 4 (MMCTM, topic
+    // M-step 5 us) 1.082 -> 1.091: there the fork / join cost what the two short launches take -- so by default only the IMMCTM forks.
+    const char* overlap_s = getenv("MMM_CTM_OVERLAP");      // (read per pass: tests switch it within one process)
+    const int overlap_env = overlap_s ? atoi(overlap_s) : -1;
+    const bool overlap = (overlap_env < 0 ? m->immctm : overlap_env != 0) && ctx->nranks == 1 && !m->wide && !m->big &&
+                         !(fit_flags & MMM_FIT_AUTO_ALPHA) && !ctx->profiling && side_stream(ctx) != nullptr;
     rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p,
-                   m->wide ? nullptr : m->lambda_prev.p, m->wide ? nullptr : m->expEeff_prev.p);
+                   m->wide ? nullptr : m->lambda_prev.p, m->wide ? nullptr : m->expEeff_prev.p, overlap);
     if (rc) return rc;
+    const int nb1 = (m->nmom + 15) / 16, nb2 = (dm.GT + 15) / 16;
+    if (overlap) {
+        StreamSwap sw(ctx, ctx->side);
+        MMM_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + sc.rep0 * m->grid_m * m->nmom, m->grid_m,
+                           m->nmom, m->stats.p + sc.rep0 * m->s_stats, m->s_stats, sc.active, 0, m->partial.p + sc.rep0 * m->grid_e * dm.GT, m->grid_e, dm.GT,
+                           m->stats.p + sc.rep0 * m->s_stats + m->nmom);
+        MMM_LAUNCH_CHECK(ctx);
+        if ((rc = run_mstep(m, sc, 0, 0, 1, 1))) return rc;
+        MMM_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    }
     // sufficient statistics: [sum lambda | sum nu | sum lambda lambda' | gamma sums]
     const size_t r0 = sc.rep0;
     ProfSpan* mid_span = new ProfSpan(ctx, 2);      // mmm_ctx_profile_select(2): moments, reduction, all-reduce, topic M-step
@@ -2586,9 +2630,8 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
                            m->aexp.p + r0 * dm.D * dm.MK, m->expEeff.p + r0 * dm.GT, m->stats.p + r0 * m->s_stats + m->nmom, m->s_stats, sc.active);
         MMM_LAUNCH_CHECK(ctx);
         if ((rc = reduce_partials(m, sc, m->mompart.p, m->grid_m, m->nmom, m->stats.p, m->s_stats))) return rc;
-    } else {   // moments and gamma sums reduced by one launch
-        const int nb1 = (m->nmom + 15) / 16, nb2 = (dm.GT + 15) / 16;
-        hipLaunchKernelGGL(k_reduce_partials, dim3(nb1 + nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + r0 * m->grid_m * m->nmom, m->grid_m,
+    } else {   // moments and gamma sums reduced by one launch (with the side stream: the moments alone -- blocks beyond nb1 do the gamma part)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(overlap ? nb1 : nb1 + nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + r0 * m->grid_m * m->nmom, m->grid_m,
                            m->nmom, m->stats.p + r0 * m->s_stats, m->s_stats, sc.active, nb1, m->partial.p + r0 * m->grid_e * dm.GT, m->grid_e, dm.GT,
                            m->stats.p + r0 * m->s_stats + m->nmom);
         MMM_LAUNCH_CHECK(ctx);
@@ -2599,7 +2642,8 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     static const int fuse_env = getenv("MMM_CTM_FUSE_GAUSS") ? atoi(getenv("MMM_CTM_FUSE_GAUSS")) : -1;
     const bool fuse = fuse_env >= 0 ? fuse_env != 0 : true;
     const int do_sig = (update_sigma || m->immctm) ? 1 : 0;
-    if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, 1, 1))) return rc;
+    if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, overlap ? 0 : 1, 1))) return rc;
+    if (overlap) MMM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if ((fit_flags & MMM_FIT_AUTO_ALPHA) && (rc = run_update_alpha(m, sc))) return rc;      // MMCTM.jl:472-474
     delete mid_span; mid_span = nullptr;
     // update_props! and the log-likelihoods

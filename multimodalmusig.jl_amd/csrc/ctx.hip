@@ -61,6 +61,9 @@ int mmm_ctx_destroy(mmm_ctx* ctx)
     if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
     mmm_p2p_release(ctx);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
     return MMM_OK;

@@ -44,6 +44,10 @@ struct mmm_ctx {
     // the context before its models without a use-after-free.
     // Finalizers may run on any thread, hence atomics; the communicator and the mailboxes are released at mmm_ctx_destroy itself (peers
     // and the runtime are still up then), only the stream, the events and the memory that models still reference wait for the last model.
+    // side stream of the CTM fit passes: work that only depends on the theta phase (reduction of the gamma statistics, topic M-step) runs
+    // beside the solve phase and is joined before the log-likelihood launch (lazily created; always joined within the pass)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::atomic<int> live_models{0};
     std::atomic<bool> destroy_pending{false};
 };

@@ -463,6 +463,28 @@ def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, monkeyp
     assert g2.elbo == pytest.approx(o2.elbo_value, rel=1e-9)
 
 
+@pytest.mark.parametrize("imm", [False, True])
+def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, monkeypatch, imm):
+    """fused_pass on one GPU may run the gamma-statistics reduction and the topic M-step on a side stream beside the solve phase (default:
+    IMMCTM only; MMM_CTM_OVERLAP=1 / 0 forces / forbids): the same kernels and sums, so whole fits are bit-identical whichever way the
+    launches are ordered, and bit-identical to the oracle -- state, per-document evaluation counts, ll history."""
+    kw = dict(D=301, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3) if imm else dict(D=260, K=[7, 5], V=[96, 38], seed=66, means=[900, 120])
+    D, MK = kw["D"], sum(kw["K"])
+    hist = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MMM_CTM_OVERLAP", mode)
+        X, g, o = _pair(mmm, oracle, order="device", **kw)
+        ll = np.asarray(mmm.fit(g, maxiter=9, tol=0.0, verbose=False))
+        for _ in range(9):
+            o.twin_pass(True)
+        _same_state(g, o, D, MK)
+        st = g.solver_stats(per_doc=True)
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+        hist[mode] = (ll, g.lam_matrix().copy(), g._get("gamma").copy(), np.asarray(g.props_matrix()).copy() if hasattr(g, "props_matrix") else None)
+        g.close()
+    assert np.array_equal(hist["0"][0], hist["1"][0]) and np.array_equal(hist["0"][1], hist["1"][1]) and np.array_equal(hist["0"][2], hist["1"][2])
+
+
 def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(mmm, monkeypatch):
     monkeypatch.setenv("MMM_CTM_DENSE", "1")
     X, g0 = np_ref.synth_mm(60, [40, 24], [5, 4], seed=4, means=[600, 80])
