@@ -10,8 +10,8 @@ LDA.jl:201-209, MMCTM.jl:462-479, IMMCTM.jl:440-451) over one batch of synthetic
   --scaling weak        (default) every rank holds its own corpus of the configuration's size
   --scaling strong      the ONE corpus of the configuration's size, documents sharded over the ranks (balanced by nonzeros)
 
-The default invocation (config 2) also measures configs 4 and 5 for a bounded number of steps and attaches them to the same JSON
-line under "also" (--no-also switches that off); the headline keys are config 2's.
+The default invocation (config 2) also measures configs 4 and 5 for a bounded number of steps, and config 2's model on 640k documents
+per GPU, and attaches them to the same JSON line under "also" (--no-also switches that off); the headline keys are config 2's.
 
 N > 1: one process per GPU.  `python3 bench.py --gpus N` starts its N rank processes ITSELF (children of a parent that never touches
 the GPU; rank r -> device r mod #devices) and relays rank 0's line; under `python -m torch.distributed.run` (WORLD_SIZE set by the
@@ -466,7 +466,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                "event_span_1_launch_us": span1, "event_span_2_launches_us": span2,
                                "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
                                          "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"}
-            tname = "lda_estep"
+            tname = "lda_estep_dense_640k" if (geo["dense"] and D == 640000) else "lda_estep"
         else:
             st = model.solver_stats()
             MK, M = sum(K), len(K)
@@ -491,7 +491,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             res["n_capped"] = st["n_capped"]
             tname = "ctm_solve_cfg%d" % cfg_id
         tr, tfile = load_pmc(tname)
-        if world == 1 and D == cfg["docs"] and tr:
+        if world == 1 and (D == cfg["docs"] or tname == "lda_estep_dense_640k") and tr:
             res["roofline"]["traffic"] = tr["hbm_bytes_per_launch_gfx950_corrected"]
             res["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch_gfx950_corrected"] / algo_bytes
             res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + tfile
@@ -567,7 +567,18 @@ def main():
             if env.rank == 0:
                 r["wall_s_including_corpus_generation_and_cpu_baseline"] = time.perf_counter() - t0
                 also["cfg%d" % c] = r
+        # ... and the headline model at a size where the kernels reach their steady state (640k documents per GPU: the roofline figures of
+        # the dense-row E-step build); bounded: ~10 s including corpus generation
+        t0 = time.perf_counter()
+        try:
+            r = run_config(env, 2, args.scaling, 20, 3, 3, 640000, False)
+        except Exception as e:       # noqa: BLE001
+            if env.world > 1:
+                raise
+            r = {"error": "%s: %s" % (type(e).__name__, e)}
         if env.rank == 0:
+            r["wall_s_including_corpus_generation"] = time.perf_counter() - t0
+            also["lda_640k_docs"] = r
             res["also"] = also
     if env.rank == 0:
         print(json.dumps(res))

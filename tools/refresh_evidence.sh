@@ -38,7 +38,7 @@ bash tools/pmc_run.sh gpurun_out/evidence/pmc cfg5 "A B C D" -- --config 5 --no-
 python3 tools/pmc_summary.py $P lda10k "k_lda_estep<" --json $E/traffic_lda_estep.json > $E/pmc_lda10k_estep.txt
 python3 tools/pmc_summary.py $P lda10k k_lda_reduce_ll_mstep > $E/pmc_lda10k_merged.txt
 python3 tools/pmc_summary.py $P lda160k k_lda_estep_dense > $E/pmc_lda160k_estep_dense.txt
-python3 tools/pmc_summary.py $P lda640k k_lda_estep_dense > $E/pmc_lda640k_estep_dense.txt
+python3 tools/pmc_summary.py $P lda640k k_lda_estep_dense --json $E/traffic_lda_estep_dense_640k.json > $E/pmc_lda640k_estep_dense.txt
 python3 tools/pmc_summary.py $P lda640k k_lda_reduce_ll_mstep > $E/pmc_lda640k_merged.txt
 python3 tools/pmc_summary.py $P cfg4 "k_ctm_solve_cpl<28" --json $E/traffic_ctm_solve_cfg4.json > $E/pmc_cfg4_solve.txt
 python3 tools/pmc_summary.py $P cfg4 "k_ctm_theta_dense<10, 6>" > $E/pmc_cfg4_theta.txt
