@@ -571,7 +571,7 @@ def main():
         # the dense-row E-step build); bounded: ~10 s including corpus generation
         t0 = time.perf_counter()
         try:
-            r = run_config(env, 2, args.scaling, 20, 3, 3, 640000, False)
+            r = run_config(env, 2, args.scaling, 30, 5, 5, 640000, False)
         except Exception as e:       # noqa: BLE001
             if env.world > 1:
                 raise
