@@ -322,6 +322,11 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
     np, pkg, ctx, world, rank = env.np, env.pkg, env.ctx, env.world, env.rank
     import np_ref
     cfg = CONFIGS[cfg_id]
+    t_start = time.perf_counter()
+
+    def note(what):      # progress on stderr (stdout carries the one JSON line): where a multi-rank run is, should it ever stall
+        print("[bench rank %d/%d] cfg %d%s: %s (+%.1f s)" % (rank, world, cfg_id, " docs=%d" % docs if docs else "", what, time.perf_counter() - t_start),
+              file=sys.stderr, flush=True)
     # ---- corpus: SURVEY section 8d generator, corpus seed = 20261003 + config index; weak: every rank its own corpus (seed + 1000 rank),
     # strong: every rank generates the one corpus and keeps its nnz-balanced contiguous shard
     Dcfg = docs or cfg["docs"]
@@ -347,6 +352,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             new.append(flat[o:o + g.size].reshape(g.shape).copy()); o += g.size
         init = new
     lib = pkg.lib()
+    note("corpus ready, %d documents" % D)
     if cfg["model"] == "lda":
         alpha = eta = 0.1
         model = pkg.LDA(K, alpha, eta, V, X, λ0=init, ctx=ctx)
@@ -365,7 +371,10 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
         def run(n):
             pkg._lib.check(lib.mmm_ctm_iterate(model._h, n, 1), ctx.h, "mmm_ctm_iterate")
 
+    note("model created")
     run(warmup)
+    ctx.synchronize()
+    note("warm-up done")
     regions = []
     for _ in range(max(1, repeats)):
         env.barrier()
@@ -374,6 +383,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
         env.barrier()
         regions.append(env.allmax(time.perf_counter() - t0))
     dt = float(np.median(regions))
+    note("timed regions done (%.4f ms per step)" % (dt / steps * 1e3))
 
     # Per-kernel durations: the same K steps again with the launches of one phase of the pass bracketed by a HIP event pair on the
     # library's stream (mmm_ctx_profile_select).  Kept out of the timed regions above because each hipEventRecord opens a ~5.6 us bubble
@@ -410,6 +420,14 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
     ctx.profile_begin(repeat=1, phase=0); ctx.profile_end()
     avg_s = avg_us * 1e-6
 
+    note("phase spans done")
+    ll_last = None
+    if cfg["model"] == "lda":
+        # on EVERY rank: reading the history flushes the lagged log-likelihood of the last pass, and that ends in the ranks' exchange -- called
+        # by rank 0 alone it left rank 0 one exchange ahead of its peers (harmless at the very end of a run, fatal before the next configuration)
+        ll = np.zeros(1); n = pkg._lib.C.c_int()
+        pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
+        ll_last = float(ll[0])
     transports = env.allgather_obj(ctx.transport)
     nranks_seen = env.allgather_obj(int(lib.mmm_comm_nranks(ctx.h)))
     docs_per_rank = env.allgather_obj(D)
@@ -439,9 +457,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                       "repeat, spans corrected by the event-pair overhead measured differentially on the E-step kernel, step_us = "
                                       "the timed regions' median; CTM: all phases in one repeat, step_us = that repeat's wall time per step"}
         if cfg["model"] == "lda":
-            ll = np.zeros(1); n = pkg._lib.C.c_int()
-            pkg._lib.check(lib.mmm_lda_ll_history(model._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
-            res["ll_last"] = float(ll[0])
+            res["ll_last"] = ll_last
             # dominant kernel: k_lda_estep (update_γ!/ϕ! sweep + λ statistics).  Algorithmic bytes per launch by SURVEY section 8d's
             # figure: 8 B per nonzero (term,count) + gamma_t read + Elntheta and gamma_{t+1} writes (3 x 8 B x K per document); phi stays in
             # registers, the topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and

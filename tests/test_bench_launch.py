@@ -49,6 +49,23 @@ def test_two_self_launched_ranks_on_one_card():
 
 
 @pytest.mark.gpu
+def test_default_invocation_with_two_ranks_carries_every_configuration():
+    """The form the driver's scaling runs use: `bench.py --gpus N` with nothing else, i.e. config 2 and then, on the same ranks and the
+    same communicator, configs 4, 5 and the 640k-document LDA under "also".  Every library call that ends in the ranks' exchange must
+    be made by every rank: round 3 shipped for a while with the ll history read by rank 0 alone (it flushes the lagged log-likelihood,
+    an all-reduce), which left rank 0 one exchange ahead -- harmless at the end of a run, a chain of 20-second time-outs before the
+    next configuration."""
+    p = _bench("--gpus", "2", "--launch-timeout", "600", timeout=700)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["config"]["comm_nranks_per_rank"] == [2, 2]
+    assert set(r["also"]) == {"cfg4", "cfg5", "lda_640k_docs"}
+    for k, v in r["also"].items():
+        assert "error" not in v and v["value"] > 0 and v["n_gpus"] == 2, (k, v.get("error"))
+    assert r["ll_last"] < 0 and r["also"]["lda_640k_docs"]["ll_last"] < 0
+
+
+@pytest.mark.gpu
 def test_single_gpu_line_keeps_its_keys():
     p = _bench("--docs", "2000", "--steps", "10", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline")
     assert p.returncode == 0, p.stdout + p.stderr
