@@ -30,7 +30,8 @@ for case in range(n):
         o = oracle.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
         it = int(rng.choice([1, 2, 5, 13]))
         ll_g = mmm.fit(g, maxiter=it, tol=0.0, verbose=False); ll_o = o.fit(maxiter=it, tol=0.0)
-        err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-300)) if len(ll_g) == len(ll_o) else np.inf      # (V = 1: ll = 0 exactly on both sides)
+        # (V = 1: the ll is 0 up to rounding on both sides -- a relative error against 1e-16 means nothing, hence the floor on the denominator)
+        err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-12)) if len(ll_g) == len(ll_o) else np.inf
         lam_err = np.max(np.abs(g.λ - o.lam.reshape(V, K, order="F")) / np.abs(o.lam.reshape(V, K, order="F")))
         el = abs(g.elbo - o.elbo_value) / abs(o.elbo_value)
         ok = err < 1e-9 and lam_err < 1e-8 and el < 1e-8
