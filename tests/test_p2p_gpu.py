@@ -61,6 +61,23 @@ def _worker(rank, world, port, q):
         c = pkg.MMCTM([5, 4], [0.1, 0.1], [40, 24], Xm[e0:e1], γ0=g0, ctx=ctx)
         llc = pkg.fit(c, maxiter=6, tol=0.0, verbose=False)
         res.update(ctm_ll=llc.tolist(), ctm_elbo=c.elbo, ctm_mu=c.μ.tolist(), ctm_gamma=c._get("gamma").tolist())
+        # ---- IMMCTM over rows of counts (forced: the shards are small), fit with a stopping tolerance: the rule runs on the device from the
+        #      GLOBAL ll row, so every rank must stop in the same pass; update_alpha off
+        SNV3 = [np.array([[t // 16 + 1, (t // 4) % 4 + 1, t % 4 + 1] for t in range(96)])]
+        Xi, _ = np_ref.synth_mm(330, [96], [6], seed=14, means=[900], empty_frac=0.05)
+        gi0 = np.random.default_rng(3).integers(1, 101, size=6 * 14).astype(np.float64)
+        f0, f1 = pkg.shard_documents(Xi, world, rank)
+        os.environ["MMM_CTM_DENSE"] = "1"
+        ci = pkg.IMMCTM([6], [0.1], SNV3, Xi[f0:f1], γ0=gi0, ctx=ctx)
+        assert ci.geometry()["tdense"]
+        lli = pkg.fit(ci, maxiter=25, tol=2e-3, verbose=False)
+        res.update(imm_ll=np.asarray(lli).tolist(), imm_elbo=ci.elbo, imm_gamma=ci._get("gamma").tolist(), imm_conv=ci.converged)
+        del os.environ["MMM_CTM_DENSE"]
+        if rank == 0:
+            plain_i = pkg.Context(0)
+            cis = pkg.IMMCTM([6], [0.1], SNV3, Xi, γ0=gi0, ctx=plain_i)
+            llis = pkg.fit(cis, maxiter=25, tol=2e-3, verbose=False)
+            res.update(ref_imm_ll=np.asarray(llis).tolist(), ref_imm_elbo=cis.elbo)
         if rank == 0:
             # the same fits, unsharded, on a plain context
             plain = pkg.Context(0)
@@ -104,6 +121,7 @@ def test_three_ranks_on_one_card_p2p_allreduce():
         assert r["lda_ll"] == r0["lda_ll"] and r["lda_beta"] == r0["lda_beta"] and r["lda_conv"] == r0["lda_conv"]
         assert r["ctm_ll"] == r0["ctm_ll"] and r["ctm_mu"] == r0["ctm_mu"] and r["ctm_gamma"] == r0["ctm_gamma"]
         assert r["ldad_ll"] == r0["ldad_ll"] and r["ldad_beta"] == r0["ldad_beta"]
+        assert r["imm_ll"] == r0["imm_ll"] and r["imm_gamma"] == r0["imm_gamma"] and r["imm_conv"] == r0["imm_conv"]
     assert sum(b - a for a, b in (r["shard"] for r in res)) == 600
     # sharded == unsharded up to the order of the sums
     assert len(r0["lda_ll"]) == len(r0["ref_lda_ll"])
@@ -117,3 +135,9 @@ def test_three_ranks_on_one_card_p2p_allreduce():
     np.testing.assert_allclose(r0["ctm_ll"], r0["ref_ctm_ll"], rtol=1e-5)
     np.testing.assert_allclose(r0["ctm_elbo"], r0["ref_ctm_elbo"], rtol=1e-5)
     np.testing.assert_allclose(r0["ctm_mu"], r0["ref_ctm_mu"], rtol=1e-3, atol=1e-5)
+    # IMMCTM over rows of counts, stopped by its tolerance: the same number of passes on every rank (asserted above through the ll
+    # rows) and, up to the forking of the LD_MMA trajectories, the unsharded fit
+    n = min(len(r0["imm_ll"]), len(r0["ref_imm_ll"]))
+    assert n >= 11 and abs(len(r0["imm_ll"]) - len(r0["ref_imm_ll"])) <= 2
+    np.testing.assert_allclose(np.asarray(r0["imm_ll"])[:n], np.asarray(r0["ref_imm_ll"])[:n], rtol=1e-4)
+    np.testing.assert_allclose(sum(r["imm_elbo"] for r in res) / WORLD, r0["imm_elbo"], rtol=1e-12)
