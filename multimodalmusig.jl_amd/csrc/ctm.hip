@@ -3383,6 +3383,7 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     double h[8];
     MMM_HIP(ctx, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = mmm_p2p_check(ctx))) return rc;      // (the ELBO's sums went through the ranks' exchange: a peer that never came is an error)
     const double MK = dm.MK, Dg = m->Dglobal, l2pi = log(2.0 * M_PI);
     double t[7];
     t[0] = h[5];                                              // ElnPϕ  MMCTM.jl:271-284

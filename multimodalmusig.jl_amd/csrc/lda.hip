@@ -3301,6 +3301,9 @@ int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)
     const int cnt = std::min(max_n, m->n_hist);
     if (cnt > 0 && ll) MMM_HIP(ctx, hipMemcpyAsync(ll, m->ll_hist.p + (m->n_hist - cnt), sizeof(double) * cnt, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (the flush ends in the ranks' exchange: a peer that never came -- e.g. a caller that reads the history on one rank only -- must be an
+    // error here, not a silently wrong last row)
+    if ((rc = mmm_p2p_check(ctx))) return rc;
     *n = cnt;
     return MMM_OK;
 }
@@ -3322,6 +3325,7 @@ int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7])
     double h[7];
     MMM_HIP(ctx, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = mmm_p2p_check(ctx))) return rc;
     const double K = m->K, V = m->V, al = m->alpha, et = m->eta;
     double t[7];
     t[0] = K * (lgamma(V * et) - V * lgamma(et)) + (et - 1.0) * h[5];            // LDA.jl:114-118
