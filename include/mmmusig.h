@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MMM_VERSION 110
+#define MMM_VERSION 120
 
 enum {
     MMM_OK = 0,
@@ -59,7 +59,8 @@ int mmm_version(void);
 /* Create a context on HIP device `device_id` with its own non-blocking stream. */
 int mmm_ctx_create(int device_id, mmm_ctx** out);
 /* With models still alive on it (a garbage-collected host destroys in no particular order) the context gives up its communicator and
- * mailboxes at once and returns MMM_DEFERRED; stream and memory go with the last mmm_*_destroy.  Such models may be destroyed, not used. */
+ * mailboxes at once and returns MMM_DEFERRED; stream and memory go with the last mmm_*_destroy.  Such models may be destroyed; if the
+ * context had a communicator (nranks > 1) every other call on them returns MMM_ERR_ARG -- their sums would silently be rank-local. */
 int mmm_ctx_destroy(mmm_ctx* ctx);
 /* Message of the last error on this ctx (ctx == NULL: last error of a failed mmm_ctx_create). */
 const char* mmm_last_error(const mmm_ctx* ctx);
@@ -144,6 +145,8 @@ int mmm_lda_update_gamma(mmm_lda* m);   /* update_γ!  LDA.jl:82-90  (+ update_E
 int mmm_lda_update_phi(mmm_lda* m);     /* update_ϕ!  LDA.jl:69-76                           */
 int mmm_lda_update_lambda(mmm_lda* m);  /* update_λ!  LDA.jl:100-108 (+ update_Elnβ! :96-98) */
 int mmm_lda_update_beta(mmm_lda* m);    /* update_β!  LDA.jl:110-112                         */
+int mmm_lda_update_Elntheta(mmm_lda* m);/* update_Elnθ! alone  LDA.jl:78-80   (the reference calls it at the end of update_γ!) */
+int mmm_lda_update_Elnbeta(mmm_lda* m); /* update_Elnβ! alone  LDA.jl:96-98 / ILDA.jl:96-101 (... at the end of update_λ!)    */
 int mmm_lda_update_theta(mmm_lda* m);   /* update_θ!  LDA.jl:92-94                           */
 int mmm_lda_loglik(mmm_lda* m, double* ll);                    /* calculate_loglikelihood LDA.jl:174-196 */
 int mmm_lda_elbo(mmm_lda* m, double* elbo, double terms[7]);   /* calculate_elbo LDA.jl:114-172          */
@@ -211,6 +214,13 @@ int mmm_ctm_update_Elnphi(mmm_ctm* m);  /* update_Elnϕ!                 MMCTM.j
 int mmm_ctm_update_alpha(mmm_ctm* m);   /* update_α! (1-D LD_MMA per α) MMCTM.jl:252-269, IMMCTM.jl:225-244 */
 int mmm_ctm_update_props(mmm_ctm* m);   /* update_props!                MMCTM.jl:145-154              */
 int mmm_ctm_update_phi(mmm_ctm* m);     /* update_ϕ!                    MMCTM.jl:244-250              */
+/* The reference's per-document functions take the document: update_ζ!(model, d), update_θ!(model, d), update_ν!(model, d),
+ * update_λ!(model, d) (MMCTM.jl:127-198; test/mmctm.jl:92-199 call them that way).  Only document d (0-based) changes. */
+enum { MMM_STAGE_ZETA = 0, MMM_STAGE_THETA = 1, MMM_STAGE_NU = 2, MMM_STAGE_LAMBDA = 3 };
+int mmm_ctm_update_doc(mmm_ctm* m, int stage, int d);
+/* calculate_sumθ(model, d) and calculate_Ndivζ(model, d) -- MMCTM.jl:110-125 / IMMCTM.jl:90-105: sum K doubles each (either may be NULL),
+ * from the stored θ and ζ of document d (0-based) */
+int mmm_ctm_doc_sums(mmm_ctm* m, int d, double* sumtheta, double* Ndivzeta);
 int mmm_ctm_loglik(mmm_ctm* m, double* ll /* M */);                /* calculate_loglikelihoods MMCTM.jl:384-448 */
 int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7]);       /* calculate_elbo MMCTM.jl:271-382           */
 /* objective/gradient of one document evaluated by the device code the MMA solves use (common.jl:11-36) */
@@ -268,6 +278,29 @@ int mmm_ctm_select(mmm_ctm* m, int r);
  * of earlier passes. */
 int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int fit_flags, double* ll_hist, int* n_iter,
                       int* converged, double* elbo);
+
+/* ---- free functions of the reference (arguments are caller arrays, no model) --------------------------------------
+ * The reference's tests call these directly (test/common.jl:79-97; test/mmctm.jl:135-148,268-293,349-388; test/immctm.jl:122-160,
+ * 273-294,350-386).  Values and gradients in the reference's MAXIMISATION form; grad may be NULL (the reference's `length(∇) > 0`). */
+/* λ_objective(λ, ∇λ, ν, Ndivζ, sumθ, μ, invΣ) -- common.jl:11-23; invSigma n x n column-major */
+int mmm_lambda_objective(mmm_ctx* ctx, int n, const double* lambda, const double* nu, const double* Ndivzeta, const double* sumtheta,
+                         const double* mu, const double* invSigma, double* val, double* grad);
+/* ν_objective(ν, ∇ν, λ, Ndivζ, μ, invΣ) -- common.jl:25-36 (μ is unused there too and may be NULL) */
+int mmm_nu_objective(mmm_ctx* ctx, int n, const double* nu, const double* lambda, const double* Ndivzeta, const double* mu,
+                     const double* invSigma, double* val, double* grad);
+/* α_objective(α, ∇α, sum_Elnϕ, K, V) -- common.jl:38-46 */
+int mmm_alpha_objective(mmm_ctx* ctx, double alpha, double sum_Elnphi, int K, int V, double* val, double* grad);
+/* Σ_d Σ_w n_w log(Σ_k props[k + K d] · phi[k V + v_w]) / Σ_d N_d over the documents with N_d > 0, CSR as in mmm_lda_create:
+ * calculate_loglikelihood(X, θ, β) LDA.jl:174-188 (props = θ K x D, phi = β V x K column-major -- the same [k V + v]),
+ * calculate_modality_loglikelihood(X, props, ϕ) MMCTM.jl:402-418, calculate_docmodality_loglikelihood (D = 1) MMCTM.jl:384-400. */
+int mmm_mixture_loglik(mmm_ctx* ctx, int D, int K, int V, const int64_t* doc_ptr, const int32_t* term, const int32_t* count,
+                       const double* props, const double* phi, double* ll);
+/* The same with a topic-term probability that factorises over the I features of a term: Π_i phi[k ΣJ + Σ_{q<i} J_q + features[i V + v]]
+ * (features 0-based, [i V + v]; phi in the IMMCTM gamma layout of one modality).  softmax = 1: calculate_modality_loglikelihood(X, η, ϕ,
+ * features) -- IMMCTM.jl:362-407, props = softmax(eta[:, d]) (eta K x D); softmax = 0: eta holds the proportions themselves --
+ * calculate_loglikelihood(X, features, θ, β) of ILDA.jl:203-231 (phi[k][i][j] = β[i][j, k]). */
+int mmm_mixture_loglik_features(mmm_ctx* ctx, int D, int K, int V, int I, const int* J, const int32_t* features, const int64_t* doc_ptr,
+                                const int32_t* term, const int32_t* count, const double* eta, int softmax, const double* phi, double* ll);
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,15 @@ _SIGS = {
     "mmm_ctm_replicas": (C.c_int, [vp]),
     "mmm_ctm_select": (C.c_int, [vp, C.c_int]),
     "mmm_ctm_fit_batch": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]),
+    "mmm_lda_update_Elntheta": (C.c_int, [vp]),
+    "mmm_lda_update_Elnbeta": (C.c_int, [vp]),
+    "mmm_ctm_update_doc": (C.c_int, [vp, C.c_int, C.c_int]),
+    "mmm_ctm_doc_sums": (C.c_int, [vp, C.c_int, vp, vp]),
+    "mmm_lambda_objective": (C.c_int, [vp, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, C.POINTER(C.c_double), vp]),
+    "mmm_nu_objective": (C.c_int, [vp, C.c_int, f64p, f64p, f64p, vp, f64p, C.POINTER(C.c_double), vp]),
+    "mmm_alpha_objective": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mmm_mixture_loglik": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, i64p, vp, vp, f64p, f64p, C.POINTER(C.c_double)]),
+    "mmm_mixture_loglik_features": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i64p, vp, vp, f64p, C.c_int, f64p, C.POINTER(C.c_double)]),
 }
 
 

@@ -1176,6 +1176,34 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
     if (act) { out[2 + l] = -g1; out[2 + MK + l] = -g2; }
 }
 
+// calculate_sumθ(model, d) / calculate_Ndivζ(model, d) (MMCTM.jl:110-125) from the stored θ and ζ: out[i] = Σ_w θ[k, w] n_w (w ascending),
+// out[MK + i] = N_dm / ζ_dm for coordinate i = off_m + k.  One block, one thread per coordinate.
+__global__ __launch_bounds__(256) void k_ctm_doc_sums(CtmDev c, int d, const double* zeta, const double* theta, double* out)
+{
+    const CtmDims& dm = c.dm;
+    const int MK = dm.MK, M = dm.M, l = threadIdx.x;
+    if (l >= MK) return;
+    int m = 0;
+    for (int q = 0; q < M; ++q) if (l >= dm.koff[q] && l < dm.koff[q + 1]) m = q;
+    const int Km = dm.K[m], k = l - dm.koff[m];
+    const int64_t* dp = c.doc_ptr + (size_t)m * (dm.D + 1);
+    double s = 0.0;
+    for (int64_t e = dp[d]; e < dp[d + 1]; ++e) s += theta[dm.toff[m] + (size_t)(e - dm.estart[m]) * Km + k] * (double)c.tc[e].y;
+    out[l] = s;
+    out[MK + l] = c.Ndm[(size_t)d * M + m] / zeta[(size_t)d * M + m];
+}
+
+// dst's theta columns of document d <- src's (per-document stage calls: only document d keeps the stage's result)
+__global__ __launch_bounds__(256) void k_ctm_copy_doc_theta(CtmDev c, int d, const double* src, double* dst)
+{
+    const CtmDims& dm = c.dm;
+    for (int m = 0; m < dm.M; ++m) {
+        const int64_t* dp = c.doc_ptr + (size_t)m * (dm.D + 1);
+        const size_t b = dm.toff[m] + (size_t)(dp[d] - dm.estart[m]) * dm.K[m], n = (size_t)(dp[d + 1] - dp[d]) * dm.K[m];
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[b + i] = src[b + i];
+    }
+}
+
 // wide tables: gamma statistics of one (modality, term) per block -- sums[goff[m] + k V_m + v] = sum over the term's postings of
 // n theta_kw (MMCTM.jl:230-240), theta_kw = a_dk e_kv / sum_k' a_dk' e_k'v from the theta phase's a_d rows and the term's table
 // column (scalar registers).  Postings (doc, count) in document order, split over the block's waves in contiguous segments,
@@ -2701,7 +2729,12 @@ int frozen_pass(mmm_ctm* m, Scope sc, int flags)
     return MMM_OK;
 }
 
-int prep(mmm_ctm* m) { MMM_HIP(m->ctx, hipSetDevice(m->ctx->device)); return MMM_OK; }
+int prep(mmm_ctm* m)
+{
+    if (int rc = mmm_ctx_usable(m->ctx, "CTM call")) return rc;
+    MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    return MMM_OK;
+}
 
 int upload_active(mmm_ctm* m)
 {
@@ -3257,6 +3290,59 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
     if (nu_val) *nu_val = h[1];
     if (lambda_grad) memcpy(lambda_grad, h.data() + 2, sizeof(double) * MK);
     if (nu_grad) memcpy(nu_grad, h.data() + 2 + MK, sizeof(double) * MK);
+    return MMM_OK;
+}
+
+int mmm_ctm_doc_sums(mmm_ctm* m, int d, double* sumtheta, double* Ndivzeta)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = begin_stage(m);
+    if (rc) return rc;
+    MMM_CHECK(ctx, d >= 0 && d < m->dm.D, "mmm_ctm_doc_sums: document %d out of range", d);
+    const size_t MK = m->dm.MK;
+    DevBuf<double> tmp;
+    MMM_HIP(ctx, tmp.alloc(2 * MK));
+    hipLaunchKernelGGL(k_ctm_doc_sums, dim3(1), dim3(256), 0, ctx->stream, m->dev(), d, m->zeta.p + (size_t)m->sel * m->dm.D * m->dm.M, m->theta.p, tmp.p);
+    MMM_LAUNCH_CHECK(ctx);
+    std::vector<double> h(2 * MK);
+    MMM_HIP(ctx, hipMemcpyAsync(h.data(), tmp.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sumtheta) memcpy(sumtheta, h.data(), sizeof(double) * MK);
+    if (Ndivzeta) memcpy(Ndivzeta, h.data() + MK, sizeof(double) * MK);
+    return MMM_OK;
+}
+
+// update_ζ!(model, d), update_θ!(model, d), update_ν!(model, d), update_λ!(model, d): the stage kernels process every document of the shard
+// in one launch, so the per-document form runs the stage and then puts every OTHER document's values back.
+int mmm_ctm_update_doc(mmm_ctm* m, int stage, int d)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = begin_stage(m);
+    if (rc) return rc;
+    MMM_CHECK(ctx, d >= 0 && d < m->dm.D, "mmm_ctm_update_doc: document %d out of range", d);
+    MMM_CHECK(ctx, stage >= MMM_STAGE_ZETA && stage <= MMM_STAGE_LAMBDA, "mmm_ctm_update_doc: unknown stage %d", stage);
+    if (stage == MMM_STAGE_THETA && (rc = claim_theta(m))) return rc;
+    const int field = stage == MMM_STAGE_ZETA ? MMM_CTM_ZETA : stage == MMM_STAGE_THETA ? MMM_CTM_THETA : stage == MMM_STAGE_NU ? MMM_CTM_NU : MMM_CTM_LAMBDA;
+    double* p; size_t cnt;
+    if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
+    DevBuf<double> save;
+    MMM_HIP(ctx, save.alloc(cnt));
+    if (cnt) MMM_HIP(ctx, hipMemcpyAsync(save.p, p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = stage == MMM_STAGE_ZETA ? mmm_ctm_update_zeta(m) : stage == MMM_STAGE_THETA ? mmm_ctm_update_theta(m) : stage == MMM_STAGE_NU ? mmm_ctm_update_nu(m)
+                                                                                                                                       : mmm_ctm_update_lambda(m);
+    if (rc) return rc;
+    if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
+    if (stage == MMM_STAGE_THETA) {
+        hipLaunchKernelGGL(k_ctm_copy_doc_theta, dim3(1), dim3(256), 0, ctx->stream, m->dev(), d, p, save.p);
+        MMM_LAUNCH_CHECK(ctx);
+    } else {
+        const size_t w = stage == MMM_STAGE_ZETA ? m->dm.M : m->dm.MK;
+        MMM_HIP(ctx, hipMemcpyAsync(save.p + (size_t)d * w, p + (size_t)d * w, sizeof(double) * w, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (cnt) MMM_HIP(ctx, hipMemcpyAsync(p, save.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMM_OK;
 }
 

@@ -40,22 +40,12 @@ int mmm_ctx_create(int device_id, mmm_ctx** out)
     return MMM_OK;
 }
 
-int mmm_ctx_destroy(mmm_ctx* ctx)
+// Lifetime: ctx->refs counts the live models plus one reference held by the owner of the context (dropped by mmm_ctx_destroy).  Whoever
+// drops the last reference runs the teardown, and nobody reads ctx after dropping a reference -- finalizers of a garbage-collected host run
+// in any order and on any thread.
+static void ctx_teardown(mmm_ctx* ctx)
 {
-    if (!ctx) return MMM_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // nothing in flight may still touch the pinned block, the events or a peer
-    if (ctx->live_models.load() > 0) {
-        // models outlive their context (a garbage-collected host): give up everything that involves other ranks NOW, while they are
-        // still there -- the models may only be destroyed after this call, not used -- and leave the rest to the last model's destroy
-        mmm_p2p_release(ctx);
-        if (ctx->comm) { (void)ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
-        ctx->nranks = 1; ctx->rank = 0;
-        ctx->destroy_pending.store(true);
-        if (ctx->live_models.load() > 0) return MMM_DEFERRED;
-        bool expect = true;      // the last model went away in between: whoever flips the flag runs the teardown
-        if (!ctx->destroy_pending.compare_exchange_strong(expect, false)) return MMM_DEFERRED;
-    }
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pin_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
@@ -66,6 +56,23 @@ int mmm_ctx_destroy(mmm_ctx* ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
+}
+
+int mmm_ctx_destroy(mmm_ctx* ctx)
+{
+    if (!ctx) return MMM_OK;
+    if (ctx->closing.exchange(true)) return MMM_DEFERRED;          // a second destroy while models are still alive: nothing left to give up
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);      // nothing in flight may still touch the pinned block, the events or a peer
+    // give up everything that involves other ranks NOW, while they are still there.  Models that outlive their context (a
+    // garbage-collected host) may only be destroyed after this call; a model of a multi-rank context that is USED afterwards gets an
+    // error from its next call (its sums would silently be rank-local), see mmm_ctx_usable
+    if (ctx->nranks > 1) ctx->closed_multi.store(true);
+    mmm_p2p_release(ctx);
+    if (ctx->comm) { (void)ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ctx->nranks = 1; ctx->rank = 0;
+    if (ctx->refs.fetch_sub(1) - 1 > 0) return MMM_DEFERRED;        // ctx may be gone from here on
+    ctx_teardown(ctx);
     return MMM_OK;
 }
 
@@ -181,10 +188,16 @@ void mmm_solver_opts_default(mmm_solver_opts* o)
 
 } // extern "C"
 
-void mmm_ctx_model_created(mmm_ctx* ctx) { ctx->live_models.fetch_add(1); }
+void mmm_ctx_model_created(mmm_ctx* ctx) { ctx->refs.fetch_add(1); }
 void mmm_ctx_model_destroyed(mmm_ctx* ctx)
 {
-    if (ctx->live_models.fetch_sub(1) - 1 > 0) return;
-    bool expect = true;
-    if (ctx->destroy_pending.compare_exchange_strong(expect, false)) (void)mmm_ctx_destroy(ctx);
+    if (ctx->refs.fetch_sub(1) - 1 == 0) ctx_teardown(ctx);      // the owner's reference went first (MMM_DEFERRED) and this was the last model
+}
+
+int mmm_ctx_usable(mmm_ctx* ctx, const char* what)
+{
+    if (ctx->closed_multi.load())
+        return mmm_fail(ctx, MMM_ERR_ARG, "%s: the context of this model was destroyed while it had %s; the model can only be destroyed", what,
+                        "a communicator (its sums would be rank-local)");
+    return MMM_OK;
 }

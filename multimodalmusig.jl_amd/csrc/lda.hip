@@ -2809,6 +2809,7 @@ int frozen_passes(mmm_lda* m, int n_iter, int unsmoothed, double tol, int conv_b
 
 int prepare_call(mmm_lda* m)
 {
+    if (int rc = mmm_ctx_usable(m->ctx, "LDA call")) return rc;
     MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
     return sync_ctl(m);
 }
@@ -3221,6 +3222,27 @@ int mmm_lda_update_lambda(mmm_lda* m)
     return run_topic_update(m, true);
 }
 
+int mmm_lda_update_Elntheta(mmm_lda* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prepare_call(m);
+    if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
+    const int c = m->cur();
+    if (m->D) hipLaunchKernelGGL(m->K > 64 ? k_lda_Elntheta_big : k_lda_Elntheta, dim3(m->grid_s), dim3(kBlock), 0, m->ctx->stream, m->dev(), m->gamma[c].p, m->Elntheta[c].p);
+    MMM_LAUNCH_CHECK(m->ctx);
+    m->gnext_valid = false; m->phi_from_prev = false;
+    return MMM_OK;
+}
+
+int mmm_lda_update_Elnbeta(mmm_lda* m)
+{
+    if (!m) return MMM_ERR_ARG;
+    int rc = prepare_call(m);
+    if (rc || (rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
+    m->gnext_valid = false; m->phi_from_prev = false;
+    return run_topic_update(m, false);      // ILDA handles: the factors' Elnβ[i] and the effective table (ILDA.jl:96-101)
+}
+
 int mmm_lda_update_beta(mmm_lda* m)
 {
     if (!m) return MMM_ERR_ARG;
@@ -3266,6 +3288,7 @@ int mmm_lda_iterate(mmm_lda* m, int n_iter)
 {
     if (!m) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
+    if (int rc = mmm_ctx_usable(ctx, "mmm_lda_iterate")) return rc;
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     MMM_CHECK(ctx, n_iter >= 0, "mmm_lda_iterate: n_iter < 0");
     if (m->stop_seen) {      // a previous fit! left the device stop flag set

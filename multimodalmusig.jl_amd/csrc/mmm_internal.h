@@ -48,12 +48,14 @@ struct mmm_ctx {
     // beside the solve phase and is joined before the log-likelihood launch (lazily created; always joined within the pass)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::atomic<int> live_models{0};
-    std::atomic<bool> destroy_pending{false};
+    std::atomic<int> refs{1};                 // live models + 1 for the owner (dropped by mmm_ctx_destroy); the last one out tears down
+    std::atomic<bool> closing{false};         // mmm_ctx_destroy has run
+    std::atomic<bool> closed_multi{false};    // ... on a context that had a communicator: surviving models must not be used any more
 };
 
 void mmm_ctx_model_created(mmm_ctx* ctx);
 void mmm_ctx_model_destroyed(mmm_ctx* ctx);      // may delete ctx
+int mmm_ctx_usable(mmm_ctx* ctx, const char* what);   // error once a multi-rank context has been destroyed under a live model
 
 // RAII span: records an event pair around a launch while profiling is on
 struct ProfSpan {

@@ -2,8 +2,10 @@
 
 Field names follow the reference structs (MMCTM.jl:1-27, IMMCTM.jl:1-27).  State lives in HBM inside the C-ABI handle;
 nested fields (`model.θ[d][m]`, `model.γ[m][k]`, ...) are write-through views.  The per-document functions of the
-reference (`update_ζ!(model, d)`, ...) process EVERY document here (the `d` argument is accepted and ignored): the result
-for document d is what the reference computes for it.  There is no CPU implementation in this package.
+reference (`update_ζ!(model, d)`, ...) change document d only (0-based here; mmm_ctm_update_doc); without `d` they process
+every document in one launch, which is what `fitdoc!` over all documents does.  The reference's free functions (λ_objective,
+ν_objective, α_objective, calculate_modality_loglikelihood: common.jl:11-46, MMCTM.jl:384-418, IMMCTM.jl:362-407) are
+here as functions over plain arrays.  There is no CPU implementation in this package.
 """
 import ctypes as C
 
@@ -346,20 +348,102 @@ def _call(model, fn, what):
     check(getattr(lib(), fn)(model._h), model.ctx.h, what)
 
 
+def _doc_stage(model, fn, stage, what, d):
+    if d is None:
+        _call(model, fn, what)
+    else:
+        check(lib().mmm_ctm_update_doc(model._h, stage, int(d)), model.ctx.h, "%s(model, %d)" % (what, d))
+
+
 def update_ζ(model, d=None):      # MMCTM.jl:172-181
-    _call(model, "mmm_ctm_update_zeta", "update_ζ!")
+    _doc_stage(model, "mmm_ctm_update_zeta", 0, "update_ζ!", d)
 
 
 def update_θ_ctm(model, d=None):  # MMCTM.jl:183-198 / IMMCTM.jl:152-172
-    _call(model, "mmm_ctm_update_theta", "update_θ!")
+    _doc_stage(model, "mmm_ctm_update_theta", 1, "update_θ!", d)
 
 
 def update_ν(model, d=None):      # MMCTM.jl:156-170
-    _call(model, "mmm_ctm_update_nu", "update_ν!")
+    _doc_stage(model, "mmm_ctm_update_nu", 2, "update_ν!", d)
 
 
 def update_λ_ctm(model, d=None):  # MMCTM.jl:127-143
-    _call(model, "mmm_ctm_update_lambda", "update_λ!")
+    _doc_stage(model, "mmm_ctm_update_lambda", 3, "update_λ!", d)
+
+
+def calculate_sumθ(model, d):     # MMCTM.jl:110-117
+    out = np.zeros(model.MK)
+    check(lib().mmm_ctm_doc_sums(model._h, int(d), out.ctypes.data, None), model.ctx.h, "calculate_sumθ")
+    return out
+
+
+def calculate_Ndivζ(model, d):    # MMCTM.jl:119-125
+    out = np.zeros(model.MK)
+    check(lib().mmm_ctm_doc_sums(model._h, int(d), None, out.ctypes.data), model.ctx.h, "calculate_Ndivζ")
+    return out
+
+
+# ---- free functions (src/common.jl; the log-likelihood helpers) --------------------------------------------------------------
+def _f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def λ_objective(λ, grad, ν, Ndivζ, sumθ, μ, invΣ, ctx=None):      # common.jl:11-23; `grad` (array or None) is filled in place like ∇λ
+    ctx = ctx or _lib.default_context()
+    n = len(λ); v = C.c_double()
+    g = np.zeros(n) if grad is not None else None
+    check(lib().mmm_lambda_objective(ctx.h, n, _f64(λ), _f64(ν), _f64(Ndivζ), _f64(sumθ), _f64(μ), _f64(np.asarray(invΣ, dtype=np.float64).T.ravel()),
+                                     C.byref(v), g.ctypes.data if g is not None else None), ctx.h, "λ_objective")
+    if grad is not None:
+        grad[:] = g
+    return v.value
+
+
+def ν_objective(ν, grad, λ, Ndivζ, μ, invΣ, ctx=None):            # common.jl:25-36
+    ctx = ctx or _lib.default_context()
+    n = len(ν); v = C.c_double()
+    g = np.zeros(n) if grad is not None else None
+    mu = _f64(μ) if μ is not None else None
+    check(lib().mmm_nu_objective(ctx.h, n, _f64(ν), _f64(λ), _f64(Ndivζ), mu.ctypes.data if mu is not None else None,
+                                 _f64(np.asarray(invΣ, dtype=np.float64).T.ravel()), C.byref(v), g.ctypes.data if g is not None else None), ctx.h, "ν_objective")
+    if grad is not None:
+        grad[:] = g
+    return v.value
+
+
+def α_objective(α, grad, sum_Elnϕ, K, V, ctx=None):               # common.jl:38-46 (α a 1-vector, as NLopt hands it over)
+    ctx = ctx or _lib.default_context()
+    v = C.c_double(); g = C.c_double()
+    check(lib().mmm_alpha_objective(ctx.h, float(α[0]), float(sum_Elnϕ), int(K), int(V), C.byref(v), C.byref(g)), ctx.h, "α_objective")
+    if grad is not None and len(grad) > 0:
+        grad[0] = g.value
+    return v.value
+
+
+def calculate_modality_loglikelihood(X, props, ϕ, features=None, ctx=None, softmax=True):
+    """MMCTM.jl:402-418 (X: documents of ONE modality, props[d]: K proportions, ϕ[k]: V term probabilities) or, with `features` (V x I,
+    1-based values), IMMCTM.jl:387-407 (props is then η[d], ϕ[k][i]: J_i feature-value probabilities)."""
+    from .utils import pack_lda
+    ctx = ctx or _lib.default_context()
+    doc_ptr, term, count = pack_lda(X)
+    D, K = len(X), len(ϕ)
+    P = _f64(np.asarray([np.asarray(p, dtype=np.float64) for p in props]).reshape(D, K))
+    tp = term.ctypes.data if term.size else None; cp = count.ctypes.data if count.size else None
+    v = C.c_double()
+    if features is None:
+        F = _f64(np.asarray([np.asarray(x, dtype=np.float64) for x in ϕ]))
+        check(lib().mmm_mixture_loglik(ctx.h, D, K, F.shape[1], doc_ptr, tp, cp, P.ravel(), F.ravel(), C.byref(v)), ctx.h, "calculate_modality_loglikelihood")
+    else:
+        f = np.asarray(features, dtype=np.int64)
+        J = np.ascontiguousarray(f.max(axis=0), dtype=np.int32)
+        F = _f64(np.concatenate([np.concatenate([np.asarray(ϕ[k][i], dtype=np.float64) for i in range(f.shape[1])]) for k in range(K)]))
+        check(lib().mmm_mixture_loglik_features(ctx.h, D, K, f.shape[0], f.shape[1], J, np.ascontiguousarray((f - 1).T.ravel(), dtype=np.int32), doc_ptr, tp, cp,
+                                                P.ravel(), 1 if softmax else 0, F, C.byref(v)), ctx.h, "calculate_modality_loglikelihood")
+    return v.value
+
+
+def calculate_docmodality_loglikelihood(Xd, props, ϕ, features=None, ctx=None):      # MMCTM.jl:384-400 / IMMCTM.jl:362-385
+    return calculate_modality_loglikelihood([Xd], [props], ϕ, features=features, ctx=ctx)
 
 
 def update_μ(model):              # MMCTM.jl:200-202

@@ -6,6 +6,15 @@
 # library handle; after `fit!` the fields the reference exposes (ϕ, θ, γ, λ, μ, Σ, props, elbo, ll, converged, ...) are
 # downloaded into ordinary Julia arrays of the reference's shapes.
 #
+# The un-exported functions the reference's own test-suite drives the path through (test/lda.jl, ilda.jl, mmctm.jl, immctm.jl,
+# common.jl: `MultiModalMuSig.update_ϕ!(model)`, `update_ζ!(model, d)`, `calculate_sumθ(model, d)`, `λ_objective(...)`,
+# `calculate_modality_loglikelihood(...)`, `calculate_ElnPβ(model)`, ...) are all defined here under the same names and
+# signatures -- the STAGE API at the end of each model's section and the FREE FUNCTIONS section.  Between stage calls the Julia
+# arrays ARE the model, exactly as upstream: the tests assign fields in place (`model.Elnθ .= Elnθ`, `model.θ[1][1] = ...`,
+# `model.ζ = ...`) and then call one function, so every stage call uploads the fields (`upload!`), runs ONE entry point of
+# the library and copies back, in place, the fields the reference function writes.  tests/golden/reference_test_api.json lists
+# every `MultiModalMuSig.<name>` the reference's tests use; tests/test_julia_shim_cpu.py checks each is defined here.
+#
 # STATUS: Julia is not installed in the build container or on the GPU test boxes, so this file has NOT been executed;
 # it is a 1:1 mechanical mapping onto the C ABI (each ccall's argument list is the corresponding prototype of
 # include/mmmusig.h), which itself is exercised end-to-end by the Python host mirror and the test-suite.
@@ -121,14 +130,52 @@ function lda_get(model, field::Int, n::Int)
     return buf
 end
 
-function download!(model::LDA)
+# field ids of mmm_lda_get / mmm_lda_set (include/mmmusig.h): 0 λ, 1 Elnβ, 2 β, 3 γ, 4 Elnθ, 5 θ, 6 ϕ; ILDA factors 7 λ, 8 Elnβ, 9 β
+const LDA_FIELDS = (λ=0, Elnβ=1, β=2, γ=3, Elnθ=4, θ=5, ϕ=6)
+
+# ϕ[d] (K x W_d) of every document out of / into the flat K x nnz buffer of the library
+function unflatten_ϕ!(model, flat::Vector{Float64})
+    K = model.K
+    ϕ = Vector{Matrix{Float64}}(undef, model.D)
+    for d in 1:model.D
+        ϕ[d] = reshape(flat[K * model.doc_ptr[d] + 1:K * model.doc_ptr[d + 1]], K, :)
+    end
+    model.ϕ = ϕ
+end
+flatten_ϕ(model) = reduce(vcat, [vec(Matrix{Float64}(p)) for p in model.ϕ]; init=Float64[])
+
+# the reference's functions mutate the model's arrays in place (`.=`): keep the array when the shape allows, replace it otherwise
+function assign!(model, f::Symbol, new::Array{Float64})
+    if isdefined(model, f) && size(getfield(model, f)) == size(new)
+        copyto!(getfield(model, f), new)
+    else
+        setfield!(model, f, new)
+    end
+    return model
+end
+
+# one field device -> Julia array
+function download_field!(model::LDA, f::Symbol)
     V, K, D = model.V, model.K, model.D
-    model.λ = reshape(lda_get(model, 0, V * K), V, K); model.Elnβ = reshape(lda_get(model, 1, V * K), V, K)
-    model.β = reshape(lda_get(model, 2, V * K), V, K)
-    model.γ = reshape(lda_get(model, 3, K * D), K, D); model.Elnθ = reshape(lda_get(model, 4, K * D), K, D)
-    model.θ = reshape(lda_get(model, 5, K * D), K, D)
-    flat = lda_get(model, 6, K * model.doc_ptr[end])
-    model.ϕ = [reshape(flat[K * model.doc_ptr[d] + 1:K * model.doc_ptr[d + 1]], K, :) for d in 1:D]
+    if f == :ϕ
+        unflatten_ϕ!(model, lda_get(model, 6, K * model.doc_ptr[end]))
+    elseif f in (:λ, :Elnβ, :β)
+        assign!(model, f, reshape(lda_get(model, LDA_FIELDS[f], V * K), V, K))
+    else
+        assign!(model, f, reshape(lda_get(model, LDA_FIELDS[f], K * D), K, D))
+    end
+    return model
+end
+
+function download!(model::LDA)
+    for f in (:λ, :Elnβ, :β, :γ, :Elnθ, :θ, :ϕ) download_field!(model, f) end
+    return model
+end
+
+# Julia arrays -> device, every field (see the header comment: the arrays are the model between stage calls)
+function upload!(model::LDA)
+    for f in (:λ, :Elnβ, :β, :γ, :Elnθ, :θ) lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f)))) end
+    lda_set(model, 6, flatten_ϕ(model))
     return model
 end
 
@@ -146,11 +193,20 @@ function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true)
     return ll
 end
 
-# ---- LDA frozen-topic inference (LDA.jl:226-295) ------------------------------------------------------------------------
 function lda_set(model, field::Int, v::Vector{Float64})
     check(ccall((:mmm_lda_set, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Csize_t), model.h, field, v, length(v)), model.ctx, "mmm_lda_set")
 end
 
+# ---- LDA / ILDA stage API: update_ϕ!, update_γ! (+ update_Elnθ!), update_λ! (+ update_Elnβ!), update_β!, update_θ! -- LDA.jl:69-112,
+# ILDA.jl:65-130 -- the calls of test/lda.jl:38-103 and test/ilda.jl:52-158.  `written`: the fields the reference function writes.
+function lda_stage!(model, rc_of_call::Function, what::String, written)
+    upload!(model)
+    check(rc_of_call(), model.ctx, what)
+    for f in written download_field!(model, f) end
+    return nothing
+end
+
+# ---- LDA frozen-topic inference (LDA.jl:226-295) ------------------------------------------------------------------------
 function lda_infer!(model, unsmoothed::Bool, maxiter::Int, tol::Float64, verbose::Bool)
     ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0)
     check(ccall((:mmm_lda_infer, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}),
@@ -226,17 +282,91 @@ end
 ILDA(k::Int, α::Float64, η::Float64, features::Matrix{Int}, X::Vector{Matrix{Int}}; kw...) =      # ILDA.jl:58-63
     ILDA(k, α, fill(η, size(features, 2)), features, X; kw...)
 
-function download!(model::ILDA)
+const ILDA_FACTOR_FIELDS = (λ=7, Elnβ=8, β=9)
+
+function download_field!(model::ILDA, f::Symbol)
     K, D = model.K, model.D
-    off = cumsum([0; model.J .* K])
-    factors(field) = (f = lda_get(model, field, off[end]); [reshape(f[off[i] + 1:off[i + 1]], model.J[i], K) for i in 1:model.I])
-    model.λ = factors(7); model.Elnβ = factors(8); model.β = factors(9)
-    model.γ = reshape(lda_get(model, 3, K * D), K, D); model.Elnθ = reshape(lda_get(model, 4, K * D), K, D)
-    model.θ = reshape(lda_get(model, 5, K * D), K, D)
-    flat = lda_get(model, 6, K * model.doc_ptr[end])
-    model.ϕ = [reshape(flat[K * model.doc_ptr[d] + 1:K * model.doc_ptr[d + 1]], K, :) for d in 1:D]
+    if f == :ϕ
+        unflatten_ϕ!(model, lda_get(model, 6, K * model.doc_ptr[end]))
+    elseif f in (:λ, :Elnβ, :β)                     # J_i x K column-major, feature after feature
+        off = cumsum([0; model.J .* K])
+        flat = lda_get(model, ILDA_FACTOR_FIELDS[f], off[end])
+        setfield!(model, f, Matrix{Float64}[reshape(flat[off[i] + 1:off[i + 1]], model.J[i], K) for i in 1:model.I])
+    else
+        assign!(model, f, reshape(lda_get(model, LDA_FIELDS[f], K * D), K, D))
+    end
     return model
 end
+
+function download!(model::ILDA)
+    for f in (:λ, :Elnβ, :β, :γ, :Elnθ, :θ, :ϕ) download_field!(model, f) end
+    return model
+end
+
+packed_factors(fs) = reduce(vcat, [vec(Matrix{Float64}(f)) for f in fs]; init=Float64[])
+
+function upload!(model::ILDA)
+    # the factor arrays; the library derives its effective V x K tables from the uploaded Elnβ[i] / β[i]
+    for f in (:λ, :Elnβ, :β) lda_set(model, ILDA_FACTOR_FIELDS[f], packed_factors(getfield(model, f))) end
+    for f in (:γ, :Elnθ, :θ) lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f)))) end
+    lda_set(model, 6, flatten_ϕ(model))
+    return model
+end
+
+# stage functions of LDA and ILDA (same C handle type, same entry points)
+const TopicModel = Union{LDA,ILDA}
+update_ϕ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_phi, LIB), Cint, (Ptr{Cvoid},), model.h), "update_ϕ!", (:ϕ,))
+update_Elnθ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_Elntheta, LIB), Cint, (Ptr{Cvoid},), model.h), "update_Elnθ!", (:Elnθ,))
+update_γ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_gamma, LIB), Cint, (Ptr{Cvoid},), model.h), "update_γ!", (:γ, :Elnθ))
+update_θ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_theta, LIB), Cint, (Ptr{Cvoid},), model.h), "update_θ!", (:θ,))
+update_Elnβ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_Elnbeta, LIB), Cint, (Ptr{Cvoid},), model.h), "update_Elnβ!", (:Elnβ,))
+update_λ!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_lambda, LIB), Cint, (Ptr{Cvoid},), model.h), "update_λ!", (:λ, :Elnβ))
+update_β!(model::TopicModel) = lda_stage!(model, () -> ccall((:mmm_lda_update_beta, LIB), Cint, (Ptr{Cvoid},), model.h), "update_β!", (:β,))
+
+# calculate_elbo and its seven terms (LDA.jl:114-172; ILDA.jl:132-201): one launch sequence, terms[7] =
+# (ElnPβ, ElnPθ, ElnPZ, ElnPX, ElnQβ, ElnQθ, ElnQZ); elbo = the first four minus the last three
+function elbo_terms(model::TopicModel)
+    upload!(model)
+    e = Ref{Cdouble}(0.0); t = Vector{Float64}(undef, 7)
+    check(ccall((:mmm_lda_elbo, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ptr{Cdouble}), model.h, e, t), model.ctx, "mmm_lda_elbo")
+    return e[], t
+end
+calculate_elbo(model::TopicModel) = elbo_terms(model)[1]
+calculate_ElnPβ(model::TopicModel) = elbo_terms(model)[2][1]
+calculate_ElnPθ(model::TopicModel) = elbo_terms(model)[2][2]
+calculate_ElnPZ(model::TopicModel) = elbo_terms(model)[2][3]
+calculate_ElnPX(model::TopicModel) = elbo_terms(model)[2][4]
+calculate_ElnQβ(model::TopicModel) = elbo_terms(model)[2][5]
+calculate_ElnQθ(model::TopicModel) = elbo_terms(model)[2][6]
+calculate_ElnQZ(model::TopicModel) = elbo_terms(model)[2][7]
+
+# calculate_loglikelihood -- LDA.jl:174-196 (X, θ, β) and ILDA.jl:203-239 (X, features, θ, β): free functions over the caller's arrays
+function calculate_loglikelihood(X::Vector{Matrix{Int}}, θ::Matrix{Float64}, β::Matrix{Float64}; ctx::Context=default_context())
+    doc_ptr, term, count = pack_lda(X)
+    ll = Ref{Cdouble}(0.0)
+    K, V = size(θ, 1), size(β, 1)
+    check(ccall((:mmm_mixture_loglik, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+                ctx.h, length(X), K, V, doc_ptr, term, count, vec(θ), vec(β), ll), ctx, "mmm_mixture_loglik")
+    return ll[]
+end
+calculate_loglikelihood(X::Vector{Matrix{Int}}, model::LDA) = calculate_loglikelihood(X, model.θ, model.β; ctx=model.ctx)
+calculate_loglikelihood(model::LDA) = calculate_loglikelihood(model.X, model.θ, model.β; ctx=model.ctx)
+
+function calculate_loglikelihood(X::Vector{Matrix{Int}}, features::Matrix{Int}, θ::Matrix{Float64}, β::Vector{Matrix{Float64}};
+                                 ctx::Context=default_context())
+    doc_ptr, term, count = pack_lda(X)
+    ll = Ref{Cdouble}(0.0)
+    K, V, I = size(θ, 1), size(features, 1), size(features, 2)
+    J = Cint[size(β[i], 1) for i in 1:I]
+    ϕflat = reduce(vcat, [reduce(vcat, [β[i][:, k] for i in 1:I]) for k in 1:K])      # [k][i][j] = β[i][j, k]
+    check(ccall((:mmm_mixture_loglik_features, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ref{Cdouble}),
+                ctx.h, length(X), K, V, I, J, Int32.(vec(features .- 1)), doc_ptr, term, count, vec(θ), 0, ϕflat, ll), ctx, "mmm_mixture_loglik_features")
+    return ll[]
+end
+calculate_loglikelihood(X::Vector{Matrix{Int}}, model::ILDA) = calculate_loglikelihood(X, model.features, model.θ, model.β; ctx=model.ctx)
+calculate_loglikelihood(model::ILDA) = calculate_loglikelihood(model.X, model.features, model.θ, model.β; ctx=model.ctx)
 
 # fit!(model; maxiter, tol, verbose) -- ILDA.jl:246-272
 function fit!(model::ILDA; maxiter=1000, tol=1e-4, verbose=true)
@@ -535,5 +665,232 @@ function predict_modality_η(Xobs::Vector{Vector{Matrix{Int}}}, m::Int, model::U
     A = model.Σ[unobs, obs] * model.invΣ[obs, obs]                         # :627-633
     return [model.μ[unobs] .+ A * (obsmodel.λ[d] .- model.μ[obs]) for d in 1:obsmodel.D]
 end
+
+
+# ---- MMCTM / IMMCTM stage API -- MMCTM.jl:110-269, IMMCTM.jl:90-244: the calls of test/mmctm.jl:59-293 and test/immctm.jl:80-294 -----
+# field ids of mmm_ctm_get / mmm_ctm_set: 0 μ, 1 Σ, 2 invΣ, 3 γ, 4 Elnϕ, 5 ϕ, 6 λ, 7 ν, 8 ζ, 9 props, 10 θ, 11 α
+const CTM = Union{MMCTM,IMMCTM}
+
+flat_docs(xs) = reduce(vcat, [Vector{Float64}(x) for x in xs]; init=Float64[])           # [d][i] -> [i + n (d-1)]
+# θ[d][m] (K_m x W_dm) -> the library's modality-major buffer: all documents of modality 1, then modality 2, ...
+flat_θ(model) = reduce(vcat, [reduce(vcat, [vec(Matrix{Float64}(model.θ[d][m])) for d in 1:model.D]; init=Float64[]) for m in 1:model.M]; init=Float64[])
+topic_flat(model::MMCTM, nested) = Vector{Float64}(flat(nested))
+topic_flat(model::IMMCTM, nested) = Vector{Float64}(flat3(nested))
+
+# Julia arrays -> device, every field (the arrays are the model between stage calls)
+function upload!(model::CTM)
+    ctm_set(model, 0, Vector{Float64}(model.μ)); ctm_set(model, 1, vec(Matrix{Float64}(model.Σ))); ctm_set(model, 2, vec(Matrix{Float64}(model.invΣ)))
+    ctm_set(model, 3, topic_flat(model, model.γ)); ctm_set(model, 4, topic_flat(model, model.Elnϕ))
+    ctm_set(model, 6, flat_docs(model.λ)); ctm_set(model, 7, flat_docs(model.ν)); ctm_set(model, 8, flat_docs(model.ζ))
+    ctm_set(model, 10, flat_θ(model))
+    if model isa MMCTM
+        ctm_set(model, 5, topic_flat(model, model.ϕ))
+        ctm_set(model, 9, reduce(vcat, [reduce(vcat, model.props[d]) for d in 1:model.D]; init=Float64[]))
+        ctm_set(model, 11, Vector{Float64}(model.α))
+    else
+        ctm_set(model, 11, Vector{Float64}(reduce(vcat, model.α)))
+    end
+    return model
+end
+
+# device -> Julia arrays, one field of the reference struct
+function download_field!(model::CTM, f::Symbol)
+    M, D, K = model.M, model.D, model.K
+    MK = sum(K); koff = cumsum([0; K])
+    if f == :μ
+        model.μ = ctm_get(model, 0, MK)
+    elseif f == :Σ
+        model.Σ = reshape(ctm_get(model, 1, MK * MK), MK, MK)
+    elseif f == :invΣ
+        model.invΣ = reshape(ctm_get(model, 2, MK * MK), MK, MK)
+    elseif f == :λ
+        lam = reshape(ctm_get(model, 6, D * MK), MK, D); model.λ = [lam[:, d] for d in 1:D]
+    elseif f == :ν
+        nu = reshape(ctm_get(model, 7, D * MK), MK, D); model.ν = [nu[:, d] for d in 1:D]
+    elseif f == :ζ
+        z = reshape(ctm_get(model, 8, D * M), M, D); model.ζ = [z[:, d] for d in 1:D]
+    elseif f == :props
+        pr = reshape(ctm_get(model, 9, D * MK), MK, D)
+        model.props = [[pr[koff[m] + 1:koff[m + 1], d] for m in 1:M] for d in 1:D]
+    elseif f == :α
+        a = ctm_get(model, 11, model isa MMCTM ? M : sum(model.I))
+        if model isa MMCTM
+            model.α = a
+        else
+            off = cumsum([0; model.I]); model.α = [a[off[m] + 1:off[m + 1]] for m in 1:M]
+        end
+    elseif f == :θ
+        dp = model.doc_ptr
+        estart = [dp[(m - 1) * (D + 1) + 1] for m in 1:M]
+        nnz = [dp[m * (D + 1)] - estart[m] for m in 1:M]
+        toff = cumsum([0; nnz .* K])
+        th = ctm_get(model, 10, toff[end])
+        model.θ = [[reshape(th[toff[m] + (dp[(m - 1) * (D + 1) + d] - estart[m]) * K[m] + 1:toff[m] + (dp[(m - 1) * (D + 1) + d + 1] - estart[m]) * K[m]], K[m], :)
+                    for m in 1:M] for d in 1:D]
+    elseif f in (:γ, :Elnϕ, :ϕ)
+        id = f == :γ ? 3 : (f == :Elnϕ ? 4 : 5)
+        if model isa MMCTM
+            V = model.V; goff = cumsum([0; K .* V])
+            fl = ctm_get(model, id, goff[end])
+            setfield!(model, f, [[fl[goff[m] + (kk - 1) * V[m] + 1:goff[m] + kk * V[m]] for kk in 1:K[m]] for m in 1:M])
+        else
+            SJ = [sum(model.J[m]) for m in 1:M]; mgoff = cumsum([0; K .* SJ])
+            fl = ctm_get(model, id, mgoff[end])
+            setfield!(model, f, [[[fl[mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i - 1]) + 1:mgoff[m] + (kk - 1) * SJ[m] + sum(model.J[m][1:i])]
+                                   for i in 1:model.I[m]] for kk in 1:K[m]] for m in 1:M])
+        end
+    else
+        error("unknown field $f")
+    end
+    return model
+end
+
+# one document of a per-document field: the other documents keep their Julia arrays (update_ζ!(model, d) etc. touch index d only)
+function download_doc!(model::CTM, f::Symbol, d::Int)
+    old = getfield(model, f)
+    download_field!(model, f)
+    new = getfield(model, f)
+    for dd in 1:model.D
+        dd == d || (new[dd] = old[dd])
+    end
+    return model
+end
+
+function ctm_stage!(model::CTM, rc_of_call::Function, what::String, written)
+    upload!(model)
+    check(rc_of_call(), model.ctx, what)
+    for f in written download_field!(model, f) end
+    return nothing
+end
+
+function ctm_doc_stage!(model::CTM, stage::Int, d::Int, what::String, f::Symbol)
+    upload!(model)
+    check(ccall((:mmm_ctm_update_doc, LIB), Cint, (Ptr{Cvoid}, Cint, Cint), model.h, stage, d - 1), model.ctx, what)
+    download_doc!(model, f, d)
+    return nothing
+end
+
+# per-document functions (MMM_STAGE_ZETA = 0, _THETA = 1, _NU = 2, _LAMBDA = 3)
+update_ζ!(model::CTM, d::Int) = ctm_doc_stage!(model, 0, d, "update_ζ!", :ζ)        # MMCTM.jl:172-181
+update_θ!(model::CTM, d::Int) = ctm_doc_stage!(model, 1, d, "update_θ!", :θ)        # MMCTM.jl:183-198 / IMMCTM.jl:152-172
+update_ν!(model::CTM, d::Int) = ctm_doc_stage!(model, 2, d, "update_ν!", :ν)        # MMCTM.jl:156-170 (LD_MMA on the device)
+update_λ!(model::CTM, d::Int) = ctm_doc_stage!(model, 3, d, "update_λ!", :λ)        # MMCTM.jl:127-143 (LD_MMA on the device)
+function fitdoc!(model::CTM, d::Int)                                                   # MMCTM.jl:450-455
+    update_ζ!(model, d); update_θ!(model, d); update_ν!(model, d); update_λ!(model, d)
+end
+
+# M-step functions
+update_μ!(model::CTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_mu, LIB), Cint, (Ptr{Cvoid},), model.h), "update_μ!", (:μ,))                   # MMCTM.jl:200-202
+update_Σ!(model::CTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_Sigma, LIB), Cint, (Ptr{Cvoid},), model.h), "update_Σ!", (:Σ, :invΣ))         # MMCTM.jl:204-212
+update_Elnϕ!(model::CTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_Elnphi, LIB), Cint, (Ptr{Cvoid},), model.h), "update_Elnϕ!", (:Elnϕ,))     # MMCTM.jl:214-222
+update_γ!(model::CTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_gamma, LIB), Cint, (Ptr{Cvoid},), model.h), "update_γ!", (:γ, :Elnϕ))         # MMCTM.jl:224-242
+update_α!(model::CTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_alpha, LIB), Cint, (Ptr{Cvoid},), model.h), "update_α!", (:α,))               # MMCTM.jl:252-269
+update_ϕ!(model::MMCTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_phi, LIB), Cint, (Ptr{Cvoid},), model.h), "update_ϕ!", (:ϕ,))               # MMCTM.jl:244-250
+update_props!(model::MMCTM) = ctm_stage!(model, () -> ccall((:mmm_ctm_update_props, LIB), Cint, (Ptr{Cvoid},), model.h), "update_props!", (:props,)) # MMCTM.jl:145-154
+
+# calculate_sumθ(model, d), calculate_Ndivζ(model, d) -- MMCTM.jl:110-125
+function calculate_sumθ(model::CTM, d::Int)
+    upload!(model)
+    out = Vector{Float64}(undef, sum(model.K))
+    check(ccall((:mmm_ctm_doc_sums, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}), model.h, d - 1, out, C_NULL), model.ctx, "mmm_ctm_doc_sums")
+    return out
+end
+function calculate_Ndivζ(model::CTM, d::Int)
+    upload!(model)
+    out = Vector{Float64}(undef, sum(model.K))
+    check(ccall((:mmm_ctm_doc_sums, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}), model.h, d - 1, C_NULL, out), model.ctx, "mmm_ctm_doc_sums")
+    return out
+end
+
+# calculate_elbo and its seven terms (MMCTM.jl:271-382; IMMCTM.jl:247-360): terms[7] = (ElnPϕ, ElnPη, ElnPZ, ElnPX, ElnQϕ, ElnQη, ElnQZ)
+function elbo_terms(model::CTM)
+    upload!(model)
+    e = Ref{Cdouble}(0.0); t = Vector{Float64}(undef, 7)
+    check(ccall((:mmm_ctm_elbo, LIB), Cint, (Ptr{Cvoid}, Ref{Cdouble}, Ptr{Cdouble}), model.h, e, t), model.ctx, "mmm_ctm_elbo")
+    return e[], t
+end
+calculate_elbo(model::CTM) = elbo_terms(model)[1]
+calculate_ElnPϕ(model::CTM) = elbo_terms(model)[2][1]
+calculate_ElnPη(model::CTM) = elbo_terms(model)[2][2]
+calculate_ElnPZ(model::CTM) = elbo_terms(model)[2][3]
+calculate_ElnPX(model::CTM) = elbo_terms(model)[2][4]
+calculate_ElnQϕ(model::CTM) = elbo_terms(model)[2][5]
+calculate_ElnQη(model::CTM) = elbo_terms(model)[2][6]
+calculate_ElnQZ(model::CTM) = elbo_terms(model)[2][7]
+
+# ---- FREE FUNCTIONS of src/common.jl and the log-likelihood helpers: caller arrays in, one `ccall` each ---------------------------
+# λ_objective(λ, ∇λ, ν, Ndivζ, sumθ, μ, invΣ) -- common.jl:11-23 (∇λ is filled in place when it has elements, as upstream)
+function λ_objective(λ::Vector{Float64}, ∇λ::Vector{Float64}, ν::Vector{Float64}, Ndivζ::Vector{Float64}, sumθ::Vector{Float64},
+                     μ::Vector{Float64}, invΣ::Matrix{Float64}; ctx::Context=default_context())
+    val = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_lambda_objective, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}),
+                ctx.h, length(λ), λ, ν, Ndivζ, sumθ, μ, vec(invΣ), val, length(∇λ) > 0 ? pointer(∇λ) : Ptr{Cdouble}(C_NULL)), ctx, "mmm_lambda_objective")
+    return val[]
+end
+
+# ν_objective(ν, ∇ν, λ, Ndivζ, μ, invΣ) -- common.jl:25-36
+function ν_objective(ν::Vector{Float64}, ∇ν::Vector{Float64}, λ::Vector{Float64}, Ndivζ::Vector{Float64}, μ::Vector{Float64},
+                     invΣ::Matrix{Float64}; ctx::Context=default_context())
+    val = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_nu_objective, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}, Ptr{Cdouble}),
+                ctx.h, length(ν), ν, λ, Ndivζ, μ, vec(invΣ), val, length(∇ν) > 0 ? pointer(∇ν) : Ptr{Cdouble}(C_NULL)), ctx, "mmm_nu_objective")
+    return val[]
+end
+
+# α_objective(α, ∇α, sum_Elnϕ, K, V) -- common.jl:38-46
+function α_objective(α::Vector{Float64}, ∇α::Vector{Float64}, sum_Elnϕ::Float64, K::Int, V::Int; ctx::Context=default_context())
+    val = Ref{Cdouble}(0.0); g = Ref{Cdouble}(0.0)
+    check(ccall((:mmm_alpha_objective, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cint, Cint, Ref{Cdouble}, Ref{Cdouble}),
+                ctx.h, α[1], sum_Elnϕ, K, V, val, g), ctx, "mmm_alpha_objective")
+    length(∇α) > 0 && (∇α[1] = g[])
+    return val[]
+end
+
+# calculate_modality_loglikelihood(X, props, ϕ) -- MMCTM.jl:402-418; the per-document form (:384-400) is the D = 1 case
+function calculate_modality_loglikelihood(X::Vector{Matrix{Int}}, props::Vector{Vector{Float64}}, ϕ::Vector{Vector{Float64}};
+                                          ctx::Context=default_context())
+    doc_ptr, term, count = pack_lda(X)
+    ll = Ref{Cdouble}(0.0)
+    K, V = length(ϕ), length(ϕ[1])
+    check(ccall((:mmm_mixture_loglik, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
+                ctx.h, length(X), K, V, doc_ptr, term, count, reduce(vcat, props; init=Float64[]), reduce(vcat, ϕ), ll), ctx, "mmm_mixture_loglik")
+    return ll[]
+end
+calculate_docmodality_loglikelihood(X::Matrix{Int}, props::Vector{Float64}, ϕ::Vector{Vector{Float64}}; kw...) =
+    calculate_modality_loglikelihood(Matrix{Int}[X], Vector{Float64}[props], ϕ; kw...)
+
+function calculate_loglikelihoods(X::Vector{Vector{Matrix{Int}}}, props::Vector{Vector{Vector{Float64}}}, ϕ::Vector{Vector{Vector{Float64}}}; kw...)   # MMCTM.jl:420-440
+    D = length(X); M = length(ϕ)
+    return [calculate_modality_loglikelihood(Matrix{Int}[X[d][m] for d in 1:D], Vector{Float64}[props[d][m] for d in 1:D], ϕ[m]; kw...) for m in 1:M]
+end
+calculate_loglikelihoods(X::Vector{Vector{Matrix{Int}}}, model::MMCTM) = calculate_loglikelihoods(X, model.props, model.ϕ; ctx=model.ctx)     # MMCTM.jl:442-444
+calculate_loglikelihoods(model::MMCTM) = calculate_loglikelihoods(model.X, model.props, model.ϕ; ctx=model.ctx)                                  # MMCTM.jl:446-448
+
+# calculate_modality_loglikelihood(X, η, ϕ, features) -- IMMCTM.jl:387-407 (ϕ[k][i]: J_i probabilities; props = softmax(η[d]) on the device)
+function calculate_modality_loglikelihood(X::Vector{Matrix{Int}}, η::Vector{Vector{Float64}}, ϕ::Vector{Vector{Vector{Float64}}},
+                                          features::Matrix{Int}; ctx::Context=default_context())
+    doc_ptr, term, count = pack_lda(X)
+    ll = Ref{Cdouble}(0.0)
+    K, V, I = length(ϕ), size(features, 1), size(features, 2)
+    J = Cint[length(ϕ[1][i]) for i in 1:I]
+    check(ccall((:mmm_mixture_loglik_features, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{Int32}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ref{Cdouble}),
+                ctx.h, length(X), K, V, I, J, Int32.(vec(features .- 1)), doc_ptr, term, count, reduce(vcat, η; init=Float64[]), 1, flat(ϕ), ll),
+          ctx, "mmm_mixture_loglik_features")
+    return ll[]
+end
+calculate_docmodality_loglikelihood(X::Matrix{Int}, η::Vector{Float64}, ϕ::Vector{Vector{Vector{Float64}}}, features::Matrix{Int}; kw...) =
+    calculate_modality_loglikelihood(Matrix{Int}[X], Vector{Float64}[η], ϕ, features; kw...)                                                  # IMMCTM.jl:362-385
+
+function calculate_loglikelihoods(X::Vector{Vector{Matrix{Int}}}, model::IMMCTM)                                                              # IMMCTM.jl:408-428
+    koff = cumsum([0; model.K])
+    return [calculate_modality_loglikelihood(Matrix{Int}[X[d][m] for d in 1:model.D], Vector{Float64}[model.λ[d][koff[m] + 1:koff[m + 1]] for d in 1:model.D],
+                                             [[model.γ[m][k][i] ./ sum(model.γ[m][k][i]) for i in 1:model.I[m]] for k in 1:model.K[m]], model.features[m];
+                                             ctx=model.ctx) for m in 1:model.M]
+end
+calculate_loglikelihoods(model::IMMCTM) = calculate_loglikelihoods(model.X, model)
 
 end # module

@@ -250,6 +250,14 @@ def update_β(model):   # LDA.jl:110-112
     _call(model, "mmm_lda_update_beta", "update_β!")
 
 
+def update_Elnθ(model):   # LDA.jl:78-80
+    _call(model, "mmm_lda_update_Elntheta", "update_Elnθ!")
+
+
+def update_Elnβ(model):   # LDA.jl:96-98 ; ILDA.jl:96-101
+    _call(model, "mmm_lda_update_Elnbeta", "update_Elnβ!")
+
+
 def update_θ(model, d=None):   # LDA.jl:92-94 ; MMCTM.jl:183-198 ; IMMCTM.jl:152-172
     if isinstance(model, LDA):
         _call(model, "mmm_lda_update_theta", "update_θ!")
@@ -258,7 +266,16 @@ def update_θ(model, d=None):   # LDA.jl:92-94 ; MMCTM.jl:183-198 ; IMMCTM.jl:15
         ctm.update_θ_ctm(model, d)
 
 
-def calculate_loglikelihood(model):   # LDA.jl:194-196
+def calculate_loglikelihood(model, θ=None, β=None, ctx=None):
+    """calculate_loglikelihood(model) -- LDA.jl:194-196, or the free form calculate_loglikelihood(X, θ, β) -- LDA.jl:174-188 (θ K x D, β V x K)."""
+    if θ is not None:
+        doc_ptr, term, count = pack_lda(model)
+        ctx = ctx or _lib.default_context()
+        th = np.ascontiguousarray(np.asarray(θ, dtype=np.float64).T); be = np.ascontiguousarray(np.asarray(β, dtype=np.float64).T)   # [k + K d], [k V + v]
+        v = C.c_double()
+        check(lib().mmm_mixture_loglik(ctx.h, len(model), th.shape[1], be.shape[1], doc_ptr, term.ctypes.data if term.size else None,
+                                       count.ctypes.data if count.size else None, th.ravel(), be.ravel(), C.byref(v)), ctx.h, "calculate_loglikelihood")
+        return v.value
     v = C.c_double()
     check(lib().mmm_lda_loglik(model._h, C.byref(v)), model.ctx.h, "calculate_loglikelihood")
     return v.value

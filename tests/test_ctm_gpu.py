@@ -55,8 +55,10 @@ def test_update_zeta(mmm, kats, imm):                       # test/mmctm.jl:158-
     model = _toy(mmm, kats, imm)
     k = kats["update_zeta"]
     model.λ = k["lambda"]; model.ν = k["nu"]
-    mmm.update_ζ(model, 1)
+    z1 = np.array(model.ζ[1])
+    mmm.update_ζ(model, 0)                                  # update_ζ!(model, 1): documents are 0-based on this side
     np.testing.assert_allclose(model.ζ[0], k["zeta_doc1"], rtol=1e-14)
+    assert np.array_equal(model.ζ[1], z1)                   # ... and only that document changes
 
 
 def test_update_theta_mmctm(mmm, kats):                     # test/mmctm.jl:168-209
@@ -65,9 +67,12 @@ def test_update_theta_mmctm(mmm, kats):                     # test/mmctm.jl:168-
     model.λ = k["lambda"]
     model.γ = k["gamma"]
     mmm.update_Elnϕ(model)
-    mmm.update_θ(model, 1)
+    t2 = np.array(model.θ[1][1])
+    mmm.update_θ(model, 0)
     np.testing.assert_allclose(model.θ[0][0].sum(axis=0), 1.0, rtol=1e-14)
     np.testing.assert_allclose(model.θ[0][0], arr(k["theta_d1_m1"]), rtol=1e-12)
+    assert np.array_equal(model.θ[1][1], t2)                # update_θ!(model, 1) leaves document 2 alone
+    mmm.update_θ(model, 1)
     np.testing.assert_allclose(model.θ[1][1], arr(k["theta_d2_m2"]), rtol=1e-12)
     assert not np.any(model.θ[0][0] < 0)
 
@@ -78,8 +83,9 @@ def test_update_theta_immctm(mmm, kats):                    # test/immctm.jl:181
     model.λ = k["lambda"]
     model.γ = k["gamma"]
     mmm.update_Elnϕ(model)
-    mmm.update_θ(model, 1)
+    mmm.update_θ(model, 0)
     np.testing.assert_allclose(model.θ[0][0], arr(k["theta_d1_m1"]), rtol=1e-12)
+    mmm.update_θ(model, 1)
     np.testing.assert_allclose(model.θ[1][1], arr(k["theta_d2_m2"]), rtol=1e-12)
 
 
@@ -102,12 +108,14 @@ def test_update_lambda_nu_qualitative(mmm, kats, imm):      # test/mmctm.jl:92-1
     model = _toy(mmm, kats, imm)
     lam = arr([1, 2, 3, 4, 1])
     model.λ[0] = lam
-    mmm.update_λ(model, 1)
+    l1 = np.array(model.λ[1])
+    mmm.update_λ(model, 0)
     assert not np.allclose(model.λ[0], lam) and not np.any(np.isnan(model.λ[0]))
+    assert np.array_equal(model.λ[1], l1)
     model = _toy(mmm, kats, imm)
     model.μ = [1, 1, 2, 2, 1]; model.λ[0] = lam; model.ν[0] = [1, 1, 1, 2, 1]; model.ζ[0] = [2, 1]
-    mmm.update_ν(model, 1)
-    assert np.all(model.ν[0] > 0.0) and np.all(model.λ[0] < 100.0)
+    mmm.update_ν(model, 0)
+    assert np.all(model.ν[0] > 0.0) and np.all(model.λ[0] < 100.0) and np.all(model.ν[1] == 1.0)
 
 
 @pytest.mark.parametrize("imm", [False, True])
