@@ -157,3 +157,110 @@ def test_python_binding_table_matches_the_header(mmm):
     assert set(sigs) == set(protos)
     for name, (ret, args) in sigs.items():
         assert len(args) == len(protos[name][1]), "%s: _SIGS has %d arguments, the header %d" % (name, len(args), len(protos[name][1]))
+
+
+# ---- the API surface the reference's OWN tests drive (tests/golden/reference_test_api.json, made by tests/golden/make_test_api.py from
+# /root/reference/test/*.jl -- a name list, not the files) must exist in the shim, method by method ----------------------------------
+_IDENT = r"[^\W\d][\w!]*"
+
+
+def _shim_methods():
+    """name -> list of (n_required_positional, n_positional, kw names, has_kw_splat, body)"""
+    txt = open(SHIM, encoding="utf-8").read()
+    txt = "\n".join(re.sub(r"(?<!\")#(?![^\"]*\"\s*[,)]).*$", "", ln) for ln in txt.split("\n"))      # comments (not '#' inside strings)
+    methods = {}
+    pat = re.compile(r"(?m)^[ \t]*(?:function[ \t]+)?(" + _IDENT + r")\(")
+    for m in pat.finditer(txt):
+        name = m.group(1)
+        is_fn = txt[m.start():m.end()].lstrip().startswith("function")
+        end = _balanced(txt, m.end() - 1)
+        rest = txt[end:end + 400]
+        if not is_fn and not re.match(r"\s*=(?!=)", rest):
+            continue                                      # a call at the start of a line, not a definition
+        if is_fn:
+            stop = re.search(r"(?m)^" + re.escape(re.match(r"[ \t]*", txt[m.start():]).group(0)) + r"end\b", txt[end:])
+            body = txt[end:end + (stop.start() if stop else 0)]
+        else:
+            nxt = re.search(r"\n(?=\S)", txt[end:])
+            body = txt[end:end + (nxt.start() if nxt else len(txt) - end)]
+        sig = txt[m.end():end - 1]
+        pos, kws, splat, after = [], [], False, False
+        depth, cur, parts = 0, "", []
+        for ch in sig:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            if ch in ",;" and depth == 0:
+                parts.append((cur.strip(), ch)); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append((cur.strip(), ""))
+        for arg, sep in parts:
+            if after:
+                if arg.endswith("..."):
+                    splat = True
+                else:
+                    kws.append(re.match(_IDENT, arg).group(0))
+            else:
+                pos.append(arg)
+            if sep == ";":
+                after = True
+        nreq = sum(1 for a in pos if not re.search(r"(?<![=!<>])=(?!=)", a))
+        methods.setdefault(name, []).append((nreq, len(pos), kws, splat, body))
+    return methods
+
+
+def _reaches_ccall(name, methods, seen=None):
+    seen = seen or set()
+    if name in seen or name not in methods:
+        return False
+    seen.add(name)
+    for _, _, _, _, body in methods[name]:
+        if "ccall((:mmm_" in body:
+            return True
+        for callee in set(re.findall(r"\b(" + _IDENT + r")\(", body)):
+            if callee != name and _reaches_ccall(callee, methods, seen):
+                return True
+    return False
+
+
+def test_every_function_the_reference_tests_call_is_defined_in_the_shim():
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_test_api.json"), encoding="utf-8"))
+    assert len(api["calls"]) >= 30
+    methods = _shim_methods()
+    missing = []
+    for name, info in api["calls"].items():
+        if name not in methods:
+            missing.append("%s (%s)" % (name, info["sites"][0])); continue
+        for sig in info["signatures"]:
+            ok = any(nreq <= sig["npos"] <= npos and (splat or set(sig["kw"]) <= set(kws)) for nreq, npos, kws, splat, _ in methods[name])
+            if not ok:
+                missing.append("%s with %d positional arguments and keywords %s (%s)" % (name, sig["npos"], sig["kw"], info["sites"][0]))
+        if not _reaches_ccall(name, methods):
+            missing.append("%s never reaches a ccall into libmmmusig_hip" % name)
+    assert not missing, "the reference's tests call, the shim lacks:\n  " + "\n  ".join(missing)
+
+
+def test_every_model_field_the_reference_tests_touch_exists_in_the_shim_structs():
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_test_api.json"), encoding="utf-8"))
+    txt = open(SHIM, encoding="utf-8").read()
+    for kind, names in api["fields"].items():
+        m = re.search(r"mutable struct " + kind + r"\n(.*?)\n\n?    function " + kind, txt, flags=re.S)
+        assert m, "no `mutable struct %s` in the shim" % kind
+        declared = set(re.findall(r"(" + _IDENT + r")::", m.group(1)))
+        lacking = [n for n in names if n not in declared]
+        assert not lacking, "%s lacks the fields %s that the reference's tests use" % (kind, lacking)
+
+
+def test_stage_calls_go_through_upload_and_write_back():
+    """every stage function syncs the Julia arrays to the device first (the reference's tests assign fields in place before the call)"""
+    methods = _shim_methods()
+    for helper in ("lda_stage!", "ctm_stage!", "ctm_doc_stage!", "elbo_terms", "calculate_sumθ", "calculate_Ndivζ"):
+        assert helper in methods, helper
+        assert all("upload!(model)" in body for _, _, _, _, body in methods[helper]), "%s does not upload the model's arrays before its ccall" % helper
+    for name in ("update_ζ!", "update_θ!", "update_ν!", "update_λ!"):      # per-document forms: (model, d), document d only
+        assert any(npos == 2 and "ctm_doc_stage!" in body for _, npos, _, _, body in methods[name]), name
