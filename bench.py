@@ -13,6 +13,14 @@ LDA.jl:201-209, MMCTM.jl:462-479, IMMCTM.jl:440-451) over one batch of synthetic
 The default invocation (config 2) also measures configs 4 and 5 for a bounded number of steps, and config 2's model on 640k documents
 per GPU, and attaches them to the same JSON line under "also" (--no-also switches that off); the headline keys are config 2's.
 
+N > 1, default invocation: the headline stays config 2 weak (10k documents per GPU) on the default transport, and the line also carries
+  "strong"           config 2's ONE 10k-document corpus sharded over the N ranks (the literal ">= 6x at 8 GPUs" target of BASELINE.json)
+  also.cfg4 / cfg5   the 50k / 100k-document corpus SHARDED over the N ranks (strong: that is BASELINE configs[3] / configs[4]), each with
+                     a "weak" entry (every rank its own 50k / 100k corpus) beside it
+and every one of these entries once per transport: the xGMI mailboxes ("p2p", the default) and ncclAllReduce ("rccl": north_star's mandated
+collective) under the entry's "transports" key -- each with docs_per_rank, allreduce_per_rank, comm_nranks_per_rank and the per-GPU
+HBM-roofline fraction.
+
 N > 1: one process per GPU.  `python3 bench.py --gpus N` starts its N rank processes ITSELF (children of a parent that never touches
 the GPU; rank r -> device r mod #devices) and relays rank 0's line; under `python -m torch.distributed.run` (WORLD_SIZE set by the
 launcher) the process is a rank and starts nothing.  One all-reduce of the packed sufficient statistics and of the ll numerators per
@@ -146,6 +154,37 @@ def parity_probe_lda(pkg, K, alpha, eta, V, seed):
     return {"elbo_rel_err_vs_oracle": rel_elbo, "phi_max_rel_err_vs_oracle": rel_phi}
 
 
+def parity_full_lda(pkg, ctx, X, lam0, K, V):
+    """The benchmark's own corpus (BASELINE configs[1] at full size) through 12 passes on the GPU and on the oracle: ll history, γ, λ, Elnβ
+    and ELBO at 1e-9, ϕ / θ at 1e-5 (the reference's bar), then fit!(tol = 1e-4): same pass count, same `converged`."""
+    import numpy as np
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    g = pkg.LDA(K, 0.1, 0.1, V, X, λ0=lam0, ctx=ctx)
+    ll = pkg.fit(g, maxiter=12, tol=0.0, verbose=False)
+    o = orc.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
+    llo = o.fit(maxiter=12, tol=0.0)
+
+    def rel(a, b):
+        a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+    D = len(X)
+    res = {"docs": D, "passes": 12, "ll_history_max_rel_err": rel(ll, llo), "gamma_max_rel_err": rel(g.γ.T, o.gamma), "lambda_max_rel_err": rel(g.λ.T, o.lam),
+           "Elnbeta_max_rel_err": rel(g.Elnβ.T, o.Elnbeta), "theta_max_rel_err": rel(g.θ.T, o.theta),
+           "phi_max_rel_err": float(np.max(np.abs(g.phi_flat() - o.phi.reshape(-1, K)) / np.maximum(np.abs(o.phi.reshape(-1, K)), 1e-12))),
+           "elbo_rel_err": abs(g.elbo - o.elbo_value) / abs(o.elbo_value)}
+    g.close()
+    g = pkg.LDA(K, 0.1, 0.1, V, X, λ0=lam0, ctx=ctx)
+    ll = pkg.fit(g, maxiter=60, tol=1e-4, verbose=False)
+    o = orc.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
+    llo = o.fit(maxiter=60, tol=1e-4)
+    res.update({"fit_tol_1e-4_passes_gpu": int(len(ll)), "fit_tol_1e-4_passes_oracle": int(len(llo)), "fit_converged_gpu": bool(g.converged),
+                "fit_converged_oracle": bool(o.converged), "fit_elbo_rel_err": abs(g.elbo - o.elbo_value) / abs(o.elbo_value),
+                "wall_s": time.perf_counter() - t0})
+    g.close()
+    return res
+
+
 def parity_probe_ctm(pkg, cfg, seed):
     """ELBO / theta relative error and per-document LD_MMA evaluation counts, GPU vs the order-matched oracle, on a bounded sample
     (400 docs, 12 passes)."""
@@ -194,6 +233,7 @@ def launch_ranks(n, argv, timeout_s):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     deadline = time.time() + timeout_s
     rc = 0
+    first_bad = None                      # (rank, code) of the first rank seen with a non-zero exit code -- before the parent ends the others
     # rank 0's stdout is drained by a thread (its JSON line can exceed a pipe buffer); the parent polls: the moment one rank fails, the
     # others -- which would sit in a collective until its own time-out -- are ended too
     import threading
@@ -203,7 +243,10 @@ def launch_ranks(n, argv, timeout_s):
     try:
         while True:
             codes = [p.poll() for p in procs]
-            if any(c not in (None, 0) for c in codes) or all(c is not None for c in codes):
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if failed and first_bad is None:
+                first_bad = failed[0]
+            if failed or all(c is not None for c in codes):
                 break
             if time.time() > deadline:
                 rc = 124
@@ -224,9 +267,9 @@ def launch_ranks(n, argv, timeout_s):
     bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
     line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
     if bad or rc or not line:
-        print("bench.py: rank exit codes %s%s" % (bad, "" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
+        print("bench.py: rank exit codes %s (first failure: %s)%s" % (bad, first_bad, "" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
         sys.stdout.write(out0 or "")
-        sys.exit(rc or (bad[0][1] if bad else 1) or 1)
+        sys.exit(rc or (first_bad[1] if first_bad else (bad[0][1] if bad else 1)) or 1)
     print(line[-1])
     sys.exit(0)
 
@@ -258,6 +301,7 @@ class Env:
         torch.cuda.set_device(self.device)
         self.ctx = ctx = pkg.Context(self.device)
         self.cuda_pg = False
+        self.has_comm = False              # an RCCL communicator exists on ctx
         if world > 1 and not self.shared_card:
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
             self.cuda_pg = True
@@ -266,12 +310,36 @@ class Env:
                 uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
             ctx.init_comm(world, rank, bytes(uid.cpu().numpy().tobytes()))
+            self.has_comm = True
         elif world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
             ctx.init_p2p(world, rank, self.allgather_obj, lambda v: min(self.allgather_obj(int(v))))
         elif os.environ.get("MMM_FORCE_RCCL"):
             # single-GPU rehearsal of the collective path: a one-rank communicator, every all-reduce goes through RCCL
             ctx.init_comm(1, 0, pkg.comm_unique_id())
+            self.has_comm = True
+
+    def transports(self):
+        """[(name, switch)] of the all-reduce transports this job can run, the current one first; switch() is called by every rank.  A
+        transport that cannot run here is listed in self.transport_unavailable with the reason."""
+        ctx = self.ctx
+        self.transport_unavailable = {}
+        if self.world == 1 and not self.has_comm:
+            return [(ctx.transport, lambda: None)]
+        cur = ctx.transport
+        out = [(cur, lambda: None)]
+        if cur == "p2p":
+            if self.has_comm:     # an RCCL communicator exists beside the mailboxes
+                out.append(("rccl", lambda: ctx.p2p_enable(False)))
+            else:
+                self.transport_unavailable["rccl"] = "the ranks share one card (a rehearsal): RCCL refuses two ranks on one device, the mailboxes were set up from host-exchanged handles"
+        elif cur == "rccl":
+            self.transport_unavailable["p2p"] = "the mailboxes were not set up (MMM_P2P=0, or their rehearsal failed on some rank)"
+        return out
+
+    def restore_transport(self, name):
+        if name == "p2p" and self.ctx.transport != "p2p":
+            self.ctx.p2p_enable(True)
 
     def allgather_obj(self, o):
         if self.world == 1:
@@ -308,17 +376,41 @@ class Env:
             self.dist.destroy_process_group()
 
 
-def load_pmc(tname):
-    """committed counter summary (rocprofv3 --pmc passes of this command, tools/pmc_run.sh + tools/pmc_summary.py) of the dominant kernel"""
-    for rnd in ("r03", "r02", "r01"):
+def csrc_sha16(model):
+    """hash of the sources the kernels of one model family are built from (the counter files record it, tools/pmc_summary.py)"""
+    import hashlib
+    d = os.path.join(ROOT, "multimodalmusig.jl_amd", "csrc")
+    files = ["dev_math.h", "mmm_arith.h", "mmm_logtab.h", "mmm_internal.h"] + (["lda.hip"] if model == "lda" else ["ctm.hip", "ctm_big.cuh"])
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(tname, model, kernel_prefix):
+    """Committed counter summary (rocprofv3 --pmc passes of this command, tools/pmc_run.sh + tools/pmc_summary.py) of the dominant kernel
+    -- attached only when it was taken from THIS build of THIS kernel: the file's kernel name must start with the template instance the
+    running handle launches and its csrc hash must equal the sources'.  Returns (summary or None, file name or None, reason or None)."""
+    for rnd in ("r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", "%s_traffic_%s.json" % (rnd, tname))
-        if os.path.exists(tp):
-            return json.load(open(tp)), os.path.basename(tp)
-    return None, None
+        if not os.path.exists(tp):
+            continue
+        tr = json.load(open(tp))
+        base = os.path.basename(tp)
+        if kernel_prefix not in tr.get("kernel", ""):
+            return None, base, "profiles/%s holds counters of `%s`, the handle launches `%s...`: not attached" % (base, tr.get("kernel"), kernel_prefix)
+        if tr.get("csrc_sha16") != csrc_sha16(model):
+            return None, base, "profiles/%s was collected from sources with hash %s, the running build has %s (re-run tools/refresh_evidence.sh pmc): not attached" % (
+                base, tr.get("csrc_sha16"), csrc_sha16(model))
+        return tr, base, None
+    return None, None, "no counter file for %s under profiles/" % tname
 
 
-def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline, cpu_target_s=None):
-    """Measure one configuration on the ranks of `env`; rank 0 gets the result dictionary, the others None."""
+def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline, cpu_target_s=None, every_transport=False, probe=True):
+    """Measure one configuration on the ranks of `env`; rank 0 gets the result dictionary, the others None.  every_transport (N > 1): after
+    the full measurement on the current all-reduce transport, the timed regions once more on every other transport the job can run, on a
+    fresh model over the same shard, under res["transports"]."""
     np, pkg, ctx, world, rank = env.np, env.pkg, env.ctx, env.world, env.rank
     import np_ref
     cfg = CONFIGS[cfg_id]
@@ -353,37 +445,37 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
         init = new
     lib = pkg.lib()
     note("corpus ready, %d documents" % D)
-    if cfg["model"] == "lda":
-        alpha = eta = 0.1
-        model = pkg.LDA(K, alpha, eta, V, X, λ0=init, ctx=ctx)
-        nnz = int(model._doc_ptr[-1])
 
-        def run(n):
-            pkg._lib.check(lib.mmm_lda_iterate(model._h, n), ctx.h, "mmm_lda_iterate")
-    else:
-        alpha = [0.1] * len(K)
+    def make_model():
+        if cfg["model"] == "lda":
+            mdl = pkg.LDA(K, 0.1, 0.1, V, X, λ0=init, ctx=ctx)
+            return mdl, int(mdl._doc_ptr[-1]), lambda n: pkg._lib.check(lib.mmm_lda_iterate(mdl._h, n), ctx.h, "mmm_lda_iterate")
         if cfg["model"] == "mmctm":
-            model = pkg.MMCTM(K, alpha, V, X, γ0=init, ctx=ctx)
+            mdl = pkg.MMCTM(K, [0.1] * len(K), V, X, γ0=init, ctx=ctx)
         else:
-            model = pkg.IMMCTM(K, alpha, snv3(), X, γ0=init, ctx=ctx)
-        nnz = int(sum(model._nnz))
+            mdl = pkg.IMMCTM(K, [0.1] * len(K), snv3(), X, γ0=init, ctx=ctx)
+        return mdl, int(sum(mdl._nnz)), lambda n: pkg._lib.check(lib.mmm_ctm_iterate(mdl._h, n, 1), ctx.h, "mmm_ctm_iterate")
 
-        def run(n):
-            pkg._lib.check(lib.mmm_ctm_iterate(model._h, n, 1), ctx.h, "mmm_ctm_iterate")
+    def timed_regions(run_fn):
+        """the contract's timed region, `repeats` times: K steps between barrier + device synchronisation on both sides, MAX over ranks"""
+        run_fn(warmup)
+        ctx.synchronize()
+        out = []
+        for _ in range(max(1, repeats)):
+            env.barrier()
+            t0 = time.perf_counter()
+            run_fn(steps)
+            env.barrier()
+            out.append(env.allmax(time.perf_counter() - t0))
+        return out
 
+    transports_avail = env.transports()
+    primary = transports_avail[0][0]
+    model, nnz, run = make_model()
     note("model created")
-    run(warmup)
-    ctx.synchronize()
-    note("warm-up done")
-    regions = []
-    for _ in range(max(1, repeats)):
-        env.barrier()
-        t0 = time.perf_counter()
-        run(steps)
-        env.barrier()
-        regions.append(env.allmax(time.perf_counter() - t0))
+    regions = timed_regions(run)
     dt = float(np.median(regions))
-    note("timed regions done (%.4f ms per step)" % (dt / steps * 1e3))
+    note("timed regions done (%.4f ms per step, all-reduce: %s)" % (dt / steps * 1e3, primary))
 
     # Per-kernel durations: the same K steps again with the launches of one phase of the pass bracketed by a HIP event pair on the
     # library's stream (mmm_ctx_profile_select).  Kept out of the timed regions above because each hipEventRecord opens a ~5.6 us bubble
@@ -483,6 +575,7 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
                                          "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"}
             tname = "lda_estep_dense_640k" if (geo["dense"] and D == 640000) else "lda_estep"
+            kprefix = ("k_lda_estep_dense<%d, %d," % (geo["KP"], geo["SL"])) if geo["dense"] == 1 else ("k_lda_estep<%d, %d," % (geo["KP"], geo["L"]))
         else:
             st = model.solver_stats()
             MK, M = sum(K), len(K)
@@ -494,7 +587,9 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             flops = st["n_eval_lambda"] * (2.0 * MK * MK + 35.0 * MK) + st["n_eval_nu"] * 35.0 * MK
             achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             tf = flops / avg_s / 1e12 if avg_s > 0 else 0.0
-            res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # the contract's roofline object prices against HBM ("bound" may only be hbm | mfma there); what really binds the solve phase is
+            # vector-f64 ISSUE -- stated in "binding_ceiling" and quantified in f64_valu below
+            res["roofline"] = {"bound": "hbm", "binding_ceiling": "f64_valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "solve phase (update_nu! + update_lambda!): %d lanes per document, %d coordinate(s) per lane" % (model.geometry()["Ls"], max(model.geometry()["cpl"], 1)),
                                "launches": n_launch, "avg_us": avg_us,
@@ -506,8 +601,14 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                "timing": "HIP events on the library's stream around the kernel, inside a repeat of the timed K steps"}
             res["n_capped"] = st["n_capped"]
             tname = "ctm_solve_cfg%d" % cfg_id
-        tr, tfile = load_pmc(tname)
-        if world == 1 and (D == cfg["docs"] or tname == "lda_estep_dense_640k") and tr:
+            kprefix = "k_ctm_solve_cpl<%d, %d," % (MK, model.geometry()["Ls"])
+        tr, tfile, why_not = (None, None, "counters are collected at N = 1 on the configuration's own corpus size")
+        if world == 1 and (D == cfg["docs"] or tname == "lda_estep_dense_640k"):
+            tr, tfile, why_not = load_pmc(tname, cfg["model"] if cfg["model"] == "lda" else "ctm", kprefix)
+        res["build"] = {"mmm_version": int(lib.mmm_version()), "csrc_sha16": csrc_sha16(cfg["model"] if cfg["model"] == "lda" else "ctm")}
+        if not tr:
+            res["roofline"]["traffic_not_attached"] = why_not
+        if tr:
             res["roofline"]["traffic"] = tr["hbm_bytes_per_launch_gfx950_corrected"]
             res["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch_gfx950_corrected"] / algo_bytes
             res["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/" + tfile
@@ -533,17 +634,64 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                    "more evaluations than the later passes timed here), so this fraction overstates the busy share of the timed launches; "
                                    "at equal passes the pipes are ~80 % busy (DESIGN.md section 4.2)")
                     res["roofline"]["f64_valu"]["issue"] = blk
-        if world == 1:
+        if world == 1 and probe:
             if cfg["model"] == "lda":
                 res.update(parity_probe_lda(pkg, K, 0.1, 0.1, V, seed + 7))
+                if D <= 20000:      # ... and the benchmark's OWN corpus against the oracle: 12 passes of the 1-thread C port cost ~0.5 s at 10k documents
+                    res["parity_on_the_bench_corpus"] = parity_full_lda(pkg, ctx, X, init, K, V)
             else:
                 res.update(parity_probe_ctm(pkg, cfg, seed + 7))
+        if world == 1:
             if cpu_baseline:
                 kw = {} if cpu_target_s is None else {"target_s": cpu_target_s}
                 res["cpu_baseline"] = cpu_baseline_lda(X, init, K, 0.1, 0.1, **kw) if cfg["model"] == "lda" else cpu_baseline_ctm(cfg, X, init, **kw)
                 res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
     model.close()
+    # ---- the same shard on every other transport the job can run (N > 1): timed regions only
+    if every_transport and (world > 1 or len(transports_avail) > 1):
+        entries = {}
+        if rank == 0:
+            entries[primary] = {"value": res["value"], "ms_per_step": res["ms_per_step"], "ms_per_step_min": res["ms_per_step_min"],
+                                "allreduce_per_rank": transports, "roofline_frac_per_gpu": res["roofline"]["frac"]}
+        for name, switch in transports_avail[1:]:
+            switch()
+            m2, _, run2 = make_model()
+            reg2 = timed_regions(run2)
+            if cfg["model"] == "lda":      # (flushes the lagged ll: an exchange every rank must make)
+                ll = np.zeros(1); n = pkg._lib.C.c_int()
+                pkg._lib.check(lib.mmm_lda_ll_history(m2._h, ll.ctypes.data, 1, pkg._lib.C.byref(n)), ctx.h)
+            tr2 = env.allgather_obj(ctx.transport)
+            m2.close()
+            d2 = float(np.median(reg2))
+            note("transport %s: %.4f ms per step" % (name, d2 / steps * 1e3))
+            if rank == 0:
+                entries[name] = {"value": sum(docs_per_rank) * steps / d2, "ms_per_step": d2 / steps * 1e3, "ms_per_step_min": min(reg2) / steps * 1e3,
+                                 "allreduce_per_rank": tr2,
+                                 "roofline_frac_per_gpu": res["roofline"]["frac"],
+                                 "note": "timed regions only; the dominant kernel is the same launch as on the primary transport (its fraction is repeated)"}
+        env.restore_transport(primary)
+        if rank == 0:
+            for name, why in env.transport_unavailable.items():
+                entries[name] = {"unavailable": why}
+            res["transports"] = entries
     return res
+
+
+def compact(r):
+    """the keys of a nested entry (strong / weak variants inside the one line)"""
+    if r is None:
+        return None
+    keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "repeats", "scaling", "dtype", "transports", "ll_last",
+            "n_capped", "error")
+    out = {k: r[k] for k in keep if k in r}
+    c = r.get("config", {})
+    out["config"] = {k: c[k] for k in ("workload", "docs_total", "docs_per_rank", "sharding", "allreduce", "allreduce_per_rank", "comm_nranks_per_rank", "note") if k in c}
+    rf = r.get("roofline", {})
+    out["roofline"] = {k: rf[k] for k in ("bound", "binding_ceiling", "achieved", "peak", "unit", "frac", "kernel", "avg_us", "algorithmic_bytes_per_launch") if k in rf}
+    out["roofline"]["per"] = "GPU (rank 0's launch over rank 0's shard)"
+    if "iteration" in r:
+        out["kernel_us"] = r["iteration"]["kernel_us"]
+    return out
 
 
 def main():
@@ -568,30 +716,43 @@ def main():
         args.warmup = 5 if cfg["model"] == "lda" else 2
 
     env = Env(args.gpus)
-    res = run_config(env, args.config, args.scaling, args.steps, args.warmup, args.repeats, args.docs, not args.no_cpu_baseline)
+    multi = env.world > 1
+    # (MMM_FORCE_RCCL=1 MMM_P2P_ONE_RANK=1 at N = 1: a one-rank communicator with mailboxes -- the transport switch rehearsed on one GPU)
+    res = run_config(env, args.config, args.scaling, args.steps, args.warmup, args.repeats, args.docs, not args.no_cpu_baseline,
+                     every_transport=multi or env.has_comm)
     # the other two throughput configurations of BASELINE.json, bounded, on the same ranks, in the same line
     if args.config == 2 and not args.docs and not args.no_also:
+        def attempt(fn):
+            try:
+                return fn()
+            except Exception as e:       # noqa: BLE001 -- one GPU: the headline stands on its own; several ranks: a rank that carried on
+                if multi:                # alone would leave the others inside a collective -- fail the job instead
+                    raise
+                return {"error": "%s: %s" % (type(e).__name__, e)}
         also = {}
+        if multi and args.scaling == "weak":
+            # BASELINE.json's ">= 6x further at 8 GPUs" read literally: the ONE 10k-document corpus, sharded
+            r = attempt(lambda: run_config(env, 2, "strong", args.steps, args.warmup, args.repeats, 0, False, every_transport=True))
+            if env.rank == 0:
+                res["strong"] = compact(r)
         for c in (4, 5):
             t0 = time.perf_counter()
-            try:
-                r = run_config(env, c, args.scaling, 10, 2, 5, 0, not args.no_cpu_baseline, cpu_target_s=8.0)
-            except Exception as e:       # noqa: BLE001 -- one GPU: the headline stands on its own; several ranks: a rank that carried on
-                if env.world > 1:        # alone would leave the others inside a collective -- fail the job instead
-                    raise
-                r = {"error": "%s: %s" % (type(e).__name__, e)}
+            if multi:
+                # BASELINE configs[3] / configs[4] ARE sharded corpora ("50k docs ... sharded 8x", "100k docs ... 8x"): strong scaling is the
+                # entry, the weak variant (every rank its own corpus of that size) rides beside it
+                r = attempt(lambda: run_config(env, c, "strong", 10, 2, 5, 0, False, every_transport=True))
+                rw = attempt(lambda: run_config(env, c, "weak", 10, 2, 3, 0, False))
+                if env.rank == 0:
+                    r["weak"] = compact(rw)
+            else:
+                r = attempt(lambda: run_config(env, c, args.scaling, 10, 2, 5, 0, not args.no_cpu_baseline, cpu_target_s=8.0))
             if env.rank == 0:
                 r["wall_s_including_corpus_generation_and_cpu_baseline"] = time.perf_counter() - t0
                 also["cfg%d" % c] = r
         # ... and the headline model at a size where the kernels reach their steady state (640k documents per GPU: the roofline figures of
         # the dense-row E-step build); bounded: ~10 s including corpus generation
         t0 = time.perf_counter()
-        try:
-            r = run_config(env, 2, args.scaling, 30, 5, 5, 640000, False)
-        except Exception as e:       # noqa: BLE001
-            if env.world > 1:
-                raise
-            r = {"error": "%s: %s" % (type(e).__name__, e)}
+        r = attempt(lambda: run_config(env, 2, "weak", 30, 5, 5, 640000, False))
         if env.rank == 0:
             r["wall_s_including_corpus_generation"] = time.perf_counter() - t0
             also["lda_640k_docs"] = r

@@ -202,6 +202,11 @@ class Context:
         """'p2p' (xGMI mailboxes), 'rccl' or 'none': what the per-iteration all-reduce uses."""
         return lib().mmm_comm_transport(self.h).decode()
 
+    def p2p_enable(self, on):
+        """Switch the per-iteration all-reduce between the xGMI mailboxes (True) and ncclAllReduce (False).  Collective in effect: every rank
+        must make the same call before its next model call (mmm_p2p_enable)."""
+        check(lib().mmm_p2p_enable(self.h, 1 if on else 0), self.h, "mmm_p2p_enable")
+
     def init_p2p(self, nranks, rank, allgather, allmin):
         """Mailbox all-reduce without an RCCL communicator.  allgather(bytes) -> list of every rank's bytes (rank order),
         allmin(int) -> minimum over ranks; both are collective calls of the host's own transport (gloo, MPI, ...)."""

@@ -63,6 +63,24 @@ def test_default_invocation_with_two_ranks_carries_every_configuration():
     for k, v in r["also"].items():
         assert "error" not in v and v["value"] > 0 and v["n_gpus"] == 2, (k, v.get("error"))
     assert r["ll_last"] < 0 and r["also"]["lda_640k_docs"]["ll_last"] < 0
+    # what the N > 1 line must carry: the headline weak AND strong; configs 4 / 5 on THEIR corpus (50k / 100k documents in
+    # total) sharded over the ranks with the weak variant beside; every entry per transport, with the ranks' view of the communicator
+    assert r["scaling"] == "weak" and r["config"]["docs_total"] == 20000
+    st = r["strong"]
+    assert st["scaling"] == "strong" and st["config"]["docs_total"] == 10000 and sum(st["config"]["docs_per_rank"]) == 10000 and "note" in st["config"]
+    want = {"cfg4": 50000, "cfg5": 100000}
+    for k, total in want.items():
+        e = r["also"][k]
+        assert e["scaling"] == "strong" and e["config"]["docs_total"] == total and sum(e["config"]["docs_per_rank"]) == total, k
+        assert e["weak"]["scaling"] == "weak" and e["weak"]["config"]["docs_total"] == 2 * total and e["weak"]["value"] > 0, k
+    for e in (r, st, r["also"]["cfg4"], r["also"]["cfg5"]):
+        c = e["config"]
+        assert c["comm_nranks_per_rank"] == [2, 2] and c["allreduce_per_rank"] == ["p2p", "p2p"] and len(c["docs_per_rank"]) == 2
+        assert 0 < e["roofline"]["frac"] < 1
+        t = e["transports"]
+        assert set(t) == {"p2p", "rccl"} and t["p2p"]["value"] > 0 and t["p2p"]["allreduce_per_rank"] == ["p2p", "p2p"] and 0 < t["p2p"]["roofline_frac_per_gpu"] < 1
+        # two ranks on ONE card: RCCL refuses that, and the line must say so rather than carry a number that did not run
+        assert "unavailable" in t["rccl"] or (t["rccl"]["value"] > 0 and t["rccl"]["allreduce_per_rank"] == ["rccl", "rccl"])
 
 
 @pytest.mark.gpu
@@ -78,3 +96,22 @@ def test_single_gpu_line_keeps_its_keys():
     assert rf["algorithmic_bytes_as_implemented"] <= rf["algorithmic_bytes_per_launch"]
     assert 0 < r["iteration"]["kernel_fraction_of_step"] < 1.5
     assert r["elbo_rel_err_vs_oracle"] < 1e-5
+
+
+@pytest.mark.gpu
+def test_transport_switch_rehearsed_on_one_rank():
+    """N > 1 on real hardware measures every entry once over the xGMI mailboxes and once over ncclAllReduce on the same communicator
+    (mmm_p2p_enable).  One card cannot hold two RCCL ranks, so the switch is rehearsed on a ONE-rank communicator with mailboxes
+    (MMM_FORCE_RCCL=1: every all-reduce really calls RCCL; MMM_P2P_ONE_RANK=1: the mailboxes are set up anyway): both entries must
+    have run, on the transport they name, with the same log-likelihood."""
+    env = dict(os.environ, MMM_FORCE_RCCL="1", MMM_P2P_ONE_RANK="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "3000", "--steps", "10", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    t = r["transports"]
+    assert r["config"]["allreduce"] == "p2p" and set(t) == {"p2p", "rccl"}
+    assert t["p2p"]["allreduce_per_rank"] == ["p2p"] and t["rccl"]["allreduce_per_rank"] == ["rccl"]
+    assert t["p2p"]["value"] > 0 and t["rccl"]["value"] > 0

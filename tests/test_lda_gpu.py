@@ -163,6 +163,34 @@ def test_invariants_at_full_size(mmm):
     np.testing.assert_array_equal(g.λ, g2.λ)
 
 
+def test_config_2_at_its_own_size_against_the_oracle(mmm, oracle):
+    """BASELINE configs[1] exactly as bench.py runs it (10,000 x 96, K = 10, corpus seed 20261004: the single-step build
+    k_lda_estep<10,16,false,96,true>) held against the oracle, not only through invariants: 12 passes -- ll history, γ, λ, Elnβ, ELBO at
+    1e-9, ϕ / θ at the reference's 1e-5 -- then fit!(tol = 1e-4): same pass count, same `converged` (LDA.jl:198-224)."""
+    D, V, K = 10000, 96, 10
+    X, lam0 = np_ref.synth_lda(D, V, K, seed=20261004)
+    g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+    geo = g.geometry()
+    assert geo["single_step"] == 1 and geo["KP"] == 10 and geo["L"] == 16 and not geo["dense"]      # the build the benchmark times
+    o = oracle.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
+    ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
+    ll_o = o.fit(maxiter=12, tol=0.0)
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    np.testing.assert_allclose(g.γ, o.gamma.reshape(D, K).T, rtol=1e-9)
+    np.testing.assert_allclose(g.λ, o.lam.reshape(K, V).T, rtol=1e-9)
+    np.testing.assert_allclose(g.Elnβ, o.Elnbeta.reshape(K, V).T, rtol=1e-9, atol=1e-12)
+    assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+    np.testing.assert_allclose(g.phi_flat(), o.phi.reshape(-1, K), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(g.θ, o.theta.reshape(D, K).T, rtol=1e-5)
+    g2 = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+    o2 = oracle.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
+    ll_g = mmm.fit(g2, maxiter=100, tol=1e-4, verbose=False)
+    ll_o = o2.fit(maxiter=100, tol=1e-4)
+    assert len(ll_g) == len(ll_o) and g2.converged == o2.converged
+    np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
+    assert g2.elbo == pytest.approx(o2.elbo_value, rel=1e-7)
+
+
 @pytest.mark.parametrize("D,V,K", [(70, 50, 16), (50, 96, 20), (40, 30, 32), (45, 96, 13)])
 def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, monkeypatch, D, V, K):
     """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16.

@@ -54,7 +54,10 @@ print("derived:")
 for k in sorted(d):
     print("  %-44s %14.4f" % (k, d[k]))
 if jout:
-    json.dump({"kernel": name, "counters_per_launch": avg, "derived": d,
+    # provenance: which sources the profiled library was built from -- bench.py attaches the counters only to a build with the same hash
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    json.dump({"kernel": name, "csrc_sha16": bench.csrc_sha16("lda" if "k_lda" in match else "ctm"), "counters_per_launch": avg, "derived": d,
                "hbm_bytes_per_launch_gfx950_corrected": d.get("hbm_bytes_per_launch_gfx950_corrected"),
                "note": "rocprofv3 --pmc, one pass per counter set (tools/pmc_run.sh); FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2 on the "
                        "read side (MI355X_MICROARCH.md); fabric-side counters: Infinity-Cache hits are included"}, open(jout, "w"), indent=1)
