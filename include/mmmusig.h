@@ -239,7 +239,8 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8]);
 /* Parity probe: out[i] = op(a[i], b[i]) evaluated by the device functions the kernels use (csrc/mmm_arith.h, dev_math.h).
  * op 0 exp, 1 log, 2 digamma (x > 0), 3 a / b, 4 sqrt, 5 / 6 / 7 sum over consecutive groups of 16 / 32 / 64 values in the
- * lane-butterfly order of the document groups (out[i] = total of i's group; n a multiple of 64), 8 the full-wave butterfly. */
+ * lane-butterfly order of the document groups (out[i] = total of i's group; n a multiple of 64), 8 the full-wave butterfly,
+ * 9 / 10 the table-driven exp / log of the LD_MMA objectives (ar_exp_tab, ar_log_tab). */
 int mmm_debug_math(mmm_ctx* ctx, int op, size_t n, const double* a, const double* b, double* out);
 /* Fused hot path: n_iter passes of the body of fit! (MMCTM.jl:462-479 / IMMCTM.jl:440-451) */
 /* fit_flags: keyword arguments of fit! (MMCTM.jl:457-458): MMM_FIT_UPDATE_SIGMA = updateΣ (IMMCTM always updates Σ,

@@ -24,6 +24,7 @@
 #include <memory>
 #include "dev_math.h"
 #include "mmm_logtab.h"
+#include "mmm_exptab.h"
 #include "mmm_internal.h"
 
 namespace {
@@ -153,14 +154,17 @@ __device__ __forceinline__ bool gnone(bool pred, int g)
 
 // ---- objectives in NLopt's minimisation form (common.jl:11-36 negated) ----------------------------------------------
 // nu: f = 1/2 sum nu_i S_ii + sum c_i exp(lambda_i + nu_i/2) - 1/2 sum log nu_i
+// exp and log of the objectives come from the two tables the solve kernels stage into LDS (SolveTabs below; mmm_arith.h: no division, a
+// third fewer instructions -- the phase is bound by vector-f64 issue)
 struct NuObj {
     double lam, c, Sll; bool act;
+    const double* tabs;       // LDS: [exp table | log table]
     template <int L, int LP = 0>
     __device__ __forceinline__ double eval(double x, double& g, const PackCtx& pc = PackCtx{}) const
     {
-        const double E = ar_exp(lam + 0.5 * x);
+        const double E = ar_exp_tab(lam + 0.5 * x, tabs);
         g = act ? 0.5 * Sll + 0.5 * c * E - dev_div(1.0, 2.0 * x) : 0.0;
-        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * ar_log(x) : 0.0;
+        const double t = act ? 0.5 * x * Sll + c * E - 0.5 * ar_log_tab(x, tabs + MMM_EXPTAB_N) : 0.0;
         return gsum<L, LP>(pc, t);
     }
 };
@@ -171,6 +175,7 @@ struct LamObj {
     double nu, c, sumth, mu; bool act; int l, MK;
     const double* sS;     // [j*MK + i], symmetric
     double* scr;          // group-private LDS, >= MK doubles
+    const double* tabs;   // LDS: [exp table | log table]
     template <int L, int LP = 0>
     __device__ __forceinline__ double eval(double x, double& g, const PackCtx& pc = PackCtx{}) const
     {
@@ -200,12 +205,18 @@ struct LamObj {
             }
             Sd = (s0 + s1) + (s2 + s3);
         }
-        const double E = ar_exp(x + 0.5 * nu);
+        const double E = ar_exp_tab(x + 0.5 * nu, tabs);
         g = act ? Sd - sumth + c * E : 0.0;
         const double t = act ? 0.5 * diff * Sd - x * sumth + c * E : 0.0;
         return gsum<L, LP>(pc, t);
     }
 };
+
+// the function tables of the objectives, staged once per block (call from every thread of the block, before a __syncthreads())
+__device__ __forceinline__ void stage_solve_tabs(double* tabs)
+{
+    for (int i = threadIdx.x; i < MMM_EXPTAB_N + MMM_LOGTAB_N; i += blockDim.x) tabs[i] = i < MMM_EXPTAB_N ? g_mmm_exptab[i] : g_mmm_logtab[i - MMM_EXPTAB_N];
+}
 
 // NLopt LD_MMA, zero constraints, for the L-lane group of the calling lane (lane l holds coordinate l).  All lanes of the
 // wave execute every trip; a finished group keeps its state through selects.  Returns the number of objective
@@ -222,11 +233,13 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
     while (!__all(done)) {
         // closed-form minimiser of the separable approximation (dual problem is trivial for m = 0)
+        // NLopt: u = g sigma^2, v = |g| sigma + rho/2, dx = (u/v) / (-1 - sqrt|1 - (u/(v sigma))^2|).  u/(v sigma) = (g sigma)/v =: q and u/v = q sigma:
+        // ONE correctly rounded quotient instead of three (the two forms differ by an ulp or two; the order-matched CPU checker of the
+        // parity tests follows this one, the index-order one keeps NLopt's)
         const double sigma2 = sigma * sigma;
-        const double u = grad * sigma2;
         const double v = fabs(grad) * sigma + 0.5 * rho;
-        const double q = dev_div(u, v * sigma);
-        double dx = dev_div(dev_div(u, v), -1.0 - dev_sqrt(fabs(1.0 - q * q)));
+        const double q = dev_div(grad * sigma, v);
+        double dx = dev_div(q * sigma, -1.0 - dev_sqrt(fabs(1.0 - q * q)));
         double xc = x + dx;
         if (has_lb && xc < lb) xc = lb;
         if (xc > x + 0.9 * sigma) xc = x + 0.9 * sigma; else if (xc < x - 0.9 * sigma) xc = x - 0.9 * sigma;
@@ -351,6 +364,12 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
     const bool slabpass = PH == 0 && !WIDE && (flags & F_SLAB);
     double* sB = sScr + (size_t)NW * (slabpass ? MMM_WAVE : SCRW);             // [GT]      (PH 0)
     double* sSlab = sB + GT;                           // [NW][GT]  (PH 0, F_SLAB)
+    const double* sTabs = nullptr;                     // exp | log tables of the objectives (PH 1)
+    if constexpr (PH == 1) {
+        __shared__ __attribute__((aligned(16))) double s_tabs[MMM_EXPTAB_N + MMM_LOGTAB_N];
+        stage_solve_tabs(s_tabs);
+        sTabs = s_tabs;
+    }
     if (PH == 1) {
         for (int i = tid; i < MK * MK; i += blockDim.x) sS[i] = p_invSigma[i];
         for (int i = tid; i < MK; i += blockDim.x) sMu[i] = p_mu[i];
@@ -536,14 +555,14 @@ __global__ __launch_bounds__(PH ? 256 : 512, PH ? OCC : 1) void k_ctm_estep(CtmE
         SolveOpts o = a.opt;
         // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ ----------------
         if (flags & F_NU) {
-            NuObj obj{lam, cl, act ? sS[l * MK + l] : 1.0, act};
+            NuObj obj{lam, cl, act ? sS[l * MK + l] : 1.0, act, sTabs};
             const int nev = mma_group<L, LP>(obj, act, g, nu, true, o.nu_lower, o, pc);
             if (act) p_nu[(size_t)d * MK + l] = nu;
             if (p_nev_nu && valid && l == 0) p_nev_nu[d] = nev;
         }
         // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν ---------------------------------------------
         if (flags & F_LAMBDA) {
-            LamObj<MKT> obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD};
+            LamObj<MKT> obj{nu, cl, sumth, act ? sMu[l] : 0.0, act, l, MK, sS, scrD, sTabs};
             const int nev = mma_group<L, LP>(obj, act, g, lam, false, 0.0, o, pc);
             if (act) p_lam_out[(size_t)d * MK + l] = lam;
             if (p_nev_lam && valid && l == 0) p_nev_lam[d] = nev;
@@ -777,6 +796,7 @@ struct NuObjC {
     double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
     int modpack, l;       // the modality of coordinate q of this lane in bits [4q, 4q + 4)
     bool lane_on, on;      // lane_on: the lane holds coordinates (l < ACT); on: ... of a document
+    const double* tabs;    // LDS: [exp table | log table]
     // start point and constants of document d (d < 0: an empty slot).  Lanes that are not `on` keep x = 0 and contribute exact zeros.
     __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
     {
@@ -804,10 +824,10 @@ struct NuObjC {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) {
-            const double E = ar_exp(lam[q] + 0.5 * x[q]);
+            const double E = ar_exp_tab(lam[q] + 0.5 * x[q], tabs);
             const bool msk = (Gm::ACT < LPD) ? on : true;        // only layouts with idle lanes need the mask
             const double gq = 0.5 * Sll[q] + 0.5 * c[q] * E - dev_div(1.0, 2.0 * x[q]);
-            const double tq = 0.5 * x[q] * Sll[q] + c[q] * E - 0.5 * ar_log(x[q]);
+            const double tq = 0.5 * x[q] * Sll[q] + c[q] * E - 0.5 * ar_log_tab(x[q], tabs + MMM_EXPTAB_N);
             g[q] = msk ? gq : 0.0;
             s += msk ? tq : 0.0;
             if (SB) __builtin_amdgcn_sched_barrier(0);
@@ -825,6 +845,7 @@ struct LamObjC {
     bool lane_on, on;
     const double* sS;     // padded layout above
     double* scr;          // group-private LDS, MKT doubles (+ pad): the differences x - mu of the whole document
+    const double* tabs;   // LDS: [exp table | log table]
     __device__ __forceinline__ void load(const CplDocs& dc, int d, double (&x)[Gm::CPL])
     {
         if (!lane_on) d = -1;
@@ -878,7 +899,7 @@ struct LamObjC {
 #pragma unroll
         for (int q = 0; q < Gm::CPL; ++q) {
             const double Sd = (s0[q] + s1[q]) + (s2[q] + s3[q]);
-            const double E = ar_exp(x[q] + 0.5 * nu[q]);
+            const double E = ar_exp_tab(x[q] + 0.5 * nu[q], tabs);
             const bool msk = (Gm::ACT < LPD) ? on : true;
             const double gq = Sd - sumth[q] + c[q] * E;
             const double tq = 0.5 * diff[q] * Sd - x[q] * sumth[q] + c[q] * E;
@@ -960,10 +981,9 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const double sigma2 = sigma[q] * sigma[q];
-            const double u = grad[q] * sigma2;
             const double v = fabs(grad[q]) * sigma[q] + 0.5 * rho;
-            const double qq = dev_div(u, v * sigma[q]);
-            double dx = dev_div(dev_div(u, v), -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
+            const double qq = dev_div(grad[q] * sigma[q], v);                 // = u / (v sigma) of NLopt's formula; u / v = qq sigma (see mma_group)
+            double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
             double c = x[q] + dx;
             c = (has_lb && c < lb) ? lb : c;
             const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
@@ -1080,6 +1100,9 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     double* sS = smem;
     double* sScr = sS + MK * Gm::ROW;
     double* sMu = sScr + (size_t)NW * G * (MK + 2);      // [LPD * CPL]
+    __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];      // exp | log tables of the objectives
+    stage_solve_tabs(sTabs);
+    if constexpr ((WHICH & 2) == 0) __syncthreads();
     if constexpr ((WHICH & 2) != 0) {
         for (int e = tid; e < LPD * CPL; e += blockDim.x) sMu[e] = e < MK ? p_mu[e] : 0.0;
         for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
@@ -1125,7 +1148,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
 #pragma unroll
         for (int q = 0; q < CPL; ++q) obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0;
         obj.modpack = modpack;
-        obj.l = l; obj.lane_on = lane_on;
+        obj.l = l; obj.lane_on = lane_on; obj.tabs = sTabs;
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, pool, gcnt);
     }
     // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
@@ -1137,6 +1160,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     if constexpr ((WHICH & 2) != 0) if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
         obj.modpack = modpack;
+        obj.tabs = sTabs;
         obj.smu = sMu;
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam, pool, gcnt);
@@ -1152,9 +1176,11 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
 {
     __shared__ double sS[64 * 64];
     __shared__ double scr[64];
+    __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];
     const CtmDims& dm = c.dm;
     const int MK = dm.MK, M = dm.M, l = threadIdx.x;
     for (int i = l; i < MK * MK; i += 64) sS[i] = invSigma[i];
+    stage_solve_tabs(sTabs);
     __syncthreads();
     const bool act = l < MK;
     int mod_l = 0;
@@ -1168,9 +1194,9 @@ __global__ __launch_bounds__(64) void k_ctm_objectives(CtmDev c, int d, const do
         for (int64_t e = dp[d]; e < dp[d + 1]; ++e) sumth += theta[dm.toff[m] + (size_t)(e - dm.estart[m]) * Km + k] * (double)c.tc[e].y;
     }
     double g1, g2;
-    LamObj<0> lo{v, cl, sumth, act ? mu[l] : 0.0, act, l, MK, sS, scr};
+    LamObj<0> lo{v, cl, sumth, act ? mu[l] : 0.0, act, l, MK, sS, scr, sTabs};
     const double f1 = lo.eval<64>(x, g1);
-    NuObj no{x, cl, act ? sS[l * MK + l] : 1.0, act};
+    NuObj no{x, cl, act ? sS[l * MK + l] : 1.0, act, sTabs};
     const double f2 = no.eval<64>(v, g2);
     if (l == 0) { out[0] = -f1; out[1] = -f2; }
     if (act) { out[2 + l] = -g1; out[2 + MK + l] = -g2; }
@@ -3379,10 +3405,15 @@ int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 namespace {
 __global__ void k_debug_math(int op, size_t n, const double* a, const double* b, double* out)
 {
+    __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];
+    stage_solve_tabs(sTabs);
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // n is a multiple of 64 for the collectives: no early return
     const double x = i < n ? a[i] : 0.0, y = (i < n && b) ? b[i] : 1.0;
     double r = 0.0;
     switch (op) {
+    case 9: r = ar_exp_tab(x, sTabs); break;
+    case 10: r = ar_log_tab(x, sTabs + MMM_EXPTAB_N); break;
     case 0: r = ar_exp(x); break;
     case 1: r = ar_log(x); break;
     case 2: r = dev_digamma_ar(x); break;
@@ -3400,8 +3431,8 @@ __global__ void k_debug_math(int op, size_t n, const double* a, const double* b,
 int mmm_debug_math(mmm_ctx* ctx, int op, size_t n, const double* a, const double* b, double* out)
 {
     if (!ctx) return MMM_ERR_ARG;
-    MMM_CHECK(ctx, a && out && op >= 0 && op <= 8, "mmm_debug_math: bad arguments");
-    MMM_CHECK(ctx, op < 5 || n % 64 == 0, "mmm_debug_math: the collectives need n %% 64 == 0");
+    MMM_CHECK(ctx, a && out && op >= 0 && op <= 10, "mmm_debug_math: bad arguments");
+    MMM_CHECK(ctx, op < 5 || op > 8 || n % 64 == 0, "mmm_debug_math: the collectives need n %% 64 == 0");
     if (!n) return MMM_OK;
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf<double> da, db, dout;

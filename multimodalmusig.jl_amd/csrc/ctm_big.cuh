@@ -101,6 +101,7 @@ struct BigDoc {          // what a lane holds of its document: coordinates i_q =
 
 struct NuObjBig {
     const BigDoc* dc; double lam[kBigSlots], Sll[kBigSlots];
+    const double* tabs;   // LDS: [exp table | log table] (stage_solve_tabs)
     __device__ __forceinline__ double eval(const double (&x)[kBigSlots], double (&g)[kBigSlots]) const
     {
         double t = 0.0;
@@ -108,9 +109,9 @@ struct NuObjBig {
         for (int q = 0; q < kBigSlots; ++q) {
             g[q] = 0.0;
             if (dc->on[q]) {
-                const double E = ar_exp(lam[q] + 0.5 * x[q]);
+                const double E = ar_exp_tab(lam[q] + 0.5 * x[q], tabs);
                 g[q] = 0.5 * Sll[q] + 0.5 * dc->c[q] * E - dev_div(1.0, 2.0 * x[q]);
-                t += 0.5 * x[q] * Sll[q] + dc->c[q] * E - 0.5 * ar_log(x[q]);
+                t += 0.5 * x[q] * Sll[q] + dc->c[q] * E - 0.5 * ar_log_tab(x[q], tabs + MMM_EXPTAB_N);
             }
         }
         return wave_sum(t);
@@ -121,6 +122,7 @@ struct LamObjBig {
     const BigDoc* dc; double nu[kBigSlots], sumth[kBigSlots], mu[kBigSlots];
     const double* S;      // Sigma^-1 [j * MK + i], symmetric, device memory (L2-resident)
     double* scr;          // the wave's LDS row, MK doubles: the differences x - mu of the whole document
+    const double* tabs;   // LDS: [exp table | log table]
     int MK, lane;
     __device__ __forceinline__ double eval(const double (&x)[kBigSlots], double (&g)[kBigSlots]) const
     {
@@ -140,7 +142,7 @@ struct LamObjBig {
         for (int q = 0; q < kBigSlots; ++q) {
             g[q] = 0.0;
             if (dc->on[q]) {
-                const double E = ar_exp(x[q] + 0.5 * nu[q]);
+                const double E = ar_exp_tab(x[q] + 0.5 * nu[q], tabs);
                 g[q] = Sd[q] - sumth[q] + dc->c[q] * E;
                 t += 0.5 * diff[q] * Sd[q] - x[q] * sumth[q] + dc->c[q] * E;
             }
@@ -168,10 +170,9 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
             xc[q] = x[q];
             if (dc.on[q]) {
                 const double sigma2 = sigma[q] * sigma[q];
-                const double u = grad[q] * sigma2;
                 const double v = fabs(grad[q]) * sigma[q] + 0.5 * rho;
-                const double qq = dev_div(u, v * sigma[q]);
-                double dx = dev_div(dev_div(u, v), -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
+                const double qq = dev_div(grad[q] * sigma[q], v);             // see mma_group (ctm.hip): one quotient for u / (v sigma) and u / v
+                double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
                 double c = x[q] + dx;
                 if (has_lb && c < lb) c = lb;
                 if (c > x[q] + 0.9 * sigma[q]) c = x[q] + 0.9 * sigma[q]; else if (c < x[q] - 0.9 * sigma[q]) c = x[q] - 0.9 * sigma[q];
@@ -249,6 +250,9 @@ __global__ __launch_bounds__(256) void k_ctm_solve_big(CtmEArgs a)
     int* p_nev_nu = a.nev_nu ? a.nev_nu + rep * D : nullptr;
     int* p_nev_lam = a.nev_lam ? a.nev_lam + rep * D : nullptr;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];      // exp | log tables of the objectives
+    stage_solve_tabs(sTabs);
+    __syncthreads();
     int mod[kBigSlots];
     double muq[kBigSlots], Sll[kBigSlots];
 #pragma unroll
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void k_ctm_solve_big(CtmEArgs a)
         }
         // update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ
         if (a.flags & F_NU) {
-            NuObjBig obj; obj.dc = &dc;
+            NuObjBig obj; obj.dc = &dc; obj.tabs = sTabs;
 #pragma unroll
             for (int q = 0; q < kBigSlots; ++q) { obj.lam[q] = lam[q]; obj.Sll[q] = Sll[q]; }
             const int nev = mma_big(obj, dc, nu, true, o.nu_lower, o);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void k_ctm_solve_big(CtmEArgs a)
         }
         // update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
         if (a.flags & F_LAMBDA) {
-            LamObjBig obj; obj.dc = &dc; obj.S = S; obj.scr = smem + (size_t)wid * MK; obj.MK = MK; obj.lane = lane;
+            LamObjBig obj; obj.dc = &dc; obj.S = S; obj.scr = smem + (size_t)wid * MK; obj.MK = MK; obj.lane = lane; obj.tabs = sTabs;
 #pragma unroll
             for (int q = 0; q < kBigSlots; ++q) { obj.nu[q] = nu[q]; obj.sumth[q] = sumth[q]; obj.mu[q] = muq[q]; }
             const int nev = mma_big(obj, dc, lam, false, 0.0, o);

@@ -53,6 +53,7 @@ __device__ __forceinline__ double dev_rcp(double x)
 
 // v_max_f64 without the canonicalising v_max(x, x) the compiler puts before fmax()
 __device__ __forceinline__ double dev_max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double dev_min_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // a / b, bit-identical to the compiler's IEEE division whenever no operand or intermediate leaves the normal range: the
 // same rcp + 2 Newton + residual-correction sequence, without the v_div_scale / v_div_fmas / v_div_fixup range handling

@@ -26,6 +26,9 @@
 #define AR_FROM_BITS(u) __longlong_as_double((long long)(u))
 #define AR_FMA(a, b, c) fma((a), (b), (c))
 #define AR_RINT(x) rint(x)
+#define AR_LDEXP(x, n) ldexp((x), (n))                 /* v_ldexp_f64: one rounding, subnormal results included -- as the host's ldexp */
+#define AR_MAXNUM(a, b) dev_max_raw((a), (b))          /* IEEE maxNum / minNum (a NaN operand loses), without a canonicalising copy */
+#define AR_MINNUM(a, b) dev_min_raw((a), (b))
 #else
 #include <math.h>
 #include <stdint.h>
@@ -38,6 +41,9 @@ static inline double ar_from_bits_(unsigned long long u) { double x; memcpy(&x, 
 #define AR_FROM_BITS(u) ar_from_bits_(u)
 #define AR_FMA(a, b, c) fma((a), (b), (c))
 #define AR_RINT(x) rint(x)
+#define AR_LDEXP(x, n) ldexp((x), (n))
+#define AR_MAXNUM(a, b) fmax((a), (b))
+#define AR_MINNUM(a, b) fmin((a), (b))
 #endif
 
 /* exp(x), any x; NaN -> NaN.  Branch-free: the argument is clamped into the range where k = rint(x / ln 2) fits the two-step
@@ -93,6 +99,50 @@ AR_FN double ar_log(double x)
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
     return AR_FMA(dk, 6.93147180369123816490e-01, f - (hfsq - AR_FMA(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+}
+
+/* ---- table-driven exp and log for the LD_MMA objectives (the solve phase is bound by vector-f64 issue, and these two are evaluated once
+ * per coordinate and objective evaluation): no division, a third fewer instructions, one 16-byte table read each.  `tab` points at the
+ * values of csrc/mmm_exptab.h / mmm_logtab.h -- in LDS on the device, a static array in the CPU restatement: same numbers, same bits.
+ *
+ * exp(x) = 2^m (hi_j + (lo_j + hi_j p(r))),  x = (128 m + j) ln2/128 + r, |r| <= ln2/256, hi_j + lo_j = 2^(j/128),
+ * p(r) = r + r^2/2 + r^3/6 + r^4/24 + r^5/120 (truncation < 5e-19 relative).  The reduction is exact in its first step (ln2/128 split like
+ * fdlibm's ln2: the high part has 21 trailing zero bits, |k| < 2^18).  < 0.51 ulp.  Any x; NaN -> NaN. */
+AR_FN double ar_exp_tab(double x, const double* tab)
+{
+    double kd = AR_RINT(x * 1.84664965233787316142e+02);                      /* 128 / ln 2 */
+    kd = AR_MINNUM(AR_MAXNUM(kd, -140000.0), 140000.0);                        /* keeps (int)kd defined; beyond +-758 the result is inf / 0 anyway */
+    const double r = AR_FMA(-kd, 1.4907929134926466e-12, AR_FMA(-kd, 5.41521234663378e-03, x));     /* ln2LO/128, ln2HI/128 = 0x1.62e42feep-8 */
+    const int k = (int)kd;
+    const int j = k & 127, m = k >> 7;                                         /* arithmetic shift: k = 128 m + j, 0 <= j < 128 */
+    const double hi = tab[2 * j], lo = tab[2 * j + 1];
+    double q = AR_FMA(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
+    q = AR_FMA(q, r, 1.66666666666666657e-01);
+    q = AR_FMA(q, r, 0.5);
+    const double p = AR_FMA(r * r, q, r);
+    const double y = hi + AR_FMA(hi, p, lo);
+    const double res = AR_LDEXP(y, m);
+    return x < -7.45133219101941108420e+02 ? 0.0 : res;                        /* (far below: r, p are -inf and y is not a number worth scaling) */
+}
+
+/* log(x) for NORMAL x > 0 (the nu of an LD_MMA solve: >= its lower bound 1e-7): x = 2^e m, m in [1, 2), interval j = top 7 mantissa
+ * bits with midpoint c_j, r = m / c_j - 1 (|r| < 2^-8; the table holds 1 / c_j and log c_j), log x = e ln 2 + log c_j + log1p(r),
+ * log1p by its series to r^6.  Absolute error < 2.5e-15 for x <= 30 (a few ulp of |log x| away from 1; the objective it enters is
+ * O(10..1e4), i.e. it stays below that sum's own rounding); no division. */
+AR_FN double ar_log_tab(double x, const double* tab)
+{
+    const unsigned long long u = AR_BITS(x);
+    const int hw = (int)(u >> 32);
+    const int e = (hw >> 20) - 1023, j = (hw >> 13) & 127;
+    const double m = AR_FROM_BITS((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double ic = tab[2 * j], lc = tab[2 * j + 1];
+    const double r = AR_FMA(m, ic, -1.0);
+    double p = AR_FMA(r, -1.0 / 6.0, 0.2);
+    p = AR_FMA(p, r, -0.25);
+    p = AR_FMA(p, r, 1.0 / 3.0);
+    p = AR_FMA(p, r, -0.5);
+    p = AR_FMA(p, r, 1.0);
+    return AR_FMA((double)e, 0.6931471805599453, lc + p * r);
 }
 
 /* psi(x) for x >= 7: log x - 1/(2x) - sum_k B_2k / (2k x^2k), 8 terms (the series of SpecialFunctions.jl) */

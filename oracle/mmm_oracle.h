@@ -164,6 +164,8 @@ void orc_twin_objectives(int n, const double* lambda, const double* nu, const do
 void orc_ar_exp_vec(int n, const double* x, double* out);
 void orc_ar_log_vec(int n, const double* x, double* out);
 void orc_ar_digamma_vec(int n, const double* x, double* out);
+void orc_ar_exptab_vec(int n, const double* x, double* out);      /* ar_exp_tab / ar_log_tab: the table-driven exp / log of the LD_MMA objectives */
+void orc_ar_logtab_vec(int n, const double* x, double* out);
 
 void orc_ctm_update_zeta(orc_ctm* m, int d);
 void orc_ctm_update_theta(orc_ctm* m, int d);

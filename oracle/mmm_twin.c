@@ -19,6 +19,12 @@
  */
 #include "mmm_oracle.h"
 #include "../multimodalmusig.jl_amd/csrc/mmm_arith.h"
+#include "../multimodalmusig.jl_amd/csrc/mmm_exptab.h"
+#include "../multimodalmusig.jl_amd/csrc/mmm_logtab.h"
+
+/* the function tables of the LD_MMA objectives (ar_exp_tab / ar_log_tab): the numbers the solve kernels stage into LDS */
+static const double tw_exptab[MMM_EXPTAB_N] = { MMM_EXPTAB_VALUES };
+static const double tw_logtab[MMM_LOGTAB_N] = { MMM_LOGTAB_VALUES };
 
 #include <math.h>
 #include <stdlib.h>
@@ -133,9 +139,9 @@ static double tw_nu_eval(const tw_obj* o, const double* x, double* g)
     for (int l = 0; l < o->L; ++l) {
         if (l >= n) { t[l] = 0.0; g[l] = 0.0; continue; }
         const double Sll = o->invSigma[(size_t)l * n + l], c = o->c[l];
-        const double E = ar_exp(o->other[l] + 0.5 * x[l]);
+        const double E = ar_exp_tab(o->other[l] + 0.5 * x[l], tw_exptab);
         g[l] = 0.5 * Sll + 0.5 * c * E - 1.0 / (2.0 * x[l]);
-        t[l] = 0.5 * x[l] * Sll + c * E - 0.5 * ar_log(x[l]);
+        t[l] = 0.5 * x[l] * Sll + c * E - 0.5 * ar_log_tab(x[l], tw_logtab);
     }
     return tw_sum(o, t);
 }
@@ -159,7 +165,7 @@ static double tw_lam_eval(const tw_obj* o, const double* x, double* g)
         for (; j < n; ++j) s0 = fma(o->invSigma[(size_t)j * n + l], diff[j], s0);
         const double Sd = (s0 + s1) + (s2 + s3);
         const double c = o->c[l], sumth = o->sumth[l];
-        const double E = ar_exp(x[l] + 0.5 * o->other[l]);
+        const double E = ar_exp_tab(x[l] + 0.5 * o->other[l], tw_exptab);
         g[l] = Sd - sumth + c * E;
         t[l] = 0.5 * diff[l] * Sd - x[l] * sumth + c * E;
     }
@@ -184,11 +190,11 @@ static int tw_mma(const tw_obj* o, tw_eval_fn eval, double* x, int has_lb, doubl
     for (;;) {
         for (int l = 0; l < L; ++l) {
             if (l >= n) { xc[l] = x[l]; gl[l] = 0.0; wl[l] = 0.0; continue; }
+            /* the device's form of NLopt's step (ctm.hip mma_group): q = u / (v sigma) = (g sigma) / v, u / v = q sigma -- one quotient */
             const double sigma2 = sigma[l] * sigma[l];
-            const double u = grad[l] * sigma2;
             const double v = fabs(grad[l]) * sigma[l] + 0.5 * rho;
-            const double q = u / (v * sigma[l]);
-            double dx = (u / v) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+            const double q = (grad[l] * sigma[l]) / v;
+            double dx = (q * sigma[l]) / (-1.0 - sqrt(fabs(1.0 - q * q)));
             double c = x[l] + dx;
             if (has_lb && c < lb) c = lb;
             if (c > x[l] + 0.9 * sigma[l]) c = x[l] + 0.9 * sigma[l]; else if (c < x[l] - 0.9 * sigma[l]) c = x[l] - 0.9 * sigma[l];
@@ -656,3 +662,5 @@ void orc_twin_objectives(int n, const double* lambda, const double* nu, const do
 void orc_ar_exp_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_exp(x[i]); }
 void orc_ar_log_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_log(x[i]); }
 void orc_ar_digamma_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_digamma_pos(x[i]); }
+void orc_ar_exptab_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_exp_tab(x[i], tw_exptab); }
+void orc_ar_logtab_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_log_tab(x[i], tw_logtab); }

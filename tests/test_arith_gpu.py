@@ -43,6 +43,34 @@ def test_exp_log_digamma_bits(mmm, oracle, ctx):
     _bits_equal(_dev(mmm, ctx, 2, xs), ref)
 
 
+def test_table_exp_log_bits_and_accuracy(mmm, oracle, ctx):
+    """ar_exp_tab / ar_log_tab (the exp / log of the LD_MMA objectives: 128-entry tables, no division): the device evaluates them from LDS,
+    the CPU restatement from a static array of the same generated numbers -- bit for bit, including the ends of the range (v_ldexp_f64 against
+    the host's ldexp on subnormal results) -- and they are as accurate as their header claims (exp < 1 ulp; log: absolute 2.5e-15 up to x = 30)."""
+    import mpmath as mp
+    rng = np.random.default_rng(21)
+    L = oracle.lib()
+    xs = np.concatenate([rng.uniform(-40, 40, 200000), rng.uniform(-760, 712, 40000), rng.normal(0, 1e-4, 2000), rng.uniform(-745.2, -707, 20000),
+                         [0.0, -0.0, 709.7, 709.78, 709.79, 710.0, 1e5, -1e5, 1e300, -1e300, np.inf, -np.inf, np.nan, -745.0, -745.13, -745.14, -746.0, -750.0, 1e-320]])
+    ref = np.empty_like(xs); L.orc_ar_exptab_vec(xs.size, xs, ref)
+    _bits_equal(_dev(mmm, ctx, 9, xs), ref)
+    with np.errstate(over="ignore"):
+        np.testing.assert_allclose(ref[:200000], np.exp(xs[:200000]), rtol=2.3e-16)
+    assert ref[-19 + 2] > 1e308 and np.isinf(ref[-19 + 4]) and np.isinf(ref[-19 + 8]) and ref[-19 + 9] == 0.0 and np.isnan(ref[-19 + 12]) and ref[-19 + 11] == 0.0
+    mp.mp.dps = 40
+    worst = 0.0
+    for x, y in zip(xs[:3000], ref[:3000]):                 # against 40-digit values: < 1 ulp
+        t = mp.exp(mp.mpf(float(x)))
+        worst = max(worst, float(abs(mp.mpf(float(y)) - t) / t) / 2.0 ** -52)
+    assert worst < 1.0, worst
+    xs = np.concatenate([rng.uniform(1e-7, 30, 200000), 10.0 ** rng.uniform(-300, 300, 20000), 1.0 + rng.normal(0, 1e-6, 2000), [1.0, 2.0, 0.5, 1e-7]])
+    ref = np.empty_like(xs); L.orc_ar_logtab_vec(xs.size, xs, ref)
+    _bits_equal(_dev(mmm, ctx, 10, xs), ref)
+    assert np.max(np.abs(ref[:200000] - np.log(xs[:200000]))) < 2.5e-15
+    worst = max(float(abs(mp.mpf(float(y)) - mp.log(mp.mpf(float(x))))) for x, y in zip(xs[:3000], ref[:3000]))
+    assert worst < 2.5e-15, worst
+
+
 def test_division_and_sqrt_are_ieee(mmm, ctx):
     """dev_div / dev_sqrt (the compiler's sequences without range handling) are correctly rounded in the range the MMA step
     algebra works in -- the host side of the parity tests uses plain `/` and sqrt()."""
