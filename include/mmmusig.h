@@ -68,6 +68,48 @@ int mmm_ctx_synchronize(mmm_ctx* ctx);
 /* The hipStream_t every kernel of this ctx is launched on (for event timing by the caller). */
 void* mmm_ctx_stream(mmm_ctx* ctx);
 int mmm_ctx_device_name(mmm_ctx* ctx, char* buf, size_t n);
+
+/* ---- run-time choices of the caller (SURVEY section 5 "Config / flags": a plain C struct across the ABI) -------------------------------
+ * What a caller may legitimately choose -- which E-step build a handle takes, a PINNED launch geometry, the side stream -- travels here,
+ * not in environment variables: mmm_ctx_set_tuning stores the options on the context and every handle CREATED afterwards keeps its own
+ * copy (two handles of one process may differ).  0 in a field = the library decides.  The all-reduce transport is chosen separately
+ * (mmm_p2p_enable).  The only environment variables the library still reads concern the transport set-up: MMM_P2P, MMM_P2P_TIMEOUT_S,
+ * MMM_P2P_ONE_RANK, MMM_FORCE_RCCL. */
+enum { MMM_BUILD_AUTO = 0,
+       MMM_BUILD_SPARSE = 1,   /* sweep the CSR arrays / padded rows through the LDS tables (any corpus)                              */
+       MMM_BUILD_DENSE = 2,    /* rows of counts, statistics in registers (dense corpora; falls back when the shape has no such build) */
+       MMM_BUILD_WIDE = 3 };   /* topic tables through L2 instead of LDS, term-major statistics sweep (large vocabularies)             */
+enum { /* mmm_tuning_opts.disable: optimisations a test or an A/B run may switch off, one bit each (results are unchanged unless noted) */
+    MMM_OFF_LDA_PADDED_ROWS = 1 << 0,   /* single-step E-step build: fetch (term, count) through doc_ptr instead of padded rows                  */
+    MMM_OFF_LDA_COUNT_ROWS = 1 << 1,    /* dense corpora: keep (term, count) rows instead of rows of counts                                        */
+    MMM_OFF_LDA_ROWS16 = 1 << 2,        /* rows of int32 instead of 16-bit counts                                                                  */
+    MMM_OFF_LDA_LL_JOIN = 1 << 3,       /* reduce blocks do not join the log-likelihood sweep of the merged launch                                 */
+    MMM_OFF_LDA_MERGED = 1 << 4,        /* reduce, ll and M-step as separate launches instead of k_lda_reduce_ll_mstep                             */
+    MMM_OFF_P2P_FOLDED = 1 << 5,        /* several GPUs: the mailbox exchange as its own launch instead of folded into the reduce / M-step blocks */
+    MMM_OFF_CTM_PACKED = 1 << 6,        /* solve phase: no packed document groups (sum K = 6 / 10 / 12 lanes per document)                         */
+    MMM_OFF_CTM_CPL = 1 << 7,           /* solve phase: one coordinate per lane everywhere (no several-coordinates-per-lane builds)                */
+    MMM_OFF_CTM_KFIT = 1 << 8,          /* theta phase: 16-wide topic loops for every shape                                                        */
+    MMM_OFF_CTM_FUSED_GAUSS = 1 << 9,   /* Gaussian M-step as its own launch instead of block 0 of the log-likelihood launch                       */
+    MMM_OFF_CTM_LL_ROWS = 1 << 10       /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
+};
+typedef struct {
+    int lda_build;        /* MMM_BUILD_*: E-step build of LDA / ILDA handles                                                              */
+    int ctm_build;        /* MMM_BUILD_*: theta phase of the fused pass of MMCTM / IMMCTM handles                                         */
+    int geometry_cus;     /* > 0: size every launch whose block count fixes the association of a cross-document sum (and so the bits of  */
+                          /* a fit) as if the device had this many CUs -- the same value gives the same bits on any gfx950 device or     */
+                          /* partition mode (256 = an MI355X in SPX mode).  0: the device's own CU count.                                */
+    int grid_blocks;      /* > 0: that many blocks for the E-step kernel (LDA: forces the grid-stride build) / the theta phase (CTM)      */
+    int waves_per_block;  /* > 0: waves per block of the LDA E-step kernel                                                                */
+    int moment_blocks;    /* > 0: blocks of the CTM moment sums                                                                           */
+    int side_stream;      /* CTM fit passes on one GPU: -1 never, 0 library's choice (IMMCTM only), 1 whenever possible                   */
+    int resident_cap;     /* > 0: lowers the residency bound of the merged LDA launch (tests of the fallback)                             */
+    unsigned disable;     /* MMM_OFF_* bits                                                                                               */
+    int reserved[7];      /* 0                                                                                                            */
+} mmm_tuning_opts;
+void mmm_tuning_opts_default(mmm_tuning_opts* o);
+/* opts == NULL: back to the defaults.  Applies to handles created on ctx from now on. */
+int mmm_ctx_set_tuning(mmm_ctx* ctx, const mmm_tuning_opts* opts);
+int mmm_ctx_get_tuning(const mmm_ctx* ctx, mmm_tuning_opts* out);
 /* HIP-event timing of the dominant kernel of the hot path (the fused E-step kernel) on the ctx stream: between
  * begin and end every launch of it is bracketed by an event pair; end synchronises and returns the number of
  * launches and the sum of their durations in milliseconds. */

@@ -108,6 +108,9 @@ _SIGS = {
     "mmm_ctm_replicas": (C.c_int, [vp]),
     "mmm_ctm_select": (C.c_int, [vp, C.c_int]),
     "mmm_ctm_fit_batch": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]),
+    "mmm_tuning_opts_default": (None, [vp]),
+    "mmm_ctx_set_tuning": (C.c_int, [vp, vp]),
+    "mmm_ctx_get_tuning": (C.c_int, [vp, vp]),
     "mmm_lda_update_Elntheta": (C.c_int, [vp]),
     "mmm_lda_update_Elnbeta": (C.c_int, [vp]),
     "mmm_ctm_update_doc": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -150,6 +153,17 @@ def check(rc, ctx_handle=None, what=""):
 _ALL_CTX = []
 
 
+class TuningOpts(C.Structure):
+    """mmm_tuning_opts (include/mmmusig.h)"""
+    _fields_ = [("lda_build", C.c_int), ("ctm_build", C.c_int), ("geometry_cus", C.c_int), ("grid_blocks", C.c_int), ("waves_per_block", C.c_int),
+                ("moment_blocks", C.c_int), ("side_stream", C.c_int), ("resident_cap", C.c_int), ("disable", C.c_uint), ("reserved", C.c_int * 7)]
+
+
+BUILDS = {"auto": 0, "sparse": 1, "dense": 2, "wide": 3}
+OFF = {"lda_padded_rows": 1 << 0, "lda_count_rows": 1 << 1, "lda_rows16": 1 << 2, "lda_ll_join": 1 << 3, "lda_merged": 1 << 4, "p2p_folded": 1 << 5,
+       "ctm_packed": 1 << 6, "ctm_cpl": 1 << 7, "ctm_kfit": 1 << 8, "ctm_fused_gauss": 1 << 9, "ctm_ll_rows": 1 << 10}
+
+
 class Context:
     """One GPU + one HIP stream (+ one RCCL rank).  Mirrors `mmm_ctx`."""
 
@@ -166,6 +180,27 @@ class Context:
 
     def synchronize(self):
         check(lib().mmm_ctx_synchronize(self.h), self.h, "mmm_ctx_synchronize")
+
+    def set_tuning(self, lda_build="auto", ctm_build="auto", geometry_cus=0, grid_blocks=0, waves_per_block=0, moment_blocks=0, side_stream=0,
+                   resident_cap=0, disable=()):
+        """mmm_ctx_set_tuning: the caller's choices for the handles created on this context FROM NOW ON (no arguments: the defaults).
+        lda_build / ctm_build: "auto" | "sparse" | "dense" | "wide"; geometry_cus: size the launches as if the device had that many CUs
+        (pins the association of the cross-document sums, and so the bits of a fit, across devices); disable: names of OFF."""
+        t = TuningOpts()
+        t.lda_build, t.ctm_build = BUILDS[lda_build], BUILDS[ctm_build]
+        t.geometry_cus, t.grid_blocks, t.waves_per_block, t.moment_blocks = int(geometry_cus), int(grid_blocks), int(waves_per_block), int(moment_blocks)
+        t.side_stream, t.resident_cap = int(side_stream), int(resident_cap)
+        d = 0
+        for name in ([disable] if isinstance(disable, str) else disable):
+            d |= OFF[name]
+        t.disable = d
+        check(lib().mmm_ctx_set_tuning(self.h, C.byref(t)), self.h, "mmm_ctx_set_tuning")
+        return self
+
+    def get_tuning(self):
+        t = TuningOpts()
+        check(lib().mmm_ctx_get_tuning(self.h, C.byref(t)), self.h, "mmm_ctx_get_tuning")
+        return t
 
     @property
     def stream(self):

@@ -311,7 +311,6 @@ struct CtmEArgs {
     // fused pass (F_SLAB): the theta phase also keeps lambda_{t-1} and the exp table of this pass (theta_t is rebuilt from them on
     // demand) -- it reads both anyway, which saves the copy launch.  Base of replica 0, may be NULL.
     double* lam_keep; double* expE_keep;
-    int* claim;             // split solve launches: the launch's document counter (one per replica, 32 ints apart; zero at launch), or NULL
 };
 
 // PH = 0: zeta / theta / sumtheta / gamma slabs (register-heavy, table- and slab-staged);
@@ -917,53 +916,12 @@ struct LamObjC {
 // to its slowest document with the other slots idle -- 1.3-2x the mean at 32 slots); a new document's first evaluation f(x0)
 // rides in the common trip with the candidate point = x0.  Every document goes through exactly the operations of mma_group,
 // whatever its slot and its neighbours.
-// Documents handed out on demand (split solve launches): the LD_MMA solves of a corpus take very different numbers of evaluations, so
-// static document ranges leave SIMDs idle behind the slowest wave (50,000 documents over 3,072 waves: the slowest SIMD carries ~25 % more
-// than the mean).  A block's slots take TICKETS from a counter in LDS; ticket t stands for entry t % kClaimChunk of the block's
-// (t / kClaimChunk)-th chunk of documents, and chunks come from one counter in device memory, kClaimChunk documents per atomic (a
-// returning device-scope atomic on this 8-XCD part is a round trip to the memory side: one per document would serialise).  The slot
-// that takes the first ticket of chunk c requests chunk c + 1, so a chunk is there before its tickets are drawn; its start is published
-// in a small ring in LDS, tagged with the chunk number.  Which slot solves which document changes nothing in the results.
-constexpr int kClaimChunk = 32, kClaimRing = 8;
-struct ClaimPool { int tix; int pad; unsigned long long ring[kClaimRing]; };
-
-// every lane of the wave calls; `want`: this lane leads a slot that needs a document.  Returns the document index (>= D: none left).
-__device__ __forceinline__ int claim_doc(ClaimPool* pool, int* gcnt, bool want, int lane)
-{
-    const unsigned long long fm = __ballot(want);
-    const int n = __popcll(fm);
-    int t0 = 0;
-    if (lane == 0) t0 = __hip_atomic_fetch_add(&pool->tix, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    t0 = __builtin_amdgcn_readfirstlane(t0);
-    const int t = t0 + __popcll(fm & ((1ull << lane) - 1ull));
-    const int c = t / kClaimChunk, off = t % kClaimChunk;
-    if (want && off == 0) {       // first ticket of chunk c: fetch chunk c + 1 (chunk 0 is fetched when the block starts)
-        const int s = __hip_atomic_fetch_add(gcnt, kClaimChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&pool->ring[(c + 1) % kClaimRing], ((unsigned long long)(c + 2) << 32) | (unsigned int)s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    int d = 0x7fffffff;
-    bool pending = want;
-    for (int spin = 0; __any(pending) && spin < (1 << 22); ++spin) {      // (the cap is never reached: an exit condition every wave has)
-        if (pending) {
-            const unsigned long long e = __hip_atomic_load(&pool->ring[c % kClaimRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((int)(e >> 32) == c + 1) { d = (int)(unsigned int)e + off; pending = false; }
-        }
-        if (__any(pending)) __builtin_amdgcn_s_sleep(2);
-    }
-    return d;
-}
-
 template <int MKT, int LPD, bool SB, class Obj>
-__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out,
-                                            ClaimPool* pool = nullptr, int* gcnt = nullptr)
+__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out)
 {
     constexpr int CPL = CplGeom<MKT, LPD>::CPL, G = MMM_WAVE / LPD;
     const int g = lane / LPD, l = lane % LPD;
     int d = r0 + g, next = r0 + G;
-    if (pool) {       // r0 = 0, r1 = D: documents on demand
-        d = claim_doc(pool, gcnt, l == 0, lane);
-        d = __shfl(d, g * LPD, MMM_WAVE);
-    }
     bool have = d < r1, fresh = true;
     double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL];
     // NLopt's sigma update looks at the SIGN of (xcur - xprev) (xprev - xprevprev).  Only the sign of the older step is kept (+1 / 0 / -1 as a
@@ -1056,14 +1014,10 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
                 obj.store(dc, d, x);
                 if (nev_out && l == 0) nev_out[d] = capped ? -nev : nev;
             }
-            // the finished slots take the next documents of the range, in slot order (or the next documents anyone has not taken yet)
+            // the finished slots take the next documents of the range, in slot order
             const unsigned long long fm = __ballot(finished && l == 0);
-            int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
+            const int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
             next += __popcll(fm);
-            if (pool) {
-                nd = claim_doc(pool, gcnt, finished && l == 0, lane);
-                nd = __shfl(nd, g * LPD, MMM_WAVE);
-            }
             if (finished) {
                 d = nd; have = nd < r1;
                 obj.load(dc, have ? d : -1, x);
@@ -1075,9 +1029,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
     }
 }
 
-// WHICH: 1 = update_ν! only, 2 = update_λ! only, 3 = both (a build with one solve keeps only that solve's registers: the ν solve needs
-// neither the Σ⁻¹ table nor the difference vectors in LDS)
-template <int MKT, int LPD, int OCC, bool SB, int WHICH = 3>
+template <int MKT, int LPD, int OCC, bool SB>
 __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1102,8 +1054,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     double* sMu = sScr + (size_t)NW * G * (MK + 2);      // [LPD * CPL]
     __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];      // exp | log tables of the objectives
     stage_solve_tabs(sTabs);
-    if constexpr ((WHICH & 2) == 0) __syncthreads();
-    if constexpr ((WHICH & 2) != 0) {
+    {
         for (int e = tid; e < LPD * CPL; e += blockDim.x) sMu[e] = e < MK ? p_mu[e] : 0.0;
         for (int e = tid; e < MK * Gm::ROW; e += blockDim.x) {
             const int j = e / Gm::ROW, r = e % Gm::ROW, ll = r / Gm::CPLP, q = r % Gm::CPLP;
@@ -1111,27 +1062,10 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         }
         __syncthreads();
     }
-    // the wave's documents: a contiguous range, or (split launches with a claim counter) whatever is next
+    // the wave's documents: a contiguous range
     const int nwaves = gridDim.x * NW, w = blockIdx.x * NW + wid;
     const int per = (D + nwaves - 1) / nwaves;
-    int r0 = min(D, w * per), r1 = min(D, r0 + per);
-    __shared__ ClaimPool s_pool;
-    ClaimPool* pool = nullptr;
-    int* gcnt = nullptr;
-    if constexpr (WHICH != 3) {
-        if (a.claim) {
-            gcnt = a.claim + rep * 32;
-            pool = &s_pool;
-            if (tid == 0) {
-                s_pool.tix = 0;
-                for (int i = 1; i < kClaimRing; ++i) s_pool.ring[i] = 0ull;
-                const int s0 = __hip_atomic_fetch_add(gcnt, kClaimChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_pool.ring[0] = (1ull << 32) | (unsigned int)s0;
-            }
-            __syncthreads();
-            r0 = 0; r1 = D;
-        }
-    }
+    const int r0 = min(D, w * per), r1 = min(D, r0 + per);
     static_assert(CPL <= 7, "modality indices are packed 4 bits each into one int");
     int modpack = 0;
 #pragma unroll
@@ -1143,27 +1077,25 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     }
     const SolveOpts o = a.opt;
     // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ -- for every document of the range
-    if constexpr ((WHICH & 1) != 0) if (a.flags & F_NU) {
+    if (a.flags & F_NU) {
         NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0;
         obj.modpack = modpack;
         obj.l = l; obj.lane_on = lane_on; obj.tabs = sTabs;
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, pool, gcnt);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu);
     }
     // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
-    if constexpr (WHICH == 3) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
-    if constexpr ((WHICH & 2) != 0) if (a.flags & F_LAMBDA) {
+    if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
         obj.modpack = modpack;
         obj.tabs = sTabs;
         obj.smu = sMu;
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam, pool, gcnt);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam);
     }
 }
 
@@ -2128,6 +2060,7 @@ __global__ void k_copy_rep(double* dst, const double* src, size_t n, const int* 
 // single-model API works on the selected replica (`sel`, 0 by default).
 struct mmm_ctm {
     mmm_ctx* ctx = nullptr;
+    mmm_tuning_opts tune{};        // the caller's choices at create time (mmm_ctx_set_tuning)
     CtmDims dm{};
     CtmTopics tp{};
     bool immctm = false;
@@ -2135,9 +2068,7 @@ struct mmm_ctm {
     int L = 64, GM = 0 /* model-layout gamma size */;
     int Ls = 64;                   // lanes per document in the solve phase: L, or sum K for the packed builds (6 / 12), or 2 / 4 (cpl > 1)
     int cpl = 1;                   // coordinates per lane in the solve phase (k_ctm_solve_cpl: sum K = 10, 14, 28)
-    // split solve phase: update_ν! and update_λ! as two launches, each in its own lane layout (nu_Ls lanes x nu_cpl coordinates; the λ
-    // solve in the layout of Ls / cpl / persist)
-    bool split = false; int nu_Ls = 0, nu_cpl = 0, nu_occ = 4, lam_occ = 4, grid_nu = 1;
+    int lam_occ = 4;               // waves per SIMD of the persistent solve build (3 for sum K = 28)
     bool persist = false;          // solve phase by k_ctm_solve_cpl (persistent waves, document slots refilled): cpl > 1, or cpl = 1 with Ls = L
     int64_t nnz = 0, theta_n = 0;
     long long nnzm[kMaxM] = {0};
@@ -2149,7 +2080,6 @@ struct mmm_ctm {
     DevBuf<double> mu, Sigma, invSigma, gamma, Elnphi, phi, Eeff, expEeff, expEeff_prev, phieff;   // [R][...]
     DevBuf<double> partial, mompart, stats, llpart, llnum, Nm, elbopart, ll_hist;
     DevBuf<int> nev_nu, nev_lam, status, active, npass;
-    DevBuf<int> claim;             // [2][R][32]: document counters of the split nu / lambda launches
     // dense corpora: the fused pass's theta phase over rows of 16-bit counts, one launch per modality (k_ctm_theta_dense)
     bool tdense = false; int tSL[kMaxM] = {0};
     DevBuf<unsigned short> trows[kMaxM];      // [D][16][SL_m rounded up to even]: lane-major rows of counts (a lane's part of a row is one load)
@@ -2217,33 +2147,6 @@ size_t solve_lds(const mmm_ctm* m)
     return sizeof(double) * ((size_t)m->dm.MK * m->dm.MK + m->dm.MK + (size_t)m->waves_s * scrw);
 }
 
-// update_ν! alone, several coordinates per lane (split solve phase)
-int launch_nu_split(mmm_ctm* m, const CtmEArgs& a, int nrep)
-{
-    mmm_ctx* ctx = m->ctx;
-    auto go = [&](auto kern) -> int {
-        hipLaunchKernelGGL(kern, dim3(m->grid_nu, nrep), dim3(m->waves_s * MMM_WAVE), 0, ctx->stream, a);
-        MMM_LAUNCH_CHECK(ctx);
-        return MMM_OK;
-    };
-    const int key = m->dm.MK * 10000 + m->nu_Ls * 10 + m->nu_occ;
-    switch (key) {
-        case 280082: return go(k_ctm_solve_cpl<28, 8, 2, false, 1>);
-        case 280083: return go(k_ctm_solve_cpl<28, 8, 3, false, 1>);
-        case 280084: return go(k_ctm_solve_cpl<28, 8, 4, false, 1>);
-        case 280162: return go(k_ctm_solve_cpl<28, 16, 2, false, 1>);
-        case 280163: return go(k_ctm_solve_cpl<28, 16, 3, false, 1>);
-        case 280164: return go(k_ctm_solve_cpl<28, 16, 4, false, 1>);
-        case 280166: return go(k_ctm_solve_cpl<28, 16, 6, false, 1>);
-        case 280042: return go(k_ctm_solve_cpl<28, 4, 2, false, 1>);
-        case 280043: return go(k_ctm_solve_cpl<28, 4, 3, false, 1>);
-        case 100022: return go(k_ctm_solve_cpl<10, 2, 2, false, 1>);
-        case 100023: return go(k_ctm_solve_cpl<10, 2, 3, false, 1>);
-        case 100024: return go(k_ctm_solve_cpl<10, 2, 4, false, 1>);
-    }
-    return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no split nu-solve build for sum K = %d, %d lanes, %d waves per SIMD", m->dm.MK, m->nu_Ls, m->nu_occ);
-}
-
 size_t theta_dense_lds(const mmm_ctm* m, int i, int kmx)
 {
     const int NW = m->waves_e;
@@ -2278,12 +2181,13 @@ int launch_theta_dense(mmm_ctm* m, const CtmEArgs& a, int nrep)
     return MMM_OK;
 }
 
+
 template <int PH>
 int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves, int nrep)
 {
     if (m->big) {      // sum K > 64: the generic kernels (ctm_big.cuh), one wave per document
         mmm_ctx* ctx = m->ctx;
-        const int nblk = std::max(1, std::min((m->dm.D + 3) / 4, ctx->num_cu * 4));
+        const int nblk = std::max(1, std::min((m->dm.D + 3) / 4, mmm_geo_cus(ctx) * 4));
         if constexpr (PH == 0) {
             const size_t l = sizeof(double) * 4 * (64 + 64 * 64);
             MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_theta_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
@@ -2296,7 +2200,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
         return MMM_OK;
     }
     if constexpr (PH == 1) {      // solve phase: compile-time sum K for the shapes of the BASELINE configs (cfg 5 / 3 / 4)
-        const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * m->ctx->num_cu;      // cannot fill 4 waves per SIMD anyway
+        const bool small = (int64_t)grid * waves * nrep <= (int64_t)3 * 4 * mmm_geo_cus(m->ctx);      // cannot fill 4 waves per SIMD anyway
         if (m->persist) {          // persistent waves with refilled document slots (several coordinates per lane, or one)
             mmm_ctx* ctx = m->ctx;
             auto go = [&](auto kern) -> int {
@@ -2305,42 +2209,23 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
                 MMM_LAUNCH_CHECK(ctx);
                 return MMM_OK;
             };
-            // builds: 2 waves per SIMD, chains of the coordinates interleaved by the scheduler (sum K = 10: 245 VGPRs, no scratch; 263 us at
-            // config 5 against 323 us for the 3-wave build with one coordinate at a time); sum K = 14 / 28: the 2-wave builds with scheduling barriers
-            if (m->dm.MK == 10 && m->Ls == 2 && !m->split) return go(k_ctm_solve_cpl<10, 2, 2, false>);
-            if (m->dm.MK == 28 && m->Ls == 8 && !m->split) return go(k_ctm_solve_cpl<28, 8, 2, false>);
-            if (m->dm.MK == 14 && m->Ls == 2) return go(k_ctm_solve_cpl<14, 2, 2, true>);
-            if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
-            if (!m->split && m->dm.MK == 28 && m->Ls == 16) return m->lam_occ == 4 ? go(k_ctm_solve_cpl<28, 16, 4, false>) : go(k_ctm_solve_cpl<28, 16, 3, false>);
-            if (!m->split && m->dm.MK == 14 && m->Ls == 8) return go(k_ctm_solve_cpl<14, 8, 4, false>);
-            if (m->split && m->dm.MK == 28 && m->Ls == 16) {
-                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 16, 2, false, 2>);
-                if (m->lam_occ == 3) return go(k_ctm_solve_cpl<28, 16, 3, false, 2>);
-                return go(k_ctm_solve_cpl<28, 16, 4, false, 2>);
-            }
-            if (m->split && m->dm.MK == 10 && m->Ls == 2) {
-                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<10, 2, 2, false, 2>);
-                if (m->lam_occ == 3) return go(k_ctm_solve_cpl<10, 2, 3, false, 2>);
-                return go(k_ctm_solve_cpl<10, 2, 4, false, 2>);
-            }
-            if (m->split && m->dm.MK == 28 && m->Ls == 8) {
-                if (m->lam_occ == 2) return go(k_ctm_solve_cpl<28, 8, 2, false, 2>);
-                return go(k_ctm_solve_cpl<28, 8, 3, false, 2>);
-            }
+            // builds: sum K = 10 (BASELINE config 5) 2 lanes x 5 coordinates at 2 waves per SIMD, the chains of the coordinates interleaved by the
+            // scheduler (245 VGPRs, no scratch); sum K = 28 (config 4) 16 lanes, 14 of them x 2 coordinates, at 3 waves per SIMD.  The other
+            // layouts that were built and measured -- 8 x 4 and 32 x 1 for sum K = 28, 2 x 7 and 8 x 2 for sum K = 14, the two solves as two
+            // launches with documents claimed on demand -- did not beat these and are gone from the source.
+            if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
+            if (m->dm.MK == 28 && m->Ls == 16) return go(k_ctm_solve_cpl<28, 16, 3, false>);
             return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
         }
         if (m->Ls != m->L) {       // packed groups: sum K lanes per document
             if (m->Ls == 6) return launch_estep_L<16, PH, 6, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
-            static const int pocc = getenv("MMM_CTM_PACK_OCC") ? atoi(getenv("MMM_CTM_PACK_OCC")) : 4;
-            if (m->Ls == 10 && pocc == 3) return launch_estep_L<16, PH, 10, 16, 3, false, true>(m, a, lds, grid, waves, nrep);
             if (m->Ls == 10) return launch_estep_L<16, PH, 10, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
             if (m->Ls == 12) return launch_estep_L<16, PH, 12, 16, 4, false, true>(m, a, lds, grid, waves, nrep);
             return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "no packed solve build for sum K = %d", m->Ls);
         }
         if (m->L == 16 && m->dm.MK == 10) return small ? launch_estep_L<16, PH, 10, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 10>(m, a, lds, grid, waves, nrep);
         if (m->L == 16 && m->dm.MK == 14) return small ? launch_estep_L<16, PH, 14, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<16, PH, 14>(m, a, lds, grid, waves, nrep);
-        static const bool occ3 = getenv("MMM_CTM_OCC3") != nullptr;
-        if (m->L == 32 && m->dm.MK == 28) return (small || occ3) ? launch_estep_L<32, PH, 28, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
+        if (m->L == 32 && m->dm.MK == 28) return small ? launch_estep_L<32, PH, 28, 16, 3>(m, a, lds, grid, waves, nrep) : launch_estep_L<32, PH, 28>(m, a, lds, grid, waves, nrep);
     }
     if constexpr (PH == 0) {      // theta phase: a modality with more than 16 topics takes the build unrolled to 32
         int kmax = 0;
@@ -2357,7 +2242,7 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
         if (kmax > 16) return m->L == 32 ? launch_estep_L<32, PH, 0, 32>(m, a, lds, grid, waves, nrep) : launch_estep_L<64, PH, 0, 32>(m, a, lds, grid, waves, nrep);
         // the topic loops are unrolled to KMX: builds with KMX = 10 / 8 for the BASELINE shapes (K = [10,10,8], [10], [7,7]) instead of 16 --
         // the padded topics cost instructions (a product, two sums, a select and an exec-masked atomic each), not results
-        static const bool kfit = getenv("MMM_CTM_KMX16") == nullptr;
+        const bool kfit = !mmm_off(m->tune, MMM_OFF_CTM_KFIT);
         if (kfit && kmax <= 8 && m->L == 16) return launch_estep_L<16, PH, 0, 8>(m, a, lds, grid, waves, nrep);
         if (kfit && kmax <= 10 && m->L == 16) return launch_estep_L<16, PH, 0, 10>(m, a, lds, grid, waves, nrep);
         if (kfit && kmax <= 10 && m->L == 32) return launch_estep_L<32, PH, 0, 10>(m, a, lds, grid, waves, nrep);
@@ -2414,20 +2299,7 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
     if (fork_after_theta) MMM_HIP(m->ctx, hipEventRecord(m->ctx->ev_fork, m->ctx->stream));
     if (flags & (F_NU | F_LAMBDA)) {
         ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
-        if (m->split) {             // update_ν! and update_λ! as two launches, each in its own lane layout
-            CtmEArgs b = a;
-            static const bool dyn = getenv("MMM_CTM_CLAIM") == nullptr || atoi(getenv("MMM_CTM_CLAIM")) != 0;
-            for (int which = 0; which < 2; ++which) {
-                if (!(flags & (which == 0 ? F_NU : F_LAMBDA))) continue;
-                b.flags = flags & ~(which == 0 ? F_LAMBDA : F_NU);
-                b.claim = nullptr;
-                if (dyn && (which == 0 || m->persist)) {       // documents on demand: the launch's counters start at 0
-                    b.claim = m->claim.p + ((size_t)which * m->R + r0) * 32;
-                    MMM_HIP(m->ctx, hipMemsetAsync(b.claim, 0, sizeof(int) * 32 * sc.nrep, m->ctx->stream));
-                }
-                if ((rc = which == 0 ? launch_nu_split(m, b, sc.nrep) : launch_phase<1>(m, b, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
-            }
-        } else if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
+        if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
     }
     return MMM_OK;
 }
@@ -2518,7 +2390,6 @@ int materialise_theta(mmm_ctm* m)
     return MMM_OK;
 }
 
-inline bool getenv_ll_dense() { static const bool on = getenv("MMM_CTM_LL_DENSE") == nullptr || atoi(getenv("MMM_CTM_LL_DENSE")) != 0; return on; }
 
 // props (+ ll written to dst + r*dst_stride for every replica of the scope)
 // gauss_mu / gauss_sigma: also run update_μ! / update_Σ! of the pass in an extra block of the same launch (see k_ctm_loglik)
@@ -2534,7 +2405,7 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
         if (gauss) { int rc = run_mstep(m, sc, gauss_mu, gauss_sigma, 0, 0); if (rc) return rc; }
         hipLaunchKernelGGL(k_ctm_loglik_big, dim3(m->grid_s, sc.nrep), dim3(kBlockS), sizeof(double) * kWavesS * 64, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
                            m->phieff.p + r0 * m->dm.GT, m->props.p + r0 * m->sDMK(), m->llpart.p + r0 * m->grid_s * M, compute_ll ? 1 : 0, sc.active);
-    } else if (m->tdense && getenv_ll_dense()) {      // dense corpora: the sweep over rows of counts
+    } else if (m->tdense && !mmm_off(m->tune, MMM_OFF_CTM_LL_ROWS)) {      // dense corpora: the sweep over rows of counts
         DenseRows dr{};
         int kmx = 8, vt = 0;
         for (int i = 0; i < M; ++i) { dr.rows[i] = m->trows[i].p; dr.SL[i] = m->tSL[i]; dr.tpoff[i] = vt; vt += 16 * m->tSL[i]; kmx = std::max(kmx, theta_dense_kmx(m->dm.K[i])); }
@@ -2647,12 +2518,10 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     // for d in 1:D fitdoc!(model, d)   (lambda is updated in place: the theta phase has consumed it before the solve phase)
     // One GPU: what only depends on the theta phase -- the reduction of the gamma statistics and the topic M-step -- runs on a side stream
     // BESIDE the solve phase (which leaves a wave slot per SIMD free) and is joined before the log-likelihood launch: two launches and
-    // their boundaries off the pass's critical path.  Same kernels, same sums; MMM_CTM_OVERLAP=0 / 1: never / whenever possible.
+    // their boundaries off the pass's critical path.  Same kernels, same sums; mmm_tuning_opts.side_stream = -1 / 1: never / whenever possible.
     // Measured (5 regions x 10 passes each): cfg 5 (IMMCTM, topic M-step 13 us) 0.467 -> 0.458 ms per pass, min 0.407 -> 0.399; cfg 4 (MMCTM, topic
     // M-step 5 us) 1.082 -> 1.091: there the fork / join cost what the two short launches take -- so by default only the IMMCTM forks.
-    const char* overlap_s = getenv("MMM_CTM_OVERLAP");      // (read per pass: tests switch it within one process)
-    const int overlap_env = overlap_s ? atoi(overlap_s) : -1;
-    const bool overlap = (overlap_env < 0 ? m->immctm : overlap_env != 0) && ctx->nranks == 1 && !m->wide && !m->big &&
+    const bool overlap = (m->tune.side_stream == 0 ? m->immctm : m->tune.side_stream > 0) && ctx->nranks == 1 && !m->wide && !m->big &&
                          !(fit_flags & MMM_FIT_AUTO_ALPHA) && !ctx->profiling && side_stream(ctx) != nullptr;
     rc = run_estep(m, sc, F_ZETA | F_THETA_COMPUTE | F_NU | F_LAMBDA | F_SLAB, m->lambda.p, m->lambda.p, m->expEeff.p,
                    m->wide ? nullptr : m->lambda_prev.p, m->wide ? nullptr : m->expEeff_prev.p, overlap);
@@ -2693,8 +2562,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     if ((rc = mmm_allreduce_sum(ctx, m->stats.p + r0 * m->s_stats, (size_t)sc.nrep * m->s_stats))) return rc;
     // update_μ!, update_Σ!, update_γ! (+Elnϕ), update_ϕ!
     // (the Gaussian part runs as an extra block of the log-likelihood launch below, beside the document sweep)
-    static const int fuse_env = getenv("MMM_CTM_FUSE_GAUSS") ? atoi(getenv("MMM_CTM_FUSE_GAUSS")) : -1;
-    const bool fuse = fuse_env >= 0 ? fuse_env != 0 : true;
+    const bool fuse = !mmm_off(m->tune, MMM_OFF_CTM_FUSED_GAUSS);
     const int do_sig = (update_sigma || m->immctm) ? 1 : 0;
     if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, overlap ? 0 : 1, 1))) return rc;
     if (overlap) MMM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -2848,6 +2716,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         for (int i = 0; i <= M; ++i) tp.mgoff[i] = dm.goff[i];
     }
     m->GM = GM;
+    m->tune = ctx->tune;
     mmm_solver_opts so; mmm_solver_opts_default(&so);
     if (opts) so = *opts;
     m->opt = SolveOpts{so.xtol_rel, so.xtol_abs, so.nu_lower, so.xtol_rule, so.max_eval > 0 ? so.max_eval : 2000};
@@ -2855,21 +2724,21 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     const int G = MMM_WAVE / m->L;
     m->waves_e = 8;
     while (m->waves_e > 1 && estep_lds(m, F_SLAB) > 150 * 1024) m->waves_e >>= 1;
-    // table + one slab beyond LDS: the wide path (theta phase through L2, gamma statistics by k_ctm_stats_terms).  MMM_CTM_WIDE=1
-    // forces it for any shape (tests, A/B)
+    // table + one slab beyond LDS: the wide path (theta phase through L2, gamma statistics by k_ctm_stats_terms).  ctm_build =
+    // MMM_BUILD_WIDE forces it for any shape (tests, A/B)
     int kmax_all = 0;
     for (int i = 0; i < dm.M; ++i) kmax_all = std::max(kmax_all, dm.K[i]);
-    if (estep_lds(m, F_SLAB) > 160 * 1024 || getenv("MMM_CTM_WIDE") != nullptr || kmax_all > 32 || m->big) { m->wide = true; m->waves_e = 8; }
+    if (estep_lds(m, F_SLAB) > 160 * 1024 || ctx->tune.ctm_build == MMM_BUILD_WIDE || kmax_all > 32 || m->big) { m->wide = true; m->waves_e = 8; }
     const int dpb = m->waves_e * G;
     const int per_cu = m->wide ? 2 : std::max(1, (int)((160 * 1024) / estep_lds(m, F_SLAB)));
-    m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ctx->num_cu * std::min(per_cu, 2)));
+    const int ncu = mmm_geo_cus(ctx);      // the CU count the geometry (and so the association of the cross-document sums) is derived from
+    m->grid_e = std::max(1, std::min((D + dpb - 1) / dpb, ncu * std::min(per_cu, 2)));
     // Dense corpora: the fused pass's theta phase over rows of 16-bit counts (k_ctm_theta_dense), when every modality has at most 16 topics
     // and 128 terms, no document lists a term twice, every count fits 16 bits and at least half of the D x V_m entries are present.
-    // MMM_CTM_DENSE=1 / 0 forces / forbids it (tests, A/B); by default corpora of at least 32 documents per CU take it (below, a block of
+    // ctm_build = MMM_BUILD_DENSE / _SPARSE forces / forbids it (tests, A/B); by default corpora of at least 32 documents per CU take it (below, a block of
     // the 16-lane layout has less than one wave step and the slab kernel is as fast).
     {
-        const char* de = getenv("MMM_CTM_DENSE");
-        const int dmode = de ? atoi(de) : -1;
+        const int dmode = ctx->tune.ctm_build == MMM_BUILD_DENSE ? 1 : (ctx->tune.ctm_build == MMM_BUILD_AUTO ? -1 : 0);
         bool ok = !m->wide && !m->big && dmode != 0 && D > 0 && (int64_t)D * dm.MK * 8 < ((int64_t)1 << 32) && D < (1 << 24);      // (32-bit byte offsets into lambda and into the rows)
         int64_t present = 0, cells = 0;
         for (int i = 0; i < M && ok; ++i) {
@@ -2879,7 +2748,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             present += m->nnzm[i]; cells += (int64_t)D * dm.V[i];
         }
         if (ok && 2 * present < cells) ok = false;
-        if (ok && dmode < 0 && D < 32 * ctx->num_cu) ok = false;
+        if (ok && dmode < 0 && D < 32 * ncu) ok = false;
         std::vector<std::vector<unsigned short>> rows((size_t)M);
         for (int i = 0; i < M && ok; ++i) {
             const int sls = (m->tSL[i] + 1) & ~1, Vp = 16 * sls;     // lane-major: the slots of lane l (terms l, 16 + l, ...) are contiguous, an even number
@@ -2899,7 +2768,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         }
         if (ok) {
             m->tdense = true;
-            m->grid_e = std::max(1, std::min((D + 31) / 32, ctx->num_cu));
+            m->grid_e = std::max(1, std::min((D + 31) / 32, ncu));
             for (int i = 0; i < M; ++i) {
                 hipError_t e_ = m->trows[i].alloc(rows[i].size());
                 if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(trows): %s", hipGetErrorString(e_)); delete m; return rc; }
@@ -2909,56 +2778,36 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
             }
         }
     }
-    if (const char* s = getenv("MMM_CTM_GRID")) m->grid_e = std::max(1, atoi(s));
-    m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * 4));
-    if (const char* gs = getenv("MMM_CTM_GRID_S")) m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ctx->num_cu * std::max(1, atoi(gs))));
+    if (ctx->tune.grid_blocks > 0) m->grid_e = ctx->tune.grid_blocks;
+    m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ncu * 4));
     m->waves_s = 4;
-    // solve phase: packed document groups (sum K lanes per document) for the shapes with a build; MMM_CTM_PACK=0: the 16-lane rows (A/B)
+    // solve phase: packed document groups (sum K lanes per document) for the shapes with a build (MMM_OFF_CTM_PACKED: the 16-lane rows)
     m->Ls = m->L;
     {
-        const char* pe = getenv("MMM_CTM_PACK");
-        const bool allow = !pe || atoi(pe) != 0;
-        if (allow && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
+        if (!mmm_off(ctx->tune, MMM_OFF_CTM_PACKED) && (dm.MK == 6 || dm.MK == 10 || dm.MK == 12)) m->Ls = dm.MK;
         // several coordinates per lane (k_ctm_solve_cpl): sum K = 10 -> 2 lanes x 5 coordinates (32 document slots per wave; BASELINE config 5:
         // solve phase 334 -> 263 us); sum K = 28 -> 16 lanes, 14 of them x 2 coordinates (round 3; 4 slots per wave, 134 VGPRs at 3 waves per
         // SIMD, no scratch: BASELINE config 4 solve phase 1,096 -> 974 us at pass 20, 794 -> 757 us at pass 60 -- and the sums of a document
-        // are associated exactly as the 32-lane butterfly associates them, so not a bit changes).  Other builds for sum K = 14 (2 x 7) and
-        // 28 (8 lanes, 7 of them x 4; 32 lanes x 1) exist and do not beat these: MMM_CTM_CPL=2 / 3 select them (tests, A/B), MMM_CTM_CPL=0
-        // switches the path off (one coordinate per lane, lock step: k_ctm_estep<L, 1>).
-        const char* ce = getenv("MMM_CTM_CPL");
-        const int cmode = ce ? atoi(ce) : 1;
-        if (cmode != 0) {
+        // are associated exactly as the 32-lane butterfly associates them, so not a bit changes).  MMM_OFF_CTM_CPL switches the path off
+        // (one coordinate per lane, lock step: k_ctm_estep<L, 1>).
+        if (!mmm_off(ctx->tune, MMM_OFF_CTM_CPL)) {
             if (dm.MK == 10) { m->Ls = 2; m->cpl = 5; }
-            else if (cmode == 2 && dm.MK == 28) { m->Ls = 8; m->cpl = 4; }        // 7 of 8 lanes x 4 coordinates
-            else if (cmode == 2 && dm.MK == 14) { m->Ls = 2; m->cpl = 7; }
-            else if (cmode == 3 && dm.MK == 28) { m->Ls = 32; m->cpl = 1; m->persist = true; }
-            else if ((cmode == 1 || cmode == 4) && dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = getenv("MMM_CTM_OCC28") ? std::max(3, std::min(4, atoi(getenv("MMM_CTM_OCC28")))) : 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
-            else if (cmode == 4 && dm.MK == 14) { m->Ls = 8; m->cpl = 2; m->lam_occ = 4; }                // 7 of 8 lanes x 2 coordinates
+            else if (dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
             if (m->cpl > 1) m->persist = true;
         }
-        // MMM_CTM_SPLIT="nuLanes:nuWaves:lamLanes:lamWaves" (sum K = 28): the two solves as two launches with their own layouts
-        if (const char* sp = getenv("MMM_CTM_SPLIT")) {
-            int a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            if ((dm.MK == 28 || dm.MK == 10) && sscanf(sp, "%d:%d:%d:%d", &a1, &a2, &a3, &a4) == 4 && a1 > 0) {
-                m->split = true; m->nu_Ls = a1; m->nu_cpl = (dm.MK + a1 - 1) / a1; m->nu_occ = a2; m->lam_occ = a4;
-                m->Ls = a3; m->cpl = (dm.MK + a3 - 1) / a3; m->persist = m->cpl > 1;
-            }
-        }
     }
-    if (m->big) { m->Ls = 64; m->cpl = kBigSlots; m->persist = false; m->split = false; }      // ctm_big.cuh: lane l holds coordinates l + 64 q
+    if (m->big) { m->Ls = 64; m->cpl = kBigSlots; m->persist = false; }      // ctm_big.cuh: lane l holds coordinates l + 64 q
     const int Gs = MMM_WAVE / m->Ls;
-    m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * 8));
+    m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ncu * 8));
     // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
     // slots work through (a finished slot takes the range's next document)
-    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ctx->num_cu * ((m->split || m->Ls == 16 || (m->Ls == 8 && m->cpl == 2)) ? m->lam_occ : (m->cpl > 1 ? 2 : 4))));
-    if (m->split) { const int Gn = MMM_WAVE / m->nu_Ls; m->grid_nu = std::max(1, std::min((D + m->waves_s * Gn - 1) / (m->waves_s * Gn), ctx->num_cu * m->nu_occ)); }
-    if (const char* sv = getenv("MMM_CTM_GRID_SOLVE")) m->grid_v = std::max(1, atoi(sv));
+    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ncu * (m->Ls == 16 ? m->lam_occ : 2)));
     // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks
     {
         const int tiles_per_block = std::max(1, (D + 32 * 1024 - 1) / (32 * 1024));
         m->grid_m = std::max(1, (D + 32 * tiles_per_block - 1) / (32 * tiles_per_block));
     }
-    if (const char* gm = getenv("MMM_CTM_GRID_M")) m->grid_m = std::max(1, atoi(gm));
+    if (ctx->tune.moment_blocks > 0) m->grid_m = ctx->tune.moment_blocks;
     const size_t MK = dm.MK, DMK = (size_t)D * MK, Rz = (size_t)R;
     m->nmom = 2 * dm.MK + dm.MK * dm.MK; m->nalpha = nalpha;
     m->s_stats = (size_t)m->nmom + dm.GT + 16;
@@ -2971,7 +2820,7 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
     A(Eeff, Rz * dm.GT); A(expEeff, Rz * dm.GT); A(expEeff_prev, Rz * dm.GT); A(phieff, Rz * dm.GT);
     A(partial, m->wide ? 1 : Rz * m->grid_e * dm.GT); A(mompart, Rz * m->grid_m * m->nmom); A(stats, Rz * m->s_stats);
     A(llpart, Rz * m->grid_s * M); A(llnum, Rz * m->s_llnum); A(Nm, (size_t)M); A(elbopart, (size_t)m->grid_s * 5 + 16 + 2 * MK);
-    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz); A(claim, 2 * Rz * 32);
+    A(nev_nu, Rz * D); A(nev_lam, Rz * D); A(status, Rz); A(active, Rz); A(npass, Rz);
     A(big_scratch, m->big ? Rz * 2 * (size_t)dm.MK * dm.MK : 1);
 #undef A
     hipStream_t st = ctx->stream;
@@ -3398,7 +3247,7 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : (m->tdense ? 2 : 0); out[5] = m->Ls; out[6] = m->cpl; out[7] = m->split ? m->nu_cpl : 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : (m->tdense ? 2 : 0); out[5] = m->Ls; out[6] = m->cpl; out[7] = 0;
     return MMM_OK;
 }
 

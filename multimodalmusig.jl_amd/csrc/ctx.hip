@@ -180,6 +180,31 @@ int mmm_comm_init_rank(mmm_ctx* ctx, int nranks, int rank, const char id_bytes[M
 
 int mmm_comm_nranks(const mmm_ctx* ctx) { return ctx ? ctx->nranks : 0; }
 
+void mmm_tuning_opts_default(mmm_tuning_opts* o)
+{
+    if (o) memset(o, 0, sizeof *o);
+}
+
+int mmm_ctx_set_tuning(mmm_ctx* ctx, const mmm_tuning_opts* opts)
+{
+    if (!ctx) return MMM_ERR_ARG;
+    mmm_tuning_opts t; mmm_tuning_opts_default(&t);
+    if (opts) t = *opts;
+    MMM_CHECK(ctx, t.lda_build >= MMM_BUILD_AUTO && t.lda_build <= MMM_BUILD_WIDE && t.ctm_build >= MMM_BUILD_AUTO && t.ctm_build <= MMM_BUILD_WIDE,
+              "mmm_ctx_set_tuning: unknown build (lda_build %d, ctm_build %d)", t.lda_build, t.ctm_build);
+    MMM_CHECK(ctx, t.geometry_cus >= 0 && t.grid_blocks >= 0 && t.waves_per_block >= 0 && t.moment_blocks >= 0 && t.resident_cap >= 0 && t.side_stream >= -1 && t.side_stream <= 1,
+              "mmm_ctx_set_tuning: negative size or side_stream outside -1..1");
+    ctx->tune = t;
+    return MMM_OK;
+}
+
+int mmm_ctx_get_tuning(const mmm_ctx* ctx, mmm_tuning_opts* out)
+{
+    if (!ctx || !out) return MMM_ERR_ARG;
+    *out = ctx->tune;
+    return MMM_OK;
+}
+
 void mmm_solver_opts_default(mmm_solver_opts* o)
 {
     if (!o) return;

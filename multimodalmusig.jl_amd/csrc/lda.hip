@@ -708,173 +708,6 @@ __global__ __launch_bounds__(512, 2) void k_lda_estep_dense(EstepArgs a, const i
     MMM_STAMP(7);
 }
 
-// The same data flow with 32-lane document groups in the term phase (round 3): a lane owns S3 = Vp / 32 term slots, HALF the statistics
-// registers of the 16-lane layout (S3 * KP doubles: 60 VGPRs at K = 10, V = 96, against 120), which is what lets a third wave per SIMD in
-// (one 12-wave block per CU, <= 168 VGPRs) -- the 16-lane build ran at 52 % VALU busy with two.  A wave step still covers four documents:
-// the Elntheta / a_k prologue in the 16-lane layout for all four at once (K + 1 lanes of 16 busy), then two term-phase sub-steps of two
-// documents each.  gamma_{t+1}: the lanes' partial sums meet in LDS, lane (k, part) of a document adds 16 of its 32 lanes' values, the
-// two parts meet through one DPP quad exchange.  The per-wave slabs exist only after the sweep and take the place of the gamma scratch,
-// as many waves at a time as fit there.
-template <int KP, int S3>
-__global__ __launch_bounds__(768, 1) void k_lda_estep_dense32(EstepArgs a, const int* __restrict__ cnt, const unsigned short* __restrict__ cnt16)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int Vp = 32 * S3;
-    const int t = a.t;
-    const int stop = a.ctl->stop;
-    const double* __restrict__ gam = a.gamma.s[t % 3];
-    double* __restrict__ gnext = a.gamma.s[(t + 1) % 3];
-    double* __restrict__ Eln = a.Elntheta.s[t % 3];
-    const double* __restrict__ eB = a.expElnbeta.s[(t + 2) % 3];
-    const int K = a.c.K, D = a.c.D, V = a.c.V;
-    const int NW = blockDim.x >> 6;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g16 = lane >> 4, l16 = lane & 15;      // prologue: 4 documents x 16 lanes
-    const int h = lane >> 5, l32 = lane & 31;        // term phase: 2 documents x 32 lanes
-    double* sT = smem;                                   // [Vp][KP] exp(Elnbeta_{t-1}), term-major; rows v >= V hold 1 (their counts are 0)
-    double* sA = sT + (size_t)Vp * KP;                   // [NW][4][KP] a_k of the wave step's four documents
-    double* sR = sA + (size_t)NW * 4 * KP;               // [NW][64][KP] gamma sums, lane-major; after the sweep: slabs [fit][K][V]
-    double* myA = sA + (size_t)wid * 4 * KP;
-    double* myR = sR + (size_t)wid * MMM_WAVE * KP;
-    const int stride = gridDim.x * NW * 4;
-    int base = (blockIdx.x * NW + wid) * 4;
-
-    double gk = (base + g16 < D && l16 < K) ? gam[(size_t)(base + g16) * K + l16] : (l16 < K ? 1.0 : 0.0);
-    int c[2][S3];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        const int dd = base + 2 * sub + h;
-#pragma unroll
-        for (int q = 0; q < S3; ++q) c[sub][q] = dd < D ? (cnt16 ? (int)cnt16[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)] : cnt[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)]) : 0;
-    }
-    for (int i = tid; i < Vp * KP; i += blockDim.x) {
-        const int v = i / KP, k = i % KP;
-        sT[i] = (k < K) ? (v < V ? eB[(size_t)k * V + v] : 1.0) : 0.0;
-    }
-    double st[S3][KP];
-#pragma unroll
-    for (int q = 0; q < S3; ++q)
-#pragma unroll
-        for (int k = 0; k < KP; ++k) st[q][k] = 0.0;
-    bool first = true;
-    for (;;) {
-        // ---- the next step's gamma rows and counts are requested before this step computes
-        const bool more = base + stride < D;
-        const int bn = base + stride;
-        double gkn = l16 < K ? 1.0 : 0.0;
-        if (more && bn + g16 < D && l16 < K) gkn = gam[(size_t)(bn + g16) * K + l16];
-        int cn[2][S3];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int dd = bn + 2 * sub + h;
-#pragma unroll
-            for (int q = 0; q < S3; ++q) cn[sub][q] = (more && dd < D) ? (cnt16 ? (int)cnt16[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)] : cnt[(size_t)dd * a.c.Vp + row_slot(q * 32 + l32, a.c.Vp >> 4)]) : 0;
-        }
-        // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k): four documents, 16 lanes each
-        const double S = group_sum<16>(gk);
-        const double ps = dev_digamma_pos(l16 < K ? gk : S);        // lane K of the group holds psi(S)
-        const double psS = __shfl(ps, g16 * 16 + K, MMM_WAVE);
-        const double el = ps - psS;
-        if (l16 < KP) myA[g16 * KP + l16] = (l16 < K) ? ar_exp(el) : 0.0;
-        if (first) {
-            if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
-            __syncthreads();
-            first = false;
-        } else lds_wave_sync();
-        if (base + g16 < D && l16 < K) Eln[(size_t)(base + g16) * K + l16] = el;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int dd = base + 2 * sub + h;
-            const double* Arow = myA + (2 * sub + h) * KP;
-            double acc[KP];
-#pragma unroll
-            for (int k = 0; k < KP; ++k) acc[k] = 0.0;
-            // ---- phi_kv n_v (LDA.jl:92-106) for the lane's S3 terms (a_k comes from LDS in every slot: a broadcast read, and 2 KP registers fewer)
-#pragma unroll
-            for (int q = 0; q < S3; ++q) {
-                const double* tb = sT + (size_t)(q * 32 + l32) * KP;
-                double b[KP], s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < KP; ++k) b[k] = Arow[k] * tb[k];
-#pragma unroll
-                for (int k = 0; k + 1 < KP; k += 2) { s0 += b[k]; s1 += b[k + 1]; }
-                if (KP & 1) s0 += b[KP - 1];
-                // a slot without mass must not see 0 x rcp(0) = NaN (see k_lda_estep_dense)
-                const double r = (double)c[sub][q] * dev_rcp(dev_max_raw(s0 + s1, 2.2250738585072014e-308));
-#pragma unroll
-                for (int k = 0; k < KP; ++k) { acc[k] = fma(b[k], r, acc[k]); st[q][k] = fma(b[k], r, st[q][k]); }
-#pragma unroll
-                for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(st[q][k]));
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- gamma_{t+1} = alpha + sum_v phi_kv n_v: lane (kk, part) adds 16 lanes' values of topic kk, the two parts meet by DPP
-#pragma unroll
-            for (int k = 0; k < KP; ++k) myR[(size_t)lane * KP + k] = acc[k];
-            lds_wave_sync();
-            {
-                const int kk = l32 >> 1, part = l32 & 1;
-                double tot = 0.0;
-                if (kk < K) {
-                    const double* col = myR + (size_t)(h * 32 + part * 16) * KP + kk;
-                    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 16; j += 4) { r0 += col[j * KP]; r1 += col[(j + 1) * KP]; r2 += col[(j + 2) * KP]; r3 += col[(j + 3) * KP]; }
-                    tot = (r0 + r1) + (r2 + r3);
-                }
-                tot += dpp_mov_f64<0xB1>(tot);          // quad_perm [1,0,3,2]: the other part
-                if (kk < K && part == 0 && dd < D) gnext[(size_t)dd * K + kk] = a.c.alpha + tot;
-            }
-            lds_wave_sync();
-        }
-        base += stride;
-        if (base >= D) break;
-        gk = gkn;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int q = 0; q < S3; ++q) c[sub][q] = cn[sub][q];
-    }
-    // ---- the lanes' statistics -> per-wave slabs [K][V] in the gamma scratch, `fit` waves at a time; block sums in wave order
-    __syncthreads();
-    const int KV = K * V;
-    const int fit = max(1, (NW * MMM_WAVE * KP) / KV);
-    double accum[4] = {0.0, 0.0, 0.0, 0.0};              // K V <= 4 blockDim (checked by the host)
-    for (int w0 = 0; w0 < NW; w0 += fit) {
-        if (wid >= w0 && wid < w0 + fit) {
-            double* slab = sR + (size_t)(wid - w0) * KV;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (h == hh) {
-#pragma unroll
-                    for (int q = 0; q < S3; ++q) {
-                        const int v = q * 32 + l32;
-                        if (v < V) {
-#pragma unroll
-                            for (int k = 0; k < KP; ++k) if (k < K) slab[(size_t)k * V + v] = (hh ? slab[(size_t)k * V + v] : 0.0) + st[q][k];
-                        }
-                    }
-                }
-                lds_wave_sync();
-            }
-        }
-        __syncthreads();
-        const int nw = min(fit, NW - w0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + j * blockDim.x;
-            if (i < KV) for (int w = 0; w < nw; ++w) accum[j] += sR[(size_t)w * KV + i];
-        }
-        __syncthreads();
-    }
-    double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + j * blockDim.x;
-        if (i < KV) out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = accum[j];
-    }
-}
-
 // ---- slab reduction + log-likelihood / stopping rule ------------------------------------------------------------
 struct ReduceArgs {
     const double* partial; const double* llpart; int nslab; int VK;
@@ -2272,6 +2105,7 @@ __global__ void k_doc_counts(LdaDev c, double* out)
 // ---------------------------------------------------------------------------------------------------------
 struct mmm_lda {
     mmm_ctx* ctx = nullptr;
+    mmm_tuning_opts tune{};      // the caller's choices at create time (mmm_ctx_set_tuning)
     int D = 0, V = 0, K = 0, KP = 0, L = 16;
     int64_t nnz = 0;
     double alpha = 0, eta = 0;
@@ -2280,7 +2114,6 @@ struct mmm_lda {
     DevBuf<unsigned short> cnt16;   // the rows as 16-bit counts, when every count fits (then cnt_dense is not built)
     DevBuf<int> cnt_dense;      // dense rows [D][16 SL] of counts (k_lda_estep_dense), or empty
     bool dense = false; int SL = 0, SLs = 0; size_t lds_d = 0; bool attr_d = false;     // SL: term slots per lane of a 16-lane group; SLs: as stored (LdaDev::Vp / 16)
-    bool dense32 = false;       // ... its 32-lane build (k_lda_estep_dense32: 12-wave blocks, three waves per SIMD)
     bool drows = false;         // cnt_dense exists (dense-row E-step build, or rows for the single-step build and the ll blocks)
     DevBuf<double> lambda[3], Elnbeta[3], expElnbeta[3], beta[3], gamma[3], Elntheta[3];
     DevBuf<double> theta, phi;
@@ -2357,16 +2190,17 @@ int set_lds(mmm_ctx* ctx, Kern kern, size_t lds)
 
 // How many blocks of a launch whose blocks WAIT for each other (cells) can be resident at once: occupancy x CUs.  Launches of
 // k_lda_reduce_ll_mstep / k_lda_reduce_ll never exceed it, so every block a waiting block waits for is on the chip -- the waits
-// cannot deadlock whatever order the dispatcher picks.  MMM_LDA_RESIDENT_CAP lowers the figure (tests).
+// cannot deadlock whatever order the dispatcher picks.  mmm_tuning_opts.resident_cap lowers the figure (tests).
 template <class Kern>
-int residency_cap(mmm_ctx* ctx, Kern kern, size_t lds, int* cap)
+int residency_cap(mmm_lda* m, Kern kern, size_t lds, int* cap)
 {
+    mmm_ctx* ctx = m->ctx;
     int nb = 0;
     MMM_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 1024, lds));
     // the blocks of such a launch wait for each other, so every one of them must be on the chip at once.  nb x #CU holds when the device is
     // ours alone; a few CUs are left out of the count so that a short kernel of another stream or process does not turn a wait into a timeout
     *cap = nb * std::max(1, ctx->num_cu - 4);
-    if (const char* e = getenv("MMM_LDA_RESIDENT_CAP")) *cap = std::min(*cap, std::max(0, atoi(e)));
+    if (m->tune.resident_cap > 0) *cap = std::min(*cap, m->tune.resident_cap);
     return MMM_OK;
 }
 
@@ -2408,18 +2242,6 @@ int go_dense(mmm_lda* m, const EstepArgs& a)
     } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no dense-row build for KP=%d SL=%d", KPV, SLV);
 }
 
-template <int KPV, int S3V>
-int go_dense32(mmm_lda* m, const EstepArgs& a)
-{
-    if constexpr (KPV * S3V <= 40) {
-        mmm_ctx* ctx = m->ctx;
-        auto k = k_lda_estep_dense32<KPV, S3V>;
-        if (!m->attr_d) { int rc = set_lds(ctx, k, m->lds_d); if (rc) return rc; m->attr_d = true; }
-        hipLaunchKernelGGL(k, dim3(m->grid_e), dim3(m->waves_e * MMM_WAVE), m->lds_d, ctx->stream, a, (const int*)m->cnt_dense.p, (const unsigned short*)m->cnt16.p);
-        return MMM_OK;
-    } else return mmm_fail(m->ctx, MMM_ERR_UNSUPPORTED, "LDA: no 32-lane dense-row build for KP=%d S3=%d", KPV, S3V);
-}
-
 // term slots per lane of the dense-row build that covers V terms (0: none)
 int dense_slots(int V) { return V <= 32 ? 2 : (V <= 48 ? 3 : (V <= 96 ? 6 : (V <= 128 ? 8 : 0))); }
 
@@ -2427,20 +2249,6 @@ int launch_estep(mmm_lda* m, const EstepArgs& a)
 {
     mmm_ctx* ctx = m->ctx;
     int rc = MMM_OK;
-    if (m->dense && m->dense32 && !a.do_ll) {
-        MMM_KP_SWITCH(m, {
-            if constexpr (KPV >= 4 && KPV <= 16) {
-                switch (m->SL) {
-                    case 2: rc = go_dense32<KPV, 1>(m, a); break;
-                    case 6: rc = go_dense32<KPV, 3>(m, a); break;
-                    default: rc = go_dense32<KPV, 4>(m, a); break;
-                }
-            }
-        })
-        if (rc) return rc;
-        MMM_LAUNCH_CHECK(ctx);
-        return MMM_OK;
-    }
     if (m->dense && !a.do_ll) {
         MMM_KP_SWITCH(m, {
             if constexpr (KPV >= 4 && KPV <= 16) {
@@ -2638,19 +2446,17 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         const int do_ll = (m->ll_pending || it > 0) ? 1 : 0;
         // Where the ll of pass t-1 is evaluated: in extra blocks of the reduce launch (the reduction occupies 60 CUs for ~6 us,
         // the ll sweep fits beside it and the E-step kernel sheds 43 % of its chunk-loop instructions and half its table
-        // reads).  MMM_LDA_LL_IN_ESTEP=1 forces the older placement (A/B).
-        static const bool ll_estep_env = getenv("MMM_LDA_LL_IN_ESTEP") != nullptr;
+        // reads).
         ReduceArgs r{m->partial.p, m->llpart.p, m->grid_e, VK, m->stats[t & 1].p, m->ctl.p, t, m->Nglobal, tol, m->ll_hist.p, do_ll, conv_base, 1};
         r.p2p = 0; r.p2p_seq = 0;
-        static const bool fold = getenv("MMM_P2P_UNFOLDED") == nullptr;
+        const bool fold = !mmm_off(m->tune, MMM_OFF_P2P_FOLDED);
         const int Vp = (m->V + 15) & ~15;
         if (fold && !m->ilda && !m->wide && mmm_p2p_begin(ctx, (size_t)Vp * m->K + 1, &r.px, &r.p2p_seq)) r.p2p = 1;      // (k_ilda_mstep does not receive)
-        const bool ll_in_k2 = !ll_estep_env && !m->wide;
+        const bool ll_in_k2 = !m->wide;
         const bool via_cells = ll_in_k2 && !r.p2p && mmm_comm_active(ctx);      // RCCL transport
         // V <= 256, plain LDA, one GPU or mailboxes: reduction, ll sweep and M-step in ONE launch (k_lda_reduce_ll_mstep), statistics
-        // rows padded to a multiple of 16; MMM_LDA_MERGE=0 keeps the split kernels (A/B)
-        static const int merge_env = getenv("MMM_LDA_MERGE") ? atoi(getenv("MMM_LDA_MERGE")) : -1;
-        bool merged = merge_env != 0 && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
+        // rows padded to a multiple of 16; MMM_OFF_LDA_MERGED keeps the split kernels (A/B, tests)
+        bool merged = !mmm_off(m->tune, MMM_OFF_LDA_MERGED) && ll_in_k2 && (r.p2p || !mmm_comm_active(ctx)) && !m->wide && m->V <= 256 &&
                       (!m->ilda || (m->ids.SJ <= 16 && !mmm_comm_active(ctx)));
         const size_t lds_red = sizeof(double) * ((size_t)m->KP * m->V + 64 * (size_t)m->KP + MMM_LOGTAB_N);      // beta table | theta rows | log table
         int cap = 0;       // residency of the launch whose blocks wait for each other
@@ -2660,7 +2466,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
                 MMM_KP_SWITCH(m, {
                     auto k = m->ilda ? k_lda_reduce_ll_mstep<KPV, false, true> : (r.p2p ? k_lda_reduce_ll_mstep<KPV, true, false> : k_lda_reduce_ll_mstep<KPV, false, false>);
                     if (!m->attr_mm[ai]) { if ((rc = set_lds(ctx, k, lds_red))) return rc; m->attr_mm[ai] = true; }
-                    if ((rc = residency_cap(ctx, k, lds_red, &m->cap_mm[ai]))) return rc;
+                    if ((rc = residency_cap(m, k, lds_red, &m->cap_mm[ai]))) return rc;
                 })
             }
             cap = m->cap_mm[ai];
@@ -2677,7 +2483,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
                 MMM_KP_SWITCH(m, {
                     auto k = k_lda_reduce_ll<KPV>;
                     if (!m->attr_m) { if ((rc = set_lds(ctx, k, lds_red))) return rc; m->attr_m = true; }
-                    if ((rc = residency_cap(ctx, k, lds_red, &m->cap_m))) return rc;
+                    if ((rc = residency_cap(m, k, lds_red, &m->cap_m))) return rc;
                 })
             }
             cap = m->cap_m;
@@ -2687,9 +2493,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             if (cap - nred_ < 1) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: the reduce launch cannot hold its %d reduce blocks and one ll block at once (%d resident)", nred_, cap);
             r.n_ll = std::min(r.n_ll, cap - nred_);       // the ll blocks stride over the documents: fewer blocks, same sums per block id
         }
-        static const bool rows_env = getenv("MMM_LDA_ROWS") == nullptr || atoi(getenv("MMM_LDA_ROWS")) != 0;
         LdaDev edev = m->dev();
-        if (!rows_env) { edev.ell = nullptr; edev.dense = nullptr; edev.dense16 = nullptr; }
+        if (mmm_off(m->tune, MMM_OFF_LDA_PADDED_ROWS)) { edev.ell = nullptr; edev.dense = nullptr; edev.dense16 = nullptr; }
         EstepArgs a{edev, m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
@@ -2704,8 +2509,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (merged) {
             const size_t lds = lds_red;
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred, 0};
-            static const bool join_env = getenv("MMM_LDA_LL_JOIN") == nullptr || atoi(getenv("MMM_LDA_LL_JOIN")) != 0;
-            ms.ll_join = (join_env && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + nred - 1 <= 512) ? 1 : 0;
+            ms.ll_join = (!mmm_off(m->tune, MMM_OFF_LDA_LL_JOIN) && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + nred - 1 <= 512) ? 1 : 0;
             const int c3 = t % 3;
             IldaMerge im{};
             if (m->ilda) im = IldaMerge{m->ids, m->ilam[c3].p, m->iEln[c3].p, m->ibeta[c3].p, m->fcells.p};
@@ -2889,6 +2693,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     }
     const int L = (K <= 15) ? 16 : (K <= 31 ? 32 : 64);
     const int G = MMM_WAVE / L;
+    const int ncu = mmm_geo_cus(ctx);      // the CU count the geometry (and so the association of the cross-document sums) is derived from
     // waves per block of the fused kernel: as many as fit 160 KiB of LDS next to the two tables, at most 8
     const size_t tabB = (size_t)KP * V * sizeof(double);
     // Small corpora (every document resident at once): 6-wave blocks, two per CU, one step per wave with the <= 168-VGPR
@@ -2902,10 +2707,10 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     bool dense = false, drows = false;
     const int SL = dense_slots(V);
     {
-        const char* de = getenv("MMM_LDA_DENSE");
-        const int dmode = de ? atoi(de) : -1;
-        static const bool drows_env = getenv("MMM_LDA_DROWS") == nullptr || atoi(getenv("MMM_LDA_DROWS")) != 0;
-        const bool rshape = SL > 0 && L == 16 && D > 0 && !getenv("MMM_LDA_WIDE");          // rows of counts make sense
+        const int build = ctx->tune.lda_build;
+        const int dmode = build == MMM_BUILD_DENSE ? 1 : (build == MMM_BUILD_AUTO ? -1 : 0);
+        const bool drows_env = !mmm_off(ctx->tune, MMM_OFF_LDA_COUNT_ROWS);
+        const bool rshape = SL > 0 && L == 16 && D > 0 && build != MMM_BUILD_WIDE;          // rows of counts make sense
         const bool shape = rshape && KP >= 4 && KP * SL <= 64;                               // ... and the dense-row E-step build exists
         const bool dense_enough = 2 * nnz >= (int64_t)D * V;
         bool dup = false;
@@ -2917,59 +2722,44 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         // measured on MI355X (K = 10, V = 96; E-step launch, dense rows vs the CSR sweep): 10k documents 12.4 vs 10.9 us (the single-step build),
         // 15k 12.8 vs 14.1, 20k 16.7 vs 19.3, 40k 20.2 vs 27.7, 640k 190 vs 380 -- every corpus beyond the single-step build's reach
         // (profiles/experiments/r03_sweeps/dense_crossover.sh; round 2's build only paid from 49k documents: its epilogue cost 19 us)
-        const bool big = D > 12 * G * ctx->num_cu;
+        const bool big = D > 12 * G * ncu;
         const bool off32 = (int64_t)D * K * 8 < ((int64_t)1 << 32) && (int64_t)D * 16 * (SL + 1) * 4 < ((int64_t)1 << 32);   // the build's 32-bit byte offsets
         dense = shape && !dup && off32 && dmode != 0 && (dmode > 0 || (big && dense_enough));
         drows = drows_env && rshape && !dup && dense_enough;
     }
-    const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ctx->num_cu) && !getenv("MMM_LDA_GRID") &&
-                       !getenv("MMM_LDA_WAVES");
+    const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ncu) && ctx->tune.grid_blocks == 0 &&
+                       ctx->tune.waves_per_block == 0;
     // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
-    // per SIMD = shorter step); MMM_LDA_SWAVES overrides for experiments
-    int swaves = std::max(4, std::min(12, (D + G * ctx->num_cu - 1) / (G * ctx->num_cu)));
-    if (const char* sw = getenv("MMM_LDA_SWAVES")) swaves = std::max(4, std::min(12, atoi(sw)));
+    // per SIMD = shorter step)
+    const int swaves = std::max(4, std::min(12, (D + G * ncu - 1) / (G * ncu)));
     int waves = small ? swaves : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
     // tables + one slab beyond LDS: the wide path (k_lda_estep_wide).  It also takes K > 24: the LDS kernel's 32-topic build
-    // spills (10k x 96-term documents, K = 32: 264 us per iteration against 189).  MMM_LDA_WIDE=1 / 0 forces / avoids it (tests, A/B).
-    const char* wide_env = getenv("MMM_LDA_WIDE");
-    const bool wide = lds_for(waves) > 160 * 1024 || KP > 32 || (wide_env ? atoi(wide_env) != 0 : KP >= 32);
+    // spills (10k x 96-term documents, K = 32: 264 us per iteration against 189).  lda_build = MMM_BUILD_WIDE forces it, MMM_BUILD_SPARSE /
+    // _DENSE avoid it where the LDS kernels can run (tests, A/B).
+    const bool wide = lds_for(waves) > 160 * 1024 || KP > 32 || (ctx->tune.lda_build == MMM_BUILD_WIDE) || (ctx->tune.lda_build == MMM_BUILD_AUTO && KP >= 32);
 
     MMM_HIP(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<mmm_lda> guard(new mmm_lda());      // every early return below (MMM_HIP, ...) destroys the model and its buffers
     mmm_lda* m = guard.get();
+    m->tune = ctx->tune;
     m->ctx = ctx; m->D = D; m->V = V; m->K = K; m->KP = KP; m->L = L; m->nnz = nnz; m->alpha = alpha; m->eta = eta;
     m->waves_e = waves; m->lds_e = wide ? 0 : lds_for(waves); m->lds_tab = tabB; m->wide = wide;
     m->dense = dense && !wide; m->SL = SL; m->drows = (dense || drows) && !wide;
-    if (const char* s = wide ? nullptr : getenv("MMM_LDA_WAVES")) { int w = atoi(s); if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
+    if (!wide && ctx->tune.waves_per_block > 0) { const int w = ctx->tune.waves_per_block; if (w >= 1 && w <= (small ? kMaxWavesE : 8) && lds_for(w) <= 160 * 1024) { m->waves_e = w; m->lds_e = lds_for(w); } }
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
     const int blocks_per_cu = wide ? 8 : std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
-    m->single_step = !wide && small && (int64_t)m->waves_e * G * ctx->num_cu >= D;
-    m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ctx->num_cu * blocks_per_cu));
-    if (wide) m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * blocks_per_cu));     // wave per document
-    if (const char* s = getenv("MMM_LDA_GRID")) m->grid_e = std::max(1, atoi(s));
+    m->single_step = !wide && small && (int64_t)m->waves_e * G * ncu >= D;
+    m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ncu * blocks_per_cu));
+    if (wide) m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ncu * blocks_per_cu));     // wave per document
+    if (ctx->tune.grid_blocks > 0) m->grid_e = ctx->tune.grid_blocks;
     if ((int64_t)m->grid_e * docs_per_block < D) m->single_step = false;
     if (m->dense)      // [16 SL][KP] table | [waves][K][V] slabs | [waves][G][KP] a_k | [waves][64][KP] gamma sums
         m->lds_d = sizeof(double) * ((size_t)16 * SL * KP + (size_t)m->waves_e * 16 * SL * KP + (size_t)m->waves_e * G * KP + (size_t)m->waves_e * MMM_WAVE * KP);
-    {   // the 32-lane build: slots per lane even in the 16-lane count (rows of 32 S3 counts), sum K x slots within its registers, one
-        // 12-wave block per CU.  LDS: [32 S3][KP] table | [12][4][KP] a_k | [12][64][KP] gamma sums (later: slabs).  MMM_LDA_DENSE32=0: the 16-lane build
-        // Measured (round 3, K = 10, V = 96, 16-bit rows): 160k documents 90.0 vs 80.9 us, 640k 337 vs 280 us -- SLOWER than the 16-lane
-        // build: 168 VGPRs with 42 spilled, and the term phase (2 documents per sub-step) pays its LDS round trips twice per wave step.
-        // Off unless MMM_LDA_DENSE32=1 (tests keep it alive).
-        const bool d32_env = getenv("MMM_LDA_DENSE32") != nullptr && atoi(getenv("MMM_LDA_DENSE32")) != 0;
-        const int S3 = SL / 2;
-        if (m->dense && d32_env && (SL == 2 || SL == 6 || SL == 8) && KP >= 4 && KP <= 16 && KP * S3 <= 40 && K * V <= 4 * 768 && K * V <= 12 * 64 * KP &&
-            !getenv("MMM_LDA_WAVES") && !getenv("MMM_LDA_GRID")) {
-            m->dense32 = true;
-            m->waves_e = 12;
-            m->lds_d = sizeof(double) * ((size_t)32 * S3 * KP + (size_t)12 * 4 * KP + (size_t)12 * MMM_WAVE * KP);
-            m->grid_e = std::max(1, std::min((D + 47) / 48, ctx->num_cu));
-        }
-    }
-    if (m->dense && m->lds_d > 160 * 1024) { m->dense = false; m->dense32 = false; m->drows = drows && !wide; }      // no dense-row build: rows only if the corpus is dense enough
-    m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ctx->num_cu * 4));
+    if (m->dense && m->lds_d > 160 * 1024) { m->dense = false; m->drows = drows && !wide; }      // no dense-row build: rows only if the corpus is dense enough
+    m->grid_s = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ncu * 4));
     const int grid_max = std::max(m->grid_e, m->grid_s);
 #define A(buf, n) do { hipError_t e_ = m->buf.alloc(n); if (e_ != hipSuccess) { int rc = mmm_fail(ctx, MMM_ERR_HIP, "hipMalloc(" #buf "): %s", hipGetErrorString(e_)); return rc; } } while (0)
     A(doc_ptr, (size_t)D + 1); A(tc, (size_t)nnz);
@@ -3006,7 +2796,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         m->stats_waves = 1;
         while (m->stats_waves < 8 && avg / (m->stats_waves * 2) >= 128) m->stats_waves *= 2;
     }
-    static const bool rows16_env = getenv("MMM_LDA_ROWS16") == nullptr || atoi(getenv("MMM_LDA_ROWS16")) != 0;
+    const bool rows16_env = !mmm_off(ctx->tune, MMM_OFF_LDA_ROWS16);
     int maxcount = 0;
     for (int64_t e = 0; e < nnz; ++e) maxcount = std::max(maxcount, count[e]);
     if (m->drows && rows16_env && maxcount < 65536) {
@@ -3303,7 +3093,7 @@ int mmm_lda_geometry(const mmm_lda* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
     out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->single_step ? 1 : 0; out[4] = m->wide ? 1 : 0;
-    out[5] = m->dense ? (m->dense32 ? 2 : 1) : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
+    out[5] = m->dense ? 1 : 0; out[6] = m->dense ? m->SL : 0; out[7] = m->KP;
     return MMM_OK;
 }
 

@@ -26,6 +26,7 @@ struct mmm_ctx {
     mmm_p2p* p2p = nullptr;       // mailbox + peer mappings (NULL: not set up)
     bool p2p_on = false;          // all-reduces of <= mailbox capacity go through the p2p kernel
     int num_cu = 256;
+    mmm_tuning_opts tune{};       // the caller's choices (mmm_ctx_set_tuning); a handle copies them when it is created
     std::string err;
     char arch[64] = {0};
     // HIP-event spans around the dominant kernel (mmm_ctx_profile_begin/end)
@@ -52,6 +53,10 @@ struct mmm_ctx {
     std::atomic<bool> closing{false};         // mmm_ctx_destroy has run
     std::atomic<bool> closed_multi{false};    // ... on a context that had a communicator: surviving models must not be used any more
 };
+
+// CU count the launch geometry is derived from: the device's, or the pinned one (mmm_tuning_opts.geometry_cus)
+inline int mmm_geo_cus(const mmm_ctx* ctx) { return ctx->tune.geometry_cus > 0 ? ctx->tune.geometry_cus : ctx->num_cu; }
+inline bool mmm_off(const mmm_tuning_opts& t, unsigned bit) { return (t.disable & bit) != 0; }
 
 void mmm_ctx_model_created(mmm_ctx* ctx);
 void mmm_ctx_model_destroyed(mmm_ctx* ctx);      // may delete ctx

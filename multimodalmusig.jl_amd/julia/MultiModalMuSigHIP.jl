@@ -42,6 +42,20 @@ mutable struct Context
     end
 end
 
+# mmm_tuning_opts (include/mmmusig.h): the caller's choices for the handles created on a context from now on -- E-step build
+# (0 auto, 1 sparse, 2 dense, 3 wide), a pinned launch geometry (`geometry_cus`: same bits on any gfx950 device), the side stream, ...
+struct TuningOpts
+    lda_build::Cint; ctm_build::Cint; geometry_cus::Cint; grid_blocks::Cint; waves_per_block::Cint; moment_blocks::Cint
+    side_stream::Cint; resident_cap::Cint; disable::Cuint; reserved::NTuple{7,Cint}
+end
+function set_tuning!(ctx::Context; lda_build=0, ctm_build=0, geometry_cus=0, grid_blocks=0, waves_per_block=0, moment_blocks=0, side_stream=0,
+                     resident_cap=0, disable=0)
+    t = Ref(TuningOpts(lda_build, ctm_build, geometry_cus, grid_blocks, waves_per_block, moment_blocks, side_stream, resident_cap, disable, ntuple(i -> Cint(0), 7)))
+    rc = ccall((:mmm_ctx_set_tuning, LIB), Cint, (Ptr{Cvoid}, Ref{TuningOpts}), ctx.h, t)
+    rc == 0 || error("mmm_ctx_set_tuning: " * unsafe_string(ccall((:mmm_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.h)))
+    return ctx
+end
+
 const DEFAULT_CTX = Ref{Union{Nothing,Context}}(nothing)
 default_context() = (DEFAULT_CTX[] === nothing && (DEFAULT_CTX[] = Context(0)); DEFAULT_CTX[])
 

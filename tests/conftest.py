@@ -32,3 +32,13 @@ def mmm():
     """The product package (directory name has a dot, so it is loaded through the root shim)."""
     import mmm_pkg
     return mmm_pkg.load()
+
+
+@pytest.fixture
+def tuning(mmm):
+    """`tuning(lda_build="dense", grid_blocks=3, disable=("lda_rows16",), ...)`: mmm_ctx_set_tuning on the default context -- the caller's
+    choices for the handles created from now on (include/mmmusig.h mmm_tuning_opts; they used to be environment variables read once per
+    process).  Back to the defaults when the test ends; `tuning()` resets in between."""
+    ctx = mmm.default_context()
+    yield ctx.set_tuning
+    ctx.set_tuning()

@@ -37,3 +37,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.lower().replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_run_time_choices_travel_in_the_abi_not_in_the_environment():
+    """a plain C struct of options across the ABI.  The library may read at most a handful of environment variables,
+    all about the transport set-up; everything a caller chooses per handle is in mmm_tuning_opts."""
+    csrc = os.path.join(ROOT, "multimodalmusig.jl_amd", "csrc")
+    seen = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h", ".cuh")):
+            seen |= set(re.findall(r'getenv\("(MMM_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    assert seen == {"MMM_P2P", "MMM_P2P_TIMEOUT_S", "MMM_P2P_ONE_RANK", "MMM_FORCE_RCCL"}, sorted(seen)
+    hdr = open(os.path.join(ROOT, "include", "mmmusig.h")).read()
+    for field in ("lda_build", "ctm_build", "geometry_cus", "grid_blocks", "side_stream", "disable"):
+        assert re.search(r"\b%s;" % field, hdr), field

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+import np_ref
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -133,9 +135,13 @@ def test_restart_driver_on_brca(mmm):
     print("restart driver: stage-1 ll per restart\n%s\nbest per modality %s, stage-2 ll %s" % (all_ll, opt_ll, model.ll))
 
 
-def test_against_committed_golden_trajectories(mmm):
+def test_against_committed_golden_trajectories(mmm, tuning):
     """The same two configurations against tests/golden/oracle_trajectories.json: a committed target that needs no oracle
-    build on the GPU box (generated by tests/golden/make_trajectories.py from the CPU oracle)."""
+    build on the GPU box (generated by tests/golden/make_trajectories.py from the CPU oracle).  The bits of a CTM fit follow the launch
+    geometry (it fixes the association of the sums across documents), and the geometry follows the CU count: the handle is created with
+    mmm_tuning_opts.geometry_cus = 256 -- the geometry the fixture was generated for -- so the comparison holds on any gfx950 device or
+    partition mode, not only on a 256-CU one."""
+    tuning(geometry_cus=256)
     import json
     traj = json.load(open(os.path.join(GOLD, "oracle_trajectories.json")))
     samples, snv, sv = _tables(mmm)
@@ -161,7 +167,7 @@ def test_against_committed_golden_trajectories(mmm):
     # ll / ELBO sums (which are outside the feedback loop)
     t = traj["config3_mmctm_77_device_order"]
     geo = c.geometry()
-    assert all(geo[k] == t["geometry"][k] for k in ("L", "grid_e", "waves_e", "grid_m")), geo
+    assert all(geo[k] == t["geometry"][k] for k in ("L", "grid_e", "waves_e", "grid_m")), geo      # what geometry_cus = 256 pins
     np.testing.assert_allclose(llc, t["ll"], rtol=1e-11)
     assert c.elbo == pytest.approx(t["elbo"], rel=1e-10)
     assert np.array_equal(c.μ, t["mu"]) and np.array_equal(np.diag(c.invΣ), t["invSigma_diag"])
@@ -170,3 +176,35 @@ def test_against_committed_golden_trajectories(mmm):
     assert c.lam_matrix().sum() == pytest.approx(t["lambda_sum"], rel=1e-13) and c.nu_matrix().sum() == pytest.approx(t["nu_sum"], rel=1e-13)
     st = c.solver_stats(per_doc=True)
     assert np.array_equal(st["per_doc_nu"], t["nev_nu_last_pass"]) and np.array_equal(st["per_doc_lambda"], t["nev_lambda_last_pass"])
+
+
+def test_two_handles_of_one_process_with_different_tuning(mmm, oracle, tuning):
+    """mmm_tuning_opts are captured per handle at create time (they used to be environment variables read once per process): two LDA
+    handles and two MMCTM handles of ONE process, created under different options, each give the oracle's fit -- and a pinned geometry
+    (geometry_cus) gives the CTM's bits of a device of that size: 64 and 256 pretended CUs associate the cross-document sums differently."""
+    X, lam0 = np_ref.synth_lda(900, 96, 10, seed=8, mean_n=700)
+    tuning(lda_build="dense")
+    a = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
+    tuning(lda_build="sparse", grid_blocks=5)
+    b = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
+    tuning()
+    assert a.geometry()["dense"] == 1 and b.geometry()["dense"] == 0 and b.geometry()["grid_e"] == 5
+    o = oracle.LdaOracle(10, 0.1, 0.1, X, V=96, lambda0=lam0)
+    ll_o = o.fit(maxiter=10, tol=0.0)
+    for g in (b, a):                                        # (used in the other order than created)
+        np.testing.assert_allclose(mmm.fit(g, maxiter=10, tol=0.0, verbose=False), ll_o, rtol=1e-9)
+        assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
+    Xm, g0 = np_ref.synth_mm(700, [96, 38], [6, 4], seed=12, means=[900, 120])
+    fits = {}
+    for cus in (64, 256):
+        tuning(geometry_cus=cus, ctm_build="dense" if cus == 64 else "sparse")
+        c = mmm.MMCTM([6, 4], [0.1, 0.1], [96, 38], Xm, γ0=g0)
+        tuning()
+        geo = c.geometry()
+        oc = oracle.CtmOracle([6, 4], [0.1, 0.1], Xm, V=[96, 38], gamma0=np.concatenate([x.ravel() for x in g0]), geometry=geo)
+        ll = mmm.fit(c, maxiter=5, tol=0.0, verbose=False)
+        llo = oc.fit(maxiter=5, tol=0.0)
+        assert np.array_equal(c.lam_matrix().ravel(), oc.lam) and np.array_equal(c._get("gamma"), oc.gamma), "CTM state differs from the order-matched oracle at geometry_cus = %d" % cus
+        np.testing.assert_allclose(ll, llo, rtol=1e-10)
+        fits[cus] = (geo, c._get("gamma").copy())
+    assert fits[64][0]["tdense"] == 1 and fits[256][0]["tdense"] == 0

@@ -403,21 +403,15 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
     print("%s: %d documents x 12 passes, evaluations per pass nu %d lambda %d -- all equal" % (case, D, st["n_eval_nu"], st["n_eval_lambda"]))
 
 
-@pytest.mark.parametrize("env,case,expect", [({"MMM_CTM_CPL": "0", "MMM_CTM_PACK": "0"}, "imm10", (16, 1)), ({"MMM_CTM_CPL": "0"}, "imm10", (10, 1)),
-                                             ({}, "imm10", (2, 5)), ({"MMM_CTM_CPL": "2"}, "cfg3_shape", (2, 7)), ({"MMM_CTM_CPL": "4"}, "cfg3_shape", (8, 2)), ({"MMM_CTM_CPL": "2"}, "cfg4_shape", (8, 4)), ({"MMM_CTM_CPL": "3"}, "cfg4_shape", (32, 1)),
-                                             ({}, "cfg4_shape", (16, 2)), ({"MMM_CTM_CPL": "0"}, "cfg4_shape", (32, 1)),
-                                             ({"MMM_CTM_SPLIT": "16:3:16:3"}, "cfg4_shape", (16, 2)), ({"MMM_CTM_SPLIT": "16:4:16:4", "MMM_CTM_CLAIM": "0"}, "cfg4_shape", (16, 2)),
-                                             ({"MMM_CTM_SPLIT": "16:3:32:4"}, "cfg4_shape", (32, 1)),
-                                             ({}, "mm33", (6, 1)), ({}, "mm66", (12, 1))])
-def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, env, case, expect):
+@pytest.mark.parametrize("off,case,expect", [(("ctm_cpl", "ctm_packed"), "imm10", (16, 1)), (("ctm_cpl",), "imm10", (10, 1)), ((), "imm10", (2, 5)),
+                                             ((), "cfg3_shape", (16, 1)), ((), "cfg4_shape", (16, 2)), (("ctm_cpl",), "cfg4_shape", (32, 1)),
+                                             ((), "mm33", (6, 1)), ((), "mm66", (12, 1))])
+def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, tuning, off, case, expect):
     """The solve phase has three lane layouts: one coordinate per lane in 16/32/64-lane DPP rows (mma_group), packed groups of sum K
-    lanes (6 / 10 / 12; ds_bpermute tree), and several coordinates per lane (k_ctm_solve_cpl; sum K = 10 by default, 14 and 28 on
-    request; round 3: 16 lanes x 2 coordinates for sum K = 28 by default).  Each associates the sums over a document differently; the
-    oracle mirrors the layout the handle reports (geometry Ls / cpl) and the fit must stay bit-identical in all of them.  MMM_CTM_SPLIT
-    runs update_nu! and update_lambda! as two launches whose slots take their documents on demand (claim_doc; MMM_CTM_CLAIM=0: static
-    ranges) -- which slot solves which document changes nothing."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    lanes (6 / 10 / 12; ds_bpermute tree), and several coordinates per lane (k_ctm_solve_cpl: sum K = 10 -> 2 lanes x 5, sum K = 28 ->
+    16 lanes x 2).  Each associates the sums over a document differently; the oracle mirrors the layout the handle reports (geometry
+    Ls / cpl) and the fit must stay bit-identical in all of them.  mmm_tuning_opts.disable switches a layout off per handle."""
+    tuning(disable=off)
     if case == "imm10":
         kw = dict(D=300, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
     elif case == "mm33":
@@ -439,12 +433,12 @@ def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, monkeypatch, e
 
 
 @pytest.mark.parametrize("case", ["cfg4_shape", "cfg3_shape", "imm10", "mm16_12", "mm"])
-def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, monkeypatch, case):
+def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, tuning, case):
     """The fused pass's theta phase over rows of counts (k_ctm_theta_dense, round 3: dense corpora -- by default from 32 documents per CU,
     forced here): 16 lanes per document, the gamma statistics in registers, one launch per modality.  The oracle mirrors its association
     (geometry tdense); the fit must stay bit-identical -- state and per-document evaluation counts -- and whole fits stop in the same pass.
     Empty documents (10 %) and a 48-term / 38-term / 24-term modality (3 / 3 / 2 slots per lane) included."""
-    monkeypatch.setenv("MMM_CTM_DENSE", "1")
+    tuning(ctm_build="dense")
     if case == "imm10":
         kw = dict(D=301, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
     elif case == "mm16_12":
@@ -472,15 +466,15 @@ def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, monkeyp
 
 
 @pytest.mark.parametrize("imm", [False, True])
-def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, monkeypatch, imm):
+def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, tuning, imm):
     """fused_pass on one GPU may run the gamma-statistics reduction and the topic M-step on a side stream beside the solve phase (default:
-    IMMCTM only; MMM_CTM_OVERLAP=1 / 0 forces / forbids): the same kernels and sums, so whole fits are bit-identical whichever way the
+    IMMCTM only; mmm_tuning_opts.side_stream = 1 / -1 forces / forbids): the same kernels and sums, so whole fits are bit-identical whichever way the
     launches are ordered, and bit-identical to the oracle -- state, per-document evaluation counts, ll history."""
     kw = dict(D=301, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3) if imm else dict(D=260, K=[7, 5], V=[96, 38], seed=66, means=[900, 120])
     D, MK = kw["D"], sum(kw["K"])
     hist = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MMM_CTM_OVERLAP", mode)
+        tuning(side_stream=1 if mode == "1" else -1)
         X, g, o = _pair(mmm, oracle, order="device", **kw)
         ll = np.asarray(mmm.fit(g, maxiter=9, tol=0.0, verbose=False))
         for _ in range(9):
@@ -493,8 +487,8 @@ def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, monkeypatch, 
     assert np.array_equal(hist["0"][0], hist["1"][0]) and np.array_equal(hist["0"][1], hist["1"][1]) and np.array_equal(hist["0"][2], hist["1"][2])
 
 
-def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(mmm, monkeypatch):
-    monkeypatch.setenv("MMM_CTM_DENSE", "1")
+def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(mmm, tuning):
+    tuning(ctm_build="dense")
     X, g0 = np_ref.synth_mm(60, [40, 24], [5, 4], seed=4, means=[600, 80])
     X[3][0] = np.vstack([X[3][0], X[3][0][:1]])                   # a term listed twice: the reference treats the rows separately
     g = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], X, γ0=g0)
@@ -502,7 +496,7 @@ def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(m
     Xs, g0s = np_ref.synth_mm(60, [400, 24], [5, 4], seed=4, means=[60, 80])      # 400 terms: beyond the rows; and sparse
     gs = mmm.MMCTM([5, 4], [0.1, 0.1], [400, 24], Xs, γ0=g0s)
     assert gs.geometry()["tdense"] == 0
-    monkeypatch.delenv("MMM_CTM_DENSE")
+    tuning()
     Xd, g0d = np_ref.synth_mm(60, [40, 24], [5, 4], seed=4, means=[600, 80])
     gd = mmm.MMCTM([5, 4], [0.1, 0.1], [40, 24], Xd, γ0=g0d)
     assert gd.geometry()["tdense"] == 0                            # small corpora keep the slab kernel by default

@@ -1,6 +1,6 @@
 """MMCTM / IMMCTM with topic tables beyond LDS (a 1536- or 3000-term modality): the wide path -- θ phase reading the table
 through L2, γ statistics from a term-major posting sweep that evaluates θ again (k_ctm_stats_terms), ll / ELBO kernels without the
-staged table -- against the CPU oracle and against the LDS path on the same inputs.  `MMM_CTM_WIDE=1` (read at create) forces it."""
+staged table -- against the CPU oracle and against the LDS path on the same inputs.  `ctm_build = MMM_BUILD_WIDE` (mmm_ctx_set_tuning; read at create) forces it."""
 import numpy as np
 import pytest
 
@@ -11,18 +11,18 @@ from test_ctm_gpu import SNV3, _cmp_docs, _pair, _robust_close
 pytestmark = pytest.mark.gpu
 
 
-def _wide_pair(mmm, oracle, monkeypatch, *a, **kw):
-    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+def _wide_pair(mmm, oracle, tuning, *a, **kw):
+    tuning(ctm_build="wide")
     out = _pair(mmm, oracle, *a, **kw)
-    monkeypatch.delenv("MMM_CTM_WIDE")
+    tuning()
     return out
 
 
 @pytest.mark.parametrize("case", ["mm2", "mm3", "imm", "k20"])
-def test_forced_wide_pass_against_oracle(mmm, oracle, monkeypatch, case):
+def test_forced_wide_pass_against_oracle(mmm, oracle, tuning, case):
     D, K, V, means, feats = {"mm2": (64, [7, 7], [96, 48], [3000, 60], None), "mm3": (45, [10, 10, 8], [96, 38, 32], [2000, 150, 100], None),
                              "imm": (50, [10], [96], [2500], SNV3), "k20": (40, [20, 12], [40, 25], [300, 200], None)}[case]
-    X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, K, V, seed=77, means=means, imm_features=feats)
+    X, g, o = _wide_pair(mmm, oracle, tuning, D, K, V, seed=77, means=means, imm_features=feats)
     MK, M = sum(K), len(K)
     check = mmm._lib.check
     for it in range(2):
@@ -40,14 +40,14 @@ def test_forced_wide_pass_against_oracle(mmm, oracle, monkeypatch, case):
     assert mmm.calculate_elbo(g) == pytest.approx(o.elbo()[0], rel=1e-5)
 
 
-def test_wide_first_pass_equals_lds_path(mmm, monkeypatch):
+def test_wide_first_pass_equals_lds_path(mmm, tuning):
     """One pass from the same state through both data flows: the γ statistics differ by summation order only."""
     D, K, V = 120, [7, 7], [96, 48]
     X, g0 = np_ref.synth_mm(D, V, K, seed=3, means=[3000, 60], empty_frac=0.1)
     a = mmm.MMCTM(K, [0.1, 0.1], V, X, γ0=g0)
-    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+    tuning(ctm_build="wide")
     b = mmm.MMCTM(K, [0.1, 0.1], V, X, γ0=g0)
-    monkeypatch.delenv("MMM_CTM_WIDE")
+    tuning()
     for m in (a, b):
         mmm._lib.check(mmm.lib().mmm_ctm_iterate(m._h, 1, 1), m.ctx.h, "iterate")
     # the two θ-loop builds round sumθ differently in the last bits, which the solves carry through (and, rarely, a stopping
@@ -87,11 +87,11 @@ def test_tables_beyond_lds(mmm, oracle, case):
             assert tot == pytest.approx(Nm[m], rel=1e-10)
 
 
-def test_wide_batch_is_bitwise_the_single_fit(mmm, monkeypatch):
+def test_wide_batch_is_bitwise_the_single_fit(mmm, tuning):
     D, K, V, R = 70, [5, 4], [40, 24], 3
     X, _ = np_ref.synth_mm(D, V, K, seed=12, means=[600, 80], empty_frac=0.1)
     g0 = _inits(K, V, R, 99)
-    monkeypatch.setenv("MMM_CTM_WIDE", "1")
+    tuning(ctm_build="wide")
     batch = _make(mmm, K, V, X, g0, None, restarts=R)
     hists = mmm.fit_restarts(batch, maxiter=20, tol=2e-3)
     for r in range(R):
@@ -102,7 +102,7 @@ def test_wide_batch_is_bitwise_the_single_fit(mmm, monkeypatch):
         for f in FIELDS:
             assert np.array_equal(batch._get(f), single._get(f)), "restart %d field %s" % (r, f)
         single.close()
-    monkeypatch.delenv("MMM_CTM_WIDE")
+    tuning()
 
 
 @pytest.mark.parametrize("case", ["mm40", "mm36_20", "imm40"])

@@ -111,11 +111,10 @@ def test_fit_matches_oracle(mmm, oracle, K):
     assert g.ll == pytest.approx(ll_o[-1], rel=1e-9)
 
 
-def test_fit_on_the_dense_row_estep_build(mmm, oracle, monkeypatch):
+def test_fit_on_the_dense_row_estep_build(mmm, oracle, tuning):
     """ILDA shares the LDA E-step: the dense-row build (forced here; default for dense corpora of >= 192 documents per CU) and the reduce
     blocks joining the ll sweep (residency lowered so that the ll blocks loop) against the oracle."""
-    monkeypatch.setenv("MMM_LDA_DENSE", "1")
-    monkeypatch.setenv("MMM_LDA_RESIDENT_CAP", "64")
+    tuning(lda_build="dense", resident_cap=64)
     X, g, o = _pair(mmm, oracle, 400, 10, seed=29)
     assert g.geometry()["dense"] == 1
     ll_g = mmm.fit(g, maxiter=30, tol=0.0, verbose=False)

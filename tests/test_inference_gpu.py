@@ -35,9 +35,9 @@ def test_lda_transform(mmm, oracle):
     np.testing.assert_allclose(th_g.sum(axis=0), 1.0, rtol=1e-13)
 
 
-def test_lda_transform_and_heldout_on_dense_row_handles(mmm, oracle, monkeypatch):
+def test_lda_transform_and_heldout_on_dense_row_handles(mmm, oracle, tuning):
     """Handles that took the dense-row E-step build (forced): the frozen-topic passes and the stage API keep to the CSR sweeps."""
-    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    tuning(lda_build="dense")
     g, o, Xn = _lda_pair(mmm, oracle, D=200, K=10, seed=6)
     assert g.geometry()["dense"] == 1
     with warnings.catch_warnings():

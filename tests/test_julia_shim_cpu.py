@@ -70,7 +70,7 @@ def ctype(decl):
         if "[" in d:                # `double terms[7]`, `char out[64]`, `int out[8]`
             base = re.sub(r"\bconst\b", "", d.split("[")[0]).split()[0]
         return "ptr:" + {"mmm_ctx": "void", "mmm_lda": "void", "mmm_ctm": "void", "void": "void", "char": "char", "double": "double", "int": "int",
-                         "int32_t": "int32", "int64_t": "int64", "mmm_solver_opts": "void", "size_t": "size_t"}.get(base, base)
+                         "int32_t": "int32", "int64_t": "int64", "mmm_solver_opts": "void", "mmm_tuning_opts": "void", "size_t": "size_t"}.get(base, base)
     toks = re.sub(r"\bconst\b", "", d).split()
     t = toks[0]
     return {"int": "int", "double": "double", "size_t": "size_t", "void": "void", "int64_t": "int64"}.get(t, t)
@@ -87,7 +87,7 @@ def jtype(t):
     if inner.startswith(("Ptr{", "Ref{")):
         return "ptr:ptr"
     return "ptr:" + {"Cvoid": "void", "Cdouble": "double", "Cint": "int", "Int32": "int32", "Int64": "int64", "UInt8": "char", "Cchar": "char",
-                     "SolverOpts": "void"}.get(inner, inner)
+                     "SolverOpts": "void", "TuningOpts": "void"}.get(inner, inner)
 
 
 def shim_ccalls():

@@ -192,10 +192,10 @@ def test_config_2_at_its_own_size_against_the_oracle(mmm, oracle):
 
 
 @pytest.mark.parametrize("D,V,K", [(70, 50, 16), (50, 96, 20), (40, 30, 32), (45, 96, 13)])
-def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, monkeypatch, D, V, K):
+def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, tuning, D, V, K):
     """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16.
     (K > 24 goes to the wide-vocabulary kernels by default -- tests/test_lda_wide_gpu.py; here the LDS kernels are kept in play.)"""
-    monkeypatch.setenv("MMM_LDA_WIDE", "0")
+    tuning(lda_build="sparse")
     X, g, o = _pair(mmm, oracle, D, V, K, seed=300 + K, empty=(2,))
     ll_g = mmm.fit(g, maxiter=13, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=13, tol=0.0)
@@ -204,9 +204,9 @@ def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, monkeypatch, D, V,
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-8)
 
 
-def test_many_documents_per_wave_loop(mmm, oracle, monkeypatch):
+def test_many_documents_per_wave_loop(mmm, oracle, tuning):
     """A tiny grid forces every wave through several document steps (the grid-stride path used for large corpora)."""
-    monkeypatch.setenv("MMM_LDA_GRID", "3")
+    tuning(grid_blocks=3)
     X, g, o = _pair(mmm, oracle, 500, 96, 10, seed=12, mean_n=500, empty=(7, 499))
     ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=12, tol=0.0)
@@ -228,26 +228,20 @@ def test_degenerate_shapes(mmm, oracle):
 
 @pytest.mark.parametrize("D,V,K,mean_n", [(500, 96, 10, 500), (300, 40, 7, 200), (260, 128, 4, 900), (70, 20, 12, 100), (333, 90, 5, 60),
                                            (200, 33, 15, 300)])
-@pytest.mark.parametrize("lanes32", ["0", "1"])
-def test_dense_row_estep_matches_oracle(mmm, oracle, monkeypatch, D, V, K, mean_n, lanes32):
+def test_dense_row_estep_matches_oracle(mmm, oracle, tuning, D, V, K, mean_n):
     """The dense-row E-step build (rows of counts, statistics in registers; taken by default for dense corpora too large for the single-step
-    build) forced on small corpora of every slot count it has builds for, sparse rows and empty documents included.  lanes32: its
-    32-lane variant (k_lda_estep_dense32, round 3: slower than the 16-lane build and off by default; where the shape has no such build
-    the 16-lane one runs)."""
-    monkeypatch.setenv("MMM_LDA_DENSE", "1")
-    monkeypatch.setenv("MMM_LDA_DENSE32", lanes32)
+    build) forced on small corpora of every slot count it has builds for, sparse rows and empty documents included."""
+    tuning(lda_build="dense")
     X, g, o = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
     geo = g.geometry()
-    assert geo["dense"] in (1, 2) and geo["SL"] * 16 >= V and geo["single_step"] == 0
-    if lanes32 == "1" and (D, V, K) == (500, 96, 10):
-        assert geo["dense"] == 2
+    assert geo["dense"] == 1 and geo["SL"] * 16 >= V and geo["single_step"] == 0
     ll_g = mmm.fit(g, maxiter=12, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=12, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
     _cmp_state(g, o, 1e-8)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-9)
     # several steps per wave and bitwise run-to-run
-    monkeypatch.setenv("MMM_LDA_GRID", "2")
+    tuning(lda_build="dense", grid_blocks=2)
     _, g2, _ = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
     _, g3, _ = _pair(mmm, oracle, D, V, K, seed=31 + D, mean_n=mean_n, empty=(3, D - 1))
     ll_2 = mmm.fit(g2, maxiter=12, tol=0.0, verbose=False)
@@ -270,20 +264,18 @@ def _random_lda_shapes(n, seed):
 
 
 @pytest.mark.parametrize("idx,shape", list(enumerate(_random_lda_shapes(16, 20261004))))
-def test_random_shapes_every_estep_build_against_oracle(mmm, oracle, monkeypatch, idx, shape):
+def test_random_shapes_every_estep_build_against_oracle(mmm, oracle, tuning, idx, shape):
     """Randomly drawn (D, V, K, document length): six fused passes through the default build of the shape, the grid-stride loop (a 3-block
     grid), the dense-row build (where the shape has one) and the wide-table path, each against the oracle."""
     D, V, K, mean_n = shape
-    envs = [{}, {"MMM_LDA_GRID": "3"}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_WIDE": "1"}]
+    envs = [{}, {"grid_blocks": 3}, {"lda_build": "dense"}, {"lda_build": "wide"}]
     ll_o = None
     for env in envs:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        tuning(**env)
         X, g, o = _pair(mmm, oracle, D, V, K, seed=400 + idx, mean_n=mean_n, empty=(0,) if D > 4 else ())
-        for k in env:
-            monkeypatch.delenv(k)
+        tuning()
         geo = g.geometry()
-        if "MMM_LDA_WIDE" in env:
+        if env.get("lda_build") == "wide":
             assert geo["wide"] == 1
         ll_g = mmm.fit(g, maxiter=6, tol=0.0, verbose=False)
         if ll_o is None:
@@ -295,13 +287,12 @@ def test_random_shapes_every_estep_build_against_oracle(mmm, oracle, monkeypatch
         g.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_DROWS": "0"}, {"MMM_LDA_ROWS16": "0"}, {"MMM_LDA_ROWS": "0"}])
-def test_rows_of_counts_with_a_count_beyond_16_bits(mmm, oracle, monkeypatch, env):
+@pytest.mark.parametrize("env", [{}, {"lda_build": "dense"}, {"disable": ("lda_count_rows",)}, {"disable": ("lda_rows16",)}, {"disable": ("lda_padded_rows",)}])
+def test_rows_of_counts_with_a_count_beyond_16_bits(mmm, oracle, tuning, env):
     """Dense corpora are also kept as rows of counts (16-bit where every count fits, else 32-bit) for the single-step E-step build, the ll
     blocks and the dense-row build; one count of 70,000 forces the 32-bit rows; every switch that selects another data path gives the
     oracle's fit."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    tuning(**env)
     for big in (False, True):
         X, lam0 = np_ref.synth_lda(300, 96, 10, seed=21, mean_n=900)
         if big:
@@ -314,26 +305,26 @@ def test_rows_of_counts_with_a_count_beyond_16_bits(mmm, oracle, monkeypatch, en
         g.close()
 
 
-def test_dense_row_build_is_not_taken_for_sparse_or_duplicated_rows(mmm, oracle, monkeypatch):
+def test_dense_row_build_is_not_taken_for_sparse_or_duplicated_rows(mmm, oracle, tuning):
     """Documents that list a term twice (the reference treats the rows separately) or a sparse corpus keep the CSR sweep."""
-    monkeypatch.setenv("MMM_LDA_DENSE", "1")
+    tuning(lda_build="dense")
     X, lam0 = np_ref.synth_lda(40, 24, 5, seed=5, mean_n=100)
     X[7] = np.vstack([X[7], X[7][:1]])
     g = mmm.LDA(5, 0.1, 0.1, 24, X, λ0=lam0)
     assert g.geometry()["dense"] == 0
     o = oracle.LdaOracle(5, 0.1, 0.1, X, V=24, lambda0=lam0)
     np.testing.assert_allclose(mmm.fit(g, maxiter=5, tol=0.0, verbose=False), o.fit(maxiter=5, tol=0.0), rtol=1e-9)
-    monkeypatch.delenv("MMM_LDA_DENSE")
+    tuning()
     X, g, o = _pair(mmm, oracle, 200, 96, 10, seed=3, mean_n=3000)
     assert g.geometry()["dense"] == 0 and g.geometry()["single_step"] == 1       # small corpora: the single-step build
 
 
 @pytest.mark.parametrize("dense", ["0", None])
-def test_large_corpus_grid_stride_paths(mmm, oracle, monkeypatch, dense):
+def test_large_corpus_grid_stride_paths(mmm, oracle, tuning, dense):
     """50,000 documents: the grid-stride E-step builds (several steps per wave; the CSR sweep and, by default for this dense corpus, the
     dense-row build) and the ll blocks' loop (more document groups than ll blocks) against the oracle."""
     if dense is not None:
-        monkeypatch.setenv("MMM_LDA_DENSE", dense)
+        tuning(lda_build="sparse")
     X, g, o = _pair(mmm, oracle, 50000, 96, 10, seed=77, mean_n=150, empty=(0, 49999))
     assert g.geometry()["dense"] == (0 if dense == "0" else 1)
     ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
@@ -344,13 +335,13 @@ def test_large_corpus_grid_stride_paths(mmm, oracle, monkeypatch, dense):
 
 
 @pytest.mark.parametrize("cap", [61, 64, 100, 30])
-def test_merged_launch_never_exceeds_residency(mmm, oracle, cap, monkeypatch):
+def test_merged_launch_never_exceeds_residency(mmm, oracle, cap, tuning):
     """The reduce + ll + M-step launch has blocks that wait for each other (16-byte cells).  The library launches it only with as
     many blocks as can be resident at once (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs; here lowered through
-    MMM_LDA_RESIDENT_CAP): the ll blocks are cut to what fits (cap 61 / 64 / 100: 60 reduce blocks + 1 / 4 / 40 ll blocks for
+    mmm_tuning_opts.resident_cap): the ll blocks are cut to what fits (cap 61 / 64 / 100: 60 reduce blocks + 1 / 4 / 40 ll blocks for
     20,000 documents, which would take 313), or the split kernels run (cap 30 < 60 reduce blocks).  Either way: the oracle's
     results, no wait_timeout."""
-    monkeypatch.setenv("MMM_LDA_RESIDENT_CAP", str(cap))
+    tuning(resident_cap=cap)
     X, g, o = _pair(mmm, oracle, 20000, 96, 10, seed=78, mean_n=120)
     ll_g = mmm.fit(g, maxiter=14, tol=0.0, verbose=False)        # raises MmmError on a device-side wait time-out
     ll_o = o.fit(maxiter=14, tol=0.0)
@@ -376,7 +367,7 @@ def test_context_may_be_destroyed_before_its_models(mmm):
     assert L.mmm_lda_destroy(hb) == 0             # releases the context
 
 
-def test_dense_row_build_with_a_never_observed_term_and_tiny_priors(mmm, monkeypatch):
+def test_dense_row_build_with_a_never_observed_term_and_tiny_priors(mmm, tuning):
     """ADVICE r2: with eta = alpha = 1e-3 the normaliser sum_k a_k exp(Elnbeta_kv) of a term that no document contains underflows to 0;
     the dense-row build visits every slot of a row, so a slot without mass must contribute 0, not 0 x rcp(0) = NaN.  Checked against the
     CSR sweep (which never sees such a slot) on the same corpus."""
@@ -386,7 +377,7 @@ def test_dense_row_build_with_a_never_observed_term_and_tiny_priors(mmm, monkeyp
     lam0 = np.ones_like(lam0)
     fits = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MMM_LDA_DENSE", mode)
+        tuning(lda_build="dense" if mode == "1" else "sparse")
         g = mmm.LDA(10, 1e-3, 1e-3, 96, X, λ0=lam0)
         assert g.geometry()["dense"] == int(mode)
         ll = mmm.fit(g, maxiter=60, tol=0.0, verbose=False)

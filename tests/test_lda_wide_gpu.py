@@ -1,6 +1,6 @@
 """The wide-vocabulary LDA path (K·V tables larger than LDS: one wave per document, tables through L2, ϕ written out, topic
 statistics by a term-major posting sweep) against the CPU oracle and against the LDS path on the same inputs.
-`MMM_LDA_WIDE=1` (read at create) forces the path for shapes the LDS path also handles, so the two can be compared directly."""
+`lda_build = MMM_BUILD_WIDE` (mmm_ctx_set_tuning; read at create) forces the path for shapes the LDS path also handles, so the two can be compared directly."""
 import warnings
 
 import numpy as np
@@ -12,16 +12,16 @@ from test_lda_gpu import _cmp_state, _pair
 pytestmark = pytest.mark.gpu
 
 
-def _wide_pair(mmm, oracle, monkeypatch, *a, **kw):
-    monkeypatch.setenv("MMM_LDA_WIDE", "1")
+def _wide_pair(mmm, oracle, tuning, *a, **kw):
+    tuning(lda_build="wide")
     out = _pair(mmm, oracle, *a, **kw)
-    monkeypatch.delenv("MMM_LDA_WIDE")
+    tuning()
     return out
 
 
 @pytest.mark.parametrize("D,V,K", [(101, 96, 10), (37, 24, 5), (40, 30, 32), (45, 96, 13)])
-def test_forced_wide_stage_api_and_fit(mmm, oracle, monkeypatch, D, V, K):
-    X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, V, K, seed=100 + D, empty=(1, D - 1))
+def test_forced_wide_stage_api_and_fit(mmm, oracle, tuning, D, V, K):
+    X, g, o = _wide_pair(mmm, oracle, tuning, D, V, K, seed=100 + D, empty=(1, D - 1))
     mmm.update_γ(g); o.update_gamma()
     mmm.update_ϕ(g); o.update_phi()
     mmm.update_λ(g); o.update_lambda()
@@ -29,7 +29,7 @@ def test_forced_wide_stage_api_and_fit(mmm, oracle, monkeypatch, D, V, K):
     mmm.update_θ(g); o.update_theta()
     _cmp_state(g, o, 1e-11)
     assert mmm.calculate_loglikelihood(g) == pytest.approx(o.loglik(), rel=1e-11)
-    X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, V, K, seed=100 + D, empty=(1, D - 1))     # (the oracle's fit starts from the constructor state)
+    X, g, o = _wide_pair(mmm, oracle, tuning, D, V, K, seed=100 + D, empty=(1, D - 1))     # (the oracle's fit starts from the constructor state)
     ll_g = mmm.fit(g, maxiter=13, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=13, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
@@ -37,15 +37,15 @@ def test_forced_wide_stage_api_and_fit(mmm, oracle, monkeypatch, D, V, K):
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-8)
 
 
-def test_wide_equals_lds_path(mmm, oracle, monkeypatch):
+def test_wide_equals_lds_path(mmm, oracle, tuning):
     """Same corpus, same λ0 through both data flows: same stopping pass, ll history and state to summation-order accuracy;
     and the wide path is deterministic (posting-order sums, no atomics)."""
     X, lam0 = np_ref.synth_lda(300, 96, 10, seed=5, mean_n=900)
     a = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
-    monkeypatch.setenv("MMM_LDA_WIDE", "1")
+    tuning(lda_build="wide")
     b = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
     c = mmm.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
-    monkeypatch.delenv("MMM_LDA_WIDE")
+    tuning()
     la, lb, lc = (mmm.fit(m, maxiter=300, tol=1e-5, verbose=False) for m in (a, b, c))
     assert len(la) == len(lb) and a.converged and b.converged
     np.testing.assert_allclose(la, lb, rtol=1e-11)
@@ -94,22 +94,22 @@ def test_wide_inference(mmm, oracle):
     assert hg.elbo == pytest.approx(ho.elbo_value, rel=1e-9)
 
 
-def test_wide_ilda(mmm, oracle, monkeypatch):
+def test_wide_ilda(mmm, oracle, tuning):
     """ILDA on the wide data flow (effective V×K tables, statistics folded onto feature values by the same M-step kernel)."""
     from test_ilda_gpu import _pair as ilda_pair
-    monkeypatch.setenv("MMM_LDA_WIDE", "1")
+    tuning(lda_build="wide")
     X, g, o = ilda_pair(mmm, oracle, 80, 6, seed=31)
-    monkeypatch.delenv("MMM_LDA_WIDE")
+    tuning()
     ll_g = mmm.fit(g, maxiter=14, tol=0.0, verbose=False)
     ll_o = o.fit(maxiter=14, tol=0.0)
     np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
     assert g.elbo == pytest.approx(o.elbo_value, rel=1e-8)
 
 
-def test_wide_degenerate_shapes(mmm, oracle, monkeypatch):
+def test_wide_degenerate_shapes(mmm, oracle, tuning):
     """K = 1, a single document, all documents empty but one, unused vocabulary tail, and a term listed twice in a document."""
     for D, V, K, empty in [(5, 7, 1, ()), (1, 96, 10, ()), (6, 30, 4, (0, 1, 2, 4, 5)), (3, 200, 2, ())]:
-        X, g, o = _wide_pair(mmm, oracle, monkeypatch, D, V, K, seed=900 + D + K, mean_n=50, empty=empty)
+        X, g, o = _wide_pair(mmm, oracle, tuning, D, V, K, seed=900 + D + K, mean_n=50, empty=empty)
         ll_g = mmm.fit(g, maxiter=4, tol=0.0, verbose=False)
         ll_o = o.fit(maxiter=4, tol=0.0)
         np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
@@ -118,9 +118,9 @@ def test_wide_degenerate_shapes(mmm, oracle, monkeypatch):
         g.close()
     X = [np.array([[1, 3], [2, 5], [1, 2]]), np.array([[2, 4], [3, 1]])]              # term 1 twice in document 0
     lam0 = np.random.default_rng(1).integers(1, 101, size=(3, 2)).astype(np.float64)
-    monkeypatch.setenv("MMM_LDA_WIDE", "1")
+    tuning(lda_build="wide")
     g = mmm.LDA(2, 0.1, 0.1, 3, X, λ0=lam0)
-    monkeypatch.delenv("MMM_LDA_WIDE")
+    tuning()
     o = oracle.LdaOracle(2, 0.1, 0.1, X, V=3, lambda0=lam0)
     np.testing.assert_allclose(mmm.fit(g, maxiter=5, tol=0.0, verbose=False), o.fit(maxiter=5, tol=0.0), rtol=1e-11)
     np.testing.assert_allclose(g.λ, o.lam.reshape(3, 2, order="F"), rtol=1e-11)

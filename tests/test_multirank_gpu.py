@@ -19,6 +19,8 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests")
 import numpy as np, mmm_pkg, np_ref
 pkg = mmm_pkg.load()
 ctx = pkg.Context(0)
+if os.environ.get("TEST_LDA_WIDE"):
+    ctx.set_tuning(lda_build="wide")
 if os.environ.get("MMM_FORCE_RCCL"):
     ctx.init_comm(1, 0, pkg.comm_unique_id())
 X, lam0 = np_ref.synth_lda(300, 96, 10, seed=9, mean_n=800)
@@ -33,9 +35,9 @@ print("RESULT " + json.dumps({"transport": ctx.transport, "ll": ll.tolist(), "el
 
 def _run(force, mailboxes=False, wide=False):
     env = dict(os.environ)
-    env.pop("MMM_FORCE_RCCL", None); env.pop("MMM_P2P_ONE_RANK", None); env.pop("MMM_LDA_WIDE", None)
+    env.pop("MMM_FORCE_RCCL", None); env.pop("MMM_P2P_ONE_RANK", None); env.pop("TEST_LDA_WIDE", None)
     if wide:
-        env["MMM_LDA_WIDE"] = "1"
+        env["TEST_LDA_WIDE"] = "1"
     if force:
         env["MMM_FORCE_RCCL"] = "1"
     if mailboxes:

@@ -49,12 +49,12 @@ def _worker(rank, world, port, q):
         res.update(lda_ll=ll.tolist(), lda_elbo=g.elbo, lda_beta=g.β.tolist(), lda_conv=g.converged, shard=(d0, d1))
         # ---- the same LDA fit through the dense-row E-step build, with the reduce blocks joining the ll sweep (residency lowered so that
         #      the ll blocks loop over their documents) -- the folded exchange rides in that launch too
-        os.environ["MMM_LDA_DENSE"] = "1"; os.environ["MMM_LDA_RESIDENT_CAP"] = "64"
+        ctx.set_tuning(lda_build="dense", resident_cap=64)
         gd = pkg.LDA(10, 0.1, 0.1, 96, X[d0:d1], λ0=lam0, ctx=ctx)
         assert gd.geometry()["dense"] == 1
         lld = pkg.fit(gd, maxiter=40, tol=1e-4, verbose=False)
         res.update(ldad_ll=lld.tolist(), ldad_beta=gd.β.tolist())
-        del os.environ["MMM_LDA_DENSE"]; del os.environ["MMM_LDA_RESIDENT_CAP"]
+        ctx.set_tuning()
         # ---- MMCTM: moments + gamma sums (1 x 7 x ... doubles) and M-double ll
         Xm, g0 = np_ref.synth_mm(240, [40, 24], [5, 4], seed=4, means=[600, 80], empty_frac=0.1)
         e0, e1 = pkg.shard_documents(Xm, world, rank)
@@ -67,12 +67,12 @@ def _worker(rank, world, port, q):
         Xi, _ = np_ref.synth_mm(330, [96], [6], seed=14, means=[900], empty_frac=0.05)
         gi0 = np.random.default_rng(3).integers(1, 101, size=6 * 14).astype(np.float64)
         f0, f1 = pkg.shard_documents(Xi, world, rank)
-        os.environ["MMM_CTM_DENSE"] = "1"
+        ctx.set_tuning(ctm_build="dense")
         ci = pkg.IMMCTM([6], [0.1], SNV3, Xi[f0:f1], γ0=gi0, ctx=ctx)
         assert ci.geometry()["tdense"]
         lli = pkg.fit(ci, maxiter=25, tol=2e-3, verbose=False)
         res.update(imm_ll=np.asarray(lli).tolist(), imm_elbo=ci.elbo, imm_gamma=ci._get("gamma").tolist(), imm_conv=ci.converged)
-        del os.environ["MMM_CTM_DENSE"]
+        ctx.set_tuning()
         if rank == 0:
             plain_i = pkg.Context(0)
             cis = pkg.IMMCTM([6], [0.1], SNV3, Xi, γ0=gi0, ctx=plain_i)

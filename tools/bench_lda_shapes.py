@@ -10,10 +10,10 @@ ap.add_argument("D", type=int); ap.add_argument("V", type=int); ap.add_argument(
 ap.add_argument("--wide", action="store_true"); ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--ilda", action="store_true", help="ILDA over the SNV factorisation (V must be 96): I = 3, J = [6, 4, 4]")
 a = ap.parse_args()
-if a.wide:
-    os.environ["MMM_LDA_WIDE"] = "1"
 import mmm_pkg, np_ref
 mmm = mmm_pkg.load()
+if a.wide:
+    mmm.default_context().set_tuning(lda_build="wide")
 X, lam0 = np_ref.synth_lda(a.D, a.V, a.K, seed=1, mean_n=a.mean_n)
 if a.ilda:
     feats = np.array([[t // 16 + 1, (t // 4) % 4 + 1, t % 4 + 1] for t in range(96)])

@@ -1,13 +1,14 @@
 """Diagnostic (not a benchmark): in-kernel s_memtime stamps of the dense-row LDA E-step kernel (k_lda_estep_dense), block 0 / wave 0.
-Usage on the GPU box: make -C multimodalmusig.jl_amd/csrc diag && MMM_LDA_DENSE=1 MMM_LIB_PATH=.../libmmmusig_hip_diag.so python tools/diag_dense_stamps.py [D]"""
+Usage on the GPU box: make -C multimodalmusig.jl_amd/csrc diag && MMM_LIB_PATH=.../libmmmusig_hip_diag.so python tools/diag_dense_stamps.py [D]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, mmm_pkg, np_ref
 pkg = mmm_pkg.load()
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 15000
 X, lam0 = np_ref.synth_lda(D, 96, 10, seed=3)
+pkg.default_context().set_tuning(lda_build="dense")
 m = pkg.LDA(10, 0.1, 0.1, 96, X, λ0=lam0)
-assert m.geometry()["dense"], "not the dense-row build (MMM_LDA_DENSE=1)"
+assert m.geometry()["dense"], "not the dense-row build"
 lib = pkg.lib()
 for rep in range(3):
     pkg._lib.check(lib.mmm_lda_iterate(m._h, 5), m.ctx.h)

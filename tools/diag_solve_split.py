@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How the solve phase of a CTM pass splits between update_nu! and update_lambda! (the two LD_MMA solves, MMCTM.jl:127-170), per build:
 after P warm-up passes the stage calls mmm_ctm_update_zeta / theta / nu / lambda are run once with HIP events around the solve launches.
-usage: python tools/diag_solve_split.py [config 4|5] [docs] [passes]      (MMM_CTM_CPL / MMM_CTM_NU_CPL ... select the build)"""
+usage: python tools/diag_solve_split.py [config 4|5] [docs] [passes]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

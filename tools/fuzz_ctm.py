@@ -21,8 +21,7 @@ for case in range(n):
     D = int(rng.choice([1, 3, 40, 130, 300]))
     means = [int(rng.choice([5, 60, 800, 4000])) for _ in range(M)]
     mode = str(rng.choice(["lds", "wide"]))
-    os.environ.pop("MMM_CTM_WIDE", None)
-    if mode == "wide": os.environ["MMM_CTM_WIDE"] = "1"
+    mmm.default_context().set_tuning(ctm_build="wide" if mode == "wide" else "auto")
     try:
         X, g, o = T._pair(mmm, oracle, D, K, V, seed=int(rng.integers(1 << 30)), means=means, empty_frac=float(rng.choice([0.0, 0.2])))
         MK = sum(K)

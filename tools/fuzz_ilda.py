@@ -24,8 +24,7 @@ for case in range(n):
     K = int(rng.choice([1, 2, 5, 8, 10, 12, 16, 24]))
     D = int(rng.choice([1, 4, 50, 300]))
     mode = str(rng.choice(["default", "wide"]))
-    os.environ.pop("MMM_LDA_WIDE", None)
-    if mode == "wide": os.environ["MMM_LDA_WIDE"] = "1"
+    mmm.default_context().set_tuning(lda_build="wide" if mode == "wide" else "auto")
     try:
         X, _ = np_ref.synth_lda(D, V, K, seed=int(rng.integers(1 << 30)), mean_n=int(rng.choice([20, 400, 3000])))
     except ValueError:

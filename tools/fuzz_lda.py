@@ -16,8 +16,7 @@ for case in range(n):
     D = int(rng.choice([1, 2, 5, 37, 64, 150, 401, 1500]))
     mean_n = int(rng.choice([5, 50, 500, 5000]))
     mode = rng.choice(["default", "wide", "split"])
-    for k in ("MMM_LDA_WIDE", "MMM_LDA_MERGE"): os.environ.pop(k, None)
-    if mode == "wide": os.environ["MMM_LDA_WIDE"] = "1"
+    mmm.default_context().set_tuning(lda_build="wide" if mode == "wide" else "auto", disable=("lda_merged",) if mode == "split" else ())
     try:
         X, lam0 = np_ref.synth_lda(D, V, K, seed=int(rng.integers(1 << 30)), mean_n=mean_n)
     except ValueError:
@@ -26,7 +25,6 @@ for case in range(n):
         X[int(d)] = np.zeros((0, 2), dtype=np.int64)
     try:
         g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
-        if mode == "split": os.environ["MMM_LDA_MERGE"] = "0"      # read once per process: only the first split case decides; kept for variety
         o = oracle.LdaOracle(K, 0.1, 0.1, X, V=V, lambda0=lam0)
         it = int(rng.choice([1, 2, 5, 13]))
         ll_g = mmm.fit(g, maxiter=it, tol=0.0, verbose=False); ll_o = o.fit(maxiter=it, tol=0.0)

@@ -35,12 +35,11 @@ builds = {}
 for idx, (D, V, K, mean_n) in enumerate(TL._random_lda_shapes(N, seed + 1)):
     try:
         ref = None
-        for env in [{}, {"MMM_LDA_GRID": "3"}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_WIDE": "1"}]:
-            os.environ.update(env)
+        for env in [{}, {"grid_blocks": 3}, {"lda_build": "dense"}, {"lda_build": "wide"}]:
+            mmm.default_context().set_tuning(**env)
             X, lam0 = np_ref.synth_lda(D, V, K, seed=7000 + idx, mean_n=mean_n)
             g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
-            for k in env:
-                del os.environ[k]
+            mmm.default_context().set_tuning()
             geo = g.geometry(); key = (geo["single_step"], geo["dense"], geo["wide"], geo["L"]); builds[key] = builds.get(key, 0) + 1
             ll_g = mmm.fit(g, maxiter=6, tol=0.0, verbose=False)
             if ref is None:
@@ -51,8 +50,7 @@ for idx, (D, V, K, mean_n) in enumerate(TL._random_lda_shapes(N, seed + 1)):
             g.close()
     except Exception as e:      # noqa: BLE001
         badl += 1
-        for k in ("MMM_LDA_GRID", "MMM_LDA_DENSE", "MMM_LDA_WIDE"):
-            os.environ.pop(k, None)
+        mmm.default_context().set_tuning()
         print("LDA case %d FAILED: D=%d V=%d K=%d mean_n=%d env=%s: %s" % (idx, D, V, K, mean_n, env, str(e)[:300]))
 print("LDA: %d shapes x 4 builds, %d failures; (single_step, dense, wide, L) seen: %s" % (N, badl, sorted(builds.items())))
 # ---- restart batches: R replicas in one handle == R single fits, bit for bit (the replicas ride on grid.y of every kernel)
@@ -86,11 +84,10 @@ rng = np.random.default_rng(seed + 3)
 for idx in range(nb):
     D, K = int(rng.integers(5, 500)), int(rng.integers(1, 16))
     try:
-        for env in [{}, {"MMM_LDA_DENSE": "1"}, {"MMM_LDA_GRID": "2"}]:
-            os.environ.update(env)
+        for env in [{}, {"lda_build": "dense"}, {"grid_blocks": 2}]:
+            mmm.default_context().set_tuning(**env)
             X, g, o = TI._pair(mmm, orc, D, K, seed=9000 + idx)
-            for k in env:
-                del os.environ[k]
+            mmm.default_context().set_tuning()
             ll_g = mmm.fit(g, maxiter=8, tol=0.0, verbose=False)
             ll_o = o.fit(maxiter=8, tol=0.0)
             np.testing.assert_allclose(ll_g, ll_o, rtol=1e-9)
@@ -99,8 +96,7 @@ for idx in range(nb):
             g.close()
     except Exception as e:      # noqa: BLE001
         badi += 1
-        for k in ("MMM_LDA_GRID", "MMM_LDA_DENSE"):
-            os.environ.pop(k, None)
+        mmm.default_context().set_tuning()
         print("ILDA case %d FAILED: D=%d K=%d env=%s: %s" % (idx, D, K, env, str(e)[:300]))
 print("ILDA: %d shapes x 3 builds, %d failures" % (nb, badi))
 sys.exit(1 if bad or badl or badb or badi else 0)

@@ -18,8 +18,7 @@ python3 bench.py --gpus 2 --no-also --no-cpu-baseline > $E/bench_2ranks_one_card
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_cfg2_steps20.json 2> /dev/null
 : > $E/lda_scaling.jsonl
 for D in 10000 40000 160000 640000; do python3 bench.py --docs $D --no-cpu-baseline >> $E/lda_scaling.jsonl 2> /dev/null; done
-MMM_LDA_DENSE32=1 python3 bench.py --docs 640000 --no-cpu-baseline > $E/lda_640k_dense32.json 2> /dev/null
-MMM_LDA_DENSE=0 python3 bench.py --docs 640000 --no-cpu-baseline > $E/lda_640k_csr.json 2> /dev/null
+python3 bench.py --docs 640000 --no-cpu-baseline --lda-build sparse > $E/lda_640k_csr.json 2> /dev/null
 echo "== kernel summaries"
 cd /tmp && export TMPDIR=/tmp
 for c in 2 4 5; do
