@@ -2527,7 +2527,14 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
                    m->wide ? nullptr : m->lambda_prev.p, m->wide ? nullptr : m->expEeff_prev.p, overlap);
     if (rc) return rc;
     const int nb1 = (m->nmom + 15) / 16, nb2 = (dm.GT + 15) / 16;
+    // the side stream is joined on EVERY way out of this function once it has been forked: an early return (a failed launch, exchange or
+    // copy further down) must not leave the reduction / topic M-step in flight while the caller reads state or retries the pass
+    struct SideJoin {
+        mmm_ctx* c; bool forked = false, joined = false;
+        ~SideJoin() { if (forked && !joined) (void)hipStreamSynchronize(c->side); }
+    } side_join{ctx};
     if (overlap) {
+        side_join.forked = true;
         StreamSwap sw(ctx, ctx->side);
         MMM_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         hipLaunchKernelGGL(k_reduce_partials, dim3(nb2, sc.nrep), dim3(16, 64), 0, ctx->stream, m->mompart.p + sc.rep0 * m->grid_m * m->nmom, m->grid_m,
@@ -2565,7 +2572,7 @@ int fused_pass(mmm_ctm* m, Scope sc, int fit_flags)
     const bool fuse = !mmm_off(m->tune, MMM_OFF_CTM_FUSED_GAUSS);
     const int do_sig = (update_sigma || m->immctm) ? 1 : 0;
     if ((rc = run_mstep(m, sc, fuse ? 0 : 1, fuse ? 0 : do_sig, overlap ? 0 : 1, 1))) return rc;
-    if (overlap) MMM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (overlap) { MMM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); side_join.joined = true; }
     if ((fit_flags & MMM_FIT_AUTO_ALPHA) && (rc = run_update_alpha(m, sc))) return rc;      // MMCTM.jl:472-474
     delete mid_span; mid_span = nullptr;
     // update_props! and the log-likelihoods

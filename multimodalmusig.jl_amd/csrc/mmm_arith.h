@@ -174,4 +174,30 @@ AR_FN double ar_digamma_pos(double x)
     return ar_digamma_series(x + 7.0) - AR_DIV(dq, q);
 }
 
+/* psi(x), 0 < x < 1e40, with the table-driven log (ar_log_tab): the same recurrence and series, 20 instructions fewer.  For the LDA E-step
+ * kernels of large corpora, whose prologue (K + 1 digammas and K exps per document) is a third of their vector work; absolute error of
+ * the log (< 2.5e-15) carries over -- LDA results are compared at 1e-9, no bit-identity rests on this function. */
+AR_FN double ar_digamma_pos_tab(double x, const double* logtab)
+{
+    double q = x, dq = 1.0;
+    for (int v = 1; v < 7; ++v) {
+        const double f = x + (double)v;
+        dq = AR_FMA(dq, f, q);
+        q *= f;
+    }
+    const double y = x + 7.0;
+    double t = AR_DIV(1.0, y);
+    const double psi = ar_log_tab(y, logtab) - 0.5 * t;
+    t *= t;
+    double p = -0.4432598039215686;
+    p = AR_FMA(p, t, 0.08333333333333333);
+    p = AR_FMA(p, t, -0.021092796092796094);
+    p = AR_FMA(p, t, 0.007575757575757576);
+    p = AR_FMA(p, t, -0.004166666666666667);
+    p = AR_FMA(p, t, 0.003968253968253968);
+    p = AR_FMA(p, t, -0.008333333333333333);
+    p = AR_FMA(p, t, 0.08333333333333333);
+    return (psi - t * p) - AR_DIV(dq, q);
+}
+
 #endif /* MMM_ARITH_H */

@@ -76,7 +76,7 @@ def test_default_invocation_with_two_ranks_carries_every_configuration():
     for e in (r, st, r["also"]["cfg4"], r["also"]["cfg5"]):
         c = e["config"]
         assert c["comm_nranks_per_rank"] == [2, 2] and c["allreduce_per_rank"] == ["p2p", "p2p"] and len(c["docs_per_rank"]) == 2
-        assert 0 < e["roofline"]["frac"] < 1
+        assert 0 < e["roofline"]["frac"] < 1 and 0 < e["roofline"].get("hbm", e["roofline"])["frac"] < 1
         t = e["transports"]
         assert set(t) == {"p2p", "rccl"} and t["p2p"]["value"] > 0 and t["p2p"]["allreduce_per_rank"] == ["p2p", "p2p"] and 0 < t["p2p"]["roofline_frac_per_gpu"] < 1
         # two ranks on ONE card: RCCL refuses that, and the line must say so rather than carry a number that did not run
