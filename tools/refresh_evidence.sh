@@ -15,6 +15,7 @@ echo "== bench lines"
 python3 bench.py > $E/bench_default.json 2> $E/bench_default.err; echo "default (cfg 2 + also cfg 4, 5) done"
 for c in 4 5; do python3 bench.py --config $c > $E/bench_cfg$c.json 2> $E/bench_cfg$c.err; echo "cfg $c done"; done
 python3 bench.py --gpus 2 --no-also --no-cpu-baseline > $E/bench_2ranks_one_card.json 2> $E/bench_2ranks_one_card.err; echo "2 self-launched ranks done"
+python3 bench.py --gpus 2 > $E/bench_2ranks_one_card_default.json 2> $E/bench_2ranks_one_card_default.err; echo "2 self-launched ranks, default line done"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_cfg2_steps20.json 2> /dev/null
 : > $E/lda_scaling.jsonl
 for D in 10000 40000 160000 640000; do python3 bench.py --docs $D --no-cpu-baseline >> $E/lda_scaling.jsonl 2> /dev/null; done
