@@ -240,12 +240,10 @@ __device__ __forceinline__ void lda_chunk(const int2 tcv, const bool act, const 
 }
 
 // SINGLE: the grid covers every document with one step per wave (no step loop: 46 VGPRs less -> 3 waves per SIMD)
-// The body of the E-step kernel: block `bid` of `nblk`, its first `nthr` threads (the caller's other waves have left).  FUSED: the block is
-// part of k_lda_fused -- its partial leaves with write-through stores and, once every storing wave has waited for its stores, the block
-// publishes the launch's sequence number in eflags[bid]: the reduce blocks of the SAME launch poll for it (no kernel boundary in between).
-template <int KP, int L, bool LL, int VT, bool SINGLE, bool FUSED = false>
-__device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem, const int bid, const int nblk, const int nthr, unsigned* eflags, unsigned eseq)
+template <int KP, int L, bool LL, int VT, bool SINGLE>
+__global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 2) void k_lda_estep(EstepArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int G = MMM_WAVE / L;                   // documents per wave step
     constexpr int PRE = (96 + L - 1) / L;             // chunks prefetched into registers (covers a 96-term document)
     MMM_STAMP(0);
@@ -260,7 +258,7 @@ __device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem,
 
     const int K = a.c.K, D = a.c.D;
     const int V = VT ? VT : a.c.V;                    // VT != 0: row stride known at compile time (immediate LDS offsets)
-    const int NW = nthr >> 6;
+    const int NW = blockDim.x >> 6;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane / L, l = lane % L;
     double* sB = smem;                                   // [KP][V] exp(Elnbeta_{t-1})
@@ -271,8 +269,8 @@ __device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem,
     double* slab = sSlab + (size_t)wid * KP * V;
     double* myA = sA + ((size_t)wid * G + g) * KP;
     double* myT = sT + ((size_t)wid * G + g) * KP;
-    const int stride = nblk * NW * G;
-    int base = (bid * NW + wid) * G;
+    const int stride = gridDim.x * NW * G;
+    int base = (blockIdx.x * NW + wid) * G;
     double ll_acc = 0.0;
 
     // ---- document loads of the first step are issued before the tables are staged (latency overlap) -------------
@@ -293,10 +291,10 @@ __device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem,
     double tb[TB];
     if (SINGLE) {
 #pragma unroll
-        for (int q = 0; q < TB; ++q) { const int i = tid + q * nthr; tb[q] = (i < K * V) ? eB[i] : 0.0; }
+        for (int q = 0; q < TB; ++q) { const int i = tid + q * (int)blockDim.x; tb[q] = (i < K * V) ? eB[i] : 0.0; }
     }
-    for (int i = tid; i < NW * KP * V; i += nthr) sSlab[i] = 0.0;
-    for (int i = tid; i < KP * V; i += nthr) {
+    for (int i = tid; i < NW * KP * V; i += blockDim.x) sSlab[i] = 0.0;
+    for (int i = tid; i < KP * V; i += blockDim.x) {
         if (!SINGLE) sB[i] = (i < K * V) ? eB[i] : 0.0;
         if (LL) sBeta[i] = (i < K * V) ? bprev[i] : 0.0;
     }
@@ -380,7 +378,7 @@ __device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem,
             if (stop) return;            // a previous pass met the stopping rule: this launch must not touch the state
             if (SINGLE) {
 #pragma unroll
-                for (int q = 0; q < TB; ++q) { const int i = tid + q * nthr; if (i < KP * V) sB[i] = tb[q]; }
+                for (int q = 0; q < TB; ++q) { const int i = tid + q * (int)blockDim.x; if (i < KP * V) sB[i] = tb[q]; }
             }
             __syncthreads();
             first = false;
@@ -496,40 +494,27 @@ __device__ __forceinline__ void lda_estep_body(const EstepArgs& a, double* smem,
     if (LL) ll_acc = wave_sum(ll_acc);
     __syncthreads();
     if (LL && lane == 0) sA[wid] = ll_acc;      // sA is free now
-    double* out = a.partial + (size_t)bid * K * a.pstride;
-    for (int i = tid; i < K * V; i += nthr) {
+    double* out = a.partial + (size_t)blockIdx.x * K * a.pstride;
+    for (int i = tid; i < K * V; i += blockDim.x) {
         double v8[kMaxWavesE];
 #pragma unroll
         for (int w = 0; w < kMaxWavesE; ++w) v8[w] = (w < NW) ? sSlab[(size_t)w * KP * V + i] : 0.0;
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kMaxWavesE; ++w) s += v8[w];
-        double* dst = out + (a.pstride == V ? i : (i / V) * a.pstride + i % V);
-        if (FUSED) __hip_atomic_store((unsigned long long*)dst, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
-        else *dst = s;
-    }
-    if (FUSED) {       // every storing wave waits for its stores, the block meets, one lane publishes
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(eflags + bid, eseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[a.pstride == V ? i : (i / V) * a.pstride + i % V] = s;
     }
     if (LL) {
         __syncthreads();
         if (tid == 0) {
             double s = 0.0;
             for (int w = 0; w < NW; ++w) s += sA[w];
-            a.llpart[bid] = s;
+            a.llpart[blockIdx.x] = s;
         }
     }
     MMM_STAMP(7);
 }
 
-template <int KP, int L, bool LL, int VT, bool SINGLE>
-__global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 2) void k_lda_estep(EstepArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    lda_estep_body<KP, L, LL, VT, SINGLE>(a, smem, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, nullptr, 0u);
-}
 
 // ---- dense-row E-step (large corpora over a small vocabulary) ---------------------------------------------------------------------
 // The corpora this model is used on are dense: mutation catalogues over the 96 SNV channels list nearly every channel in every sample
