@@ -29,7 +29,9 @@ for case in range(n):
         it = int(rng.choice([1, 2, 5, 13]))
         ll_g = mmm.fit(g, maxiter=it, tol=0.0, verbose=False); ll_o = o.fit(maxiter=it, tol=0.0)
         # (V = 1: the ll is 0 up to rounding on both sides -- a relative error against 1e-16 means nothing, hence the floor on the denominator)
-        err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-12)) if len(ll_g) == len(ll_o) else np.inf
+        # (V = 1: every document is its one term, log p = 0 up to rounding on both sides -- the figure is relative to max(|ll|, 1e-3), i.e. an
+        #  ABSOLUTE 1e-12 where the ll itself is 1e-16)
+        err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-3)) if len(ll_g) == len(ll_o) else np.inf
         lam_err = np.max(np.abs(g.λ - o.lam.reshape(V, K, order="F")) / np.abs(o.lam.reshape(V, K, order="F")))
         el = abs(g.elbo - o.elbo_value) / abs(o.elbo_value)
         ok = err < 1e-9 and lam_err < 1e-8 and el < 1e-8
