@@ -23,7 +23,7 @@ def build(force=False):
     so = os.path.join(_HERE, "build", "libmmm_oracle.so")
     so_omp = os.path.join(_HERE, "build", "libmmm_oracle_omp.so")
     src = [os.path.join(_HERE, f) for f in ("mmm_oracle.c", "mmm_oracle.h", "mmm_oracle_omp.c", "mmm_twin.c")]
-    src.append(os.path.join(_HERE, "..", "multimodalmusig.jl_amd", "csrc", "mmm_arith.h"))
+    src += [os.path.join(_HERE, "..", "multimodalmusig.jl_amd", "csrc", h) for h in ("mmm_arith.h", "mmm_exptab.h", "mmm_logtab.h")]
     stale = (not os.path.exists(so)) or (not os.path.exists(so_omp)) or any(os.path.getmtime(s) > min(os.path.getmtime(so), os.path.getmtime(so_omp)) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
@@ -54,7 +54,8 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    L = C.CDLL(build())
+    # MMM_ORACLE_SO: another build of the same sources (`make -C oracle asan`, run under LD_PRELOAD=libasan.so: DESIGN section 2)
+    L = C.CDLL(os.environ.get("MMM_ORACLE_SO") or build())
     L.orc_digamma.restype = C.c_double; L.orc_digamma.argtypes = [C.c_double]
     L.orc_lgamma.restype = C.c_double; L.orc_lgamma.argtypes = [C.c_double]
     L.orc_digamma_vec.argtypes = [C.c_int, f64p, f64p]
