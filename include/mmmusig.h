@@ -90,7 +90,8 @@ enum { /* mmm_tuning_opts.disable: optimisations a test or an A/B run may switch
     MMM_OFF_CTM_CPL = 1 << 7,           /* solve phase: one coordinate per lane everywhere (no several-coordinates-per-lane builds)                */
     MMM_OFF_CTM_KFIT = 1 << 8,          /* theta phase: 16-wide topic loops for every shape                                                        */
     MMM_OFF_CTM_FUSED_GAUSS = 1 << 9,   /* Gaussian M-step as its own launch instead of block 0 of the log-likelihood launch                       */
-    MMM_OFF_CTM_LL_ROWS = 1 << 10       /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
+    MMM_OFF_CTM_LL_ROWS = 1 << 10,      /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
+    MMM_OFF_LDA_EARLY_PROLOGUE = 1 << 11 /* single-step E-step build: every pass forms its own Elntheta / exp(Elntheta) instead of the previous pass's merged launch */
 };
 typedef struct {
     int lda_build;        /* MMM_BUILD_*: E-step build of LDA / ILDA handles                                                              */

@@ -148,6 +148,8 @@ struct EstepArgs {
     int do_ll;
     int t;             // this pass (1-based); the host's count, valid unless ctl->stop is set
     int pstride;       // row stride of a block's partial: V, or V rounded up to 16 for k_lda_reduce_ll_mstep (pad entries stay 0)
+    const double* aexp; // single-step build: a = exp(Elntheta_t) [D][K], formed (with Elntheta_t) by the PREVIOUS pass's merged launch (its
+                       // prologue blocks, k_lda_reduce_ll_mstep) -- the kernel then starts at the term phase; NULL: it forms them itself
 };
 
 #ifdef MMM_DIAG_STAMPS
@@ -276,7 +278,10 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
     // ---- document loads of the first step are issued before the tables are staged (latency overlap) -------------
     int d = base + g;
     bool valid = d < D;
-    double gk = (valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
+    // ext: this pass's prologue (digamma, exp: 2 us of this kernel's 10 at BASELINE config 2, all of it on every wave's dependent chain)
+    // has run beside the previous pass's reduction, off the critical path; the same functions on the same lanes, hence the same bits
+    const bool ext = SINGLE && !LL && a.aexp != nullptr;
+    double gk = ext ? ((valid && l < K) ? a.aexp[(size_t)d * K + l] : 0.0) : ((valid && l < K) ? gam[(size_t)d * K + l] : (l < K ? 1.0 : 0.0));
     double gp = (LL && valid && l < K) ? gprev[(size_t)d * K + l] : (l < K ? 1.0 : 0.0);
     // Single-step build over padded rows (c.ell: [D][V] (term,count), (-1,0) past the document's end): the document's pairs are
     // addressed by d alone, so their loads leave with the gamma row instead of a memory round trip later (doc_ptr -> tc), every
@@ -365,11 +370,15 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             }
         }
         // ---- Elntheta (LDA.jl:78-80), a_k = exp(Elntheta_k), theta_{t-1} (LDA.jl:92-94) ------------------------------
-        const double S = group_sum<L>(gk);
-        const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
-        const double psS = __shfl(ps, g * L + K, MMM_WAVE);
-        const double el = ps - psS;
-        if (l < KP) myA[l] = (l < K) ? ar_exp(el) : 0.0;
+        double el = 0.0;
+        if (ext) { if (l < KP) myA[l] = gk; }
+        else {
+            const double S = group_sum<L>(gk);
+            const double ps = dev_digamma_pos(l < K ? gk : S);        // lane K of the group holds psi(S)
+            const double psS = __shfl(ps, g * L + K, MMM_WAVE);
+            el = ps - psS;
+            if (l < KP) myA[l] = (l < K) ? ar_exp(el) : 0.0;
+        }
         if (LL) {
             const double Sp = group_sum<L>(gp);
             if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(SINGLE ? kMaxWavesE * MMM_WAVE : 512, SINGLE ? 3 : 
             first = false;
             MMM_STAMP(2);
         } else lds_wave_sync();
-        if (valid && l < K) Eln[(size_t)d * K + l] = el;
+        if (!ext && valid && l < K) Eln[(size_t)d * K + l] = el;
         MMM_STAMP(3);
         // ---- requests of the next two steps (grid-stride build) ---------------------------------------------------------
         int2 tcn[PRE];
@@ -1054,6 +1063,11 @@ struct MergeArgs {
     int ll_join;                    // large corpora (the ll blocks loop over their documents): the reduce blocks 1.. take a share of the ll sweep
                                     // once their 16 entries are done -- the launch holds only as many blocks as are resident at once (61 of the
                                     // 256 at K = 10, V = 96 are reduce blocks, busy for ~6 us of a ~200 us sweep at 640k documents)
+    int n_ll;                       // ll blocks [nred, nred + n_ll)
+    // pro: the ll blocks also form Elntheta_{t+1} = psi(gamma_{t+1}) - psi(sum) and a = exp(Elntheta_{t+1}) (LDA.jl:78-80) of their documents
+    // for the NEXT pass's single-step E-step kernel, after their numerator has left (one step covers the corpus: n_ll x 64 >= D)
+    int pro;
+    const double* pro_gamma; double* pro_Eln; double* pro_a;
 };
 
 // P2P: several GPUs with the mailboxes up -- a reduce block sends its 16 sums to the peers and adds theirs (rank order) before the
@@ -1074,9 +1088,31 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     if ((int)blockIdx.x >= ms.nred) {        // ---- ll block: numerator of pass t-1 into its cell
         if (stop) return;
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
-        const int lb = (int)blockIdx.x - ms.nred, n_ll = (int)gridDim.x - ms.nred;
+        const int lb = (int)blockIdx.x - ms.nred, n_ll = ms.n_ll;
+        // ms.pro: the block also runs the NEXT pass's prologue for its documents (the four of each wave, 16 lanes per document as
+        // k_lda_estep<., 16, ...> has them): gamma_{t+1} is requested before the sweep and used after the block's numerator has left --
+        // the pass tail (wave 1 of block 0, the end of this launch's critical path) does not wait a cycle longer for it
+        double gnx = 0.0;
+        int pd = 0;
+        if constexpr (KP <= 12) {
+            if (ms.pro) {
+                const int lane = tid & 63, l = lane & 15;
+                pd = (lb * 16 + (tid >> 6)) * 4 + (lane >> 4);
+                gnx = (pd < c.D && l < c.K) ? ms.pro_gamma[(size_t)pd * c.K + l] : (l < c.K ? 1.0 : 0.0);
+            }
+        }
         lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nred - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
         MMM_RSTAMP((int)blockIdx.x == ms.nred && tid == 0, 17);
+        if constexpr (KP <= 12) {
+            if (ms.pro) {          // Elntheta_{t+1}, exp(Elntheta_{t+1}) (LDA.jl:78-80): the operations of the E-step kernel's prologue
+                const int lane = tid & 63, g = lane >> 4, l = lane & 15, K = c.K;
+                const double S = group_sum<16>(gnx);
+                const double ps = dev_digamma_pos(l < K ? gnx : S);        // lane K of the group holds psi(S)
+                const double psS = __shfl(ps, g * 16 + K, MMM_WAVE);
+                const double el = ps - psS;
+                if (pd < c.D && l < K) { ms.pro_Eln[(size_t)pd * K + l] = el; ms.pro_a[(size_t)pd * K + l] = ar_exp(el); }
+            }
+        }
         return;
     }
     // ---- reduce block: 16 entries of the statistics (as lda_reduce_block)
@@ -1166,12 +1202,12 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     }
     if (ms.ll_join && rb > 0) {              // (uniform per block; block 0 keeps the pass tail)
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
-        const int n_ll = (int)gridDim.x - ms.nred, lb = n_ll + rb - 1;
+        const int n_ll = ms.n_ll, lb = n_ll + rb - 1;
         lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + ms.nred - 1, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
         return;
     }
     if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
-        const int lane = tid & 63, n_ll = (int)gridDim.x - ms.nred + (ms.ll_join ? ms.nred - 1 : 0);
+        const int lane = tid & 63, n_ll = ms.n_ll + (ms.ll_join ? ms.nred - 1 : 0);
         // what the tail needs from memory is fetched before the wait, not after it (lda_pass_tail's dependent loads)
         const int n = r.ctl->n_hist;
         const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
@@ -2147,6 +2183,8 @@ struct mmm_lda {
     DevBuf<int64_t> term_ptr;           // wide: the postings of term v are tpost[term_ptr[v] .. term_ptr[v+1])
     DevBuf<int2> tpost;                 // (document, count), documents ascending within a term
     DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x KP, written by the document sweep for the term sweep
+    DevBuf<double> aexp_next;           // single-step build: exp(Elntheta_{t+1}), D x K, written by the merged launch of pass t (its prologue blocks)
+    int aexp_for = -1;                  // the pass whose Elntheta / aexp_next the last merged launch of THIS call has formed (prepare_call resets it)
     DevBuf<double> tabT;                // wide: [2][V][KP] term-major copies of the pass's exp(Elnbeta) and beta tables
     int stats_waves = 1;                // waves per term block of k_lda_stats_terms
     bool attr_big = false, attr_bigs = false;
@@ -2503,6 +2541,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (mmm_off(m->tune, MMM_OFF_LDA_PADDED_ROWS)) { edev.ell = nullptr; edev.dense = nullptr; edev.dense16 = nullptr; }
         EstepArgs a{edev, m->ctl.p, m->ring(m->gamma), m->ring(m->Elntheta), m->ring(m->expElnbeta), m->ring(m->beta),
                     m->partial.p, m->llpart.p, ll_in_k2 ? 0 : do_ll, t, merged ? Vp : m->V};
+        if (m->aexp_for == t) a.aexp = m->aexp_next.p;       // the previous pass's merged launch has run this pass's prologue
         {   // the E-step kernel is idempotent (it reads pass t's inputs and overwrites pass t's outputs), so a profiled span may
             // hold it several times: (span with 2 launches) - (span with 1) is the kernel's duration free of the event overhead
             ProfSpan span(ctx);
@@ -2516,6 +2555,12 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             const size_t lds = lds_red;
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred, 0};
             ms.ll_join = (!mmm_off(m->tune, MMM_OFF_LDA_LL_JOIN) && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + nred - 1 <= 512) ? 1 : 0;
+            ms.n_ll = r.n_ll;
+            // The next pass's prologue beside this pass's reduction, in the ll blocks: single-step build (every wave of the E-step kernel walks
+            // its chain once, the prologue is 2 us of it), every document in exactly one ll block's single step, plain LDA
+            ms.pro = (m->single_step && !m->ilda && m->KP <= 12 && m->L == 16 && m->aexp_next.p && r.n_ll > 0 && !ms.ll_join &&
+                      (int64_t)r.n_ll * docs_per_ll_block >= (int64_t)m->D && !mmm_off(m->tune, MMM_OFF_LDA_EARLY_PROLOGUE)) ? 1 : 0;
+            ms.pro_gamma = m->gamma[(t + 1) % 3].p; ms.pro_Eln = m->Elntheta[(t + 1) % 3].p; ms.pro_a = m->aexp_next.p;
             const int c3 = t % 3;
             IldaMerge im{};
             if (m->ilda) im = IldaMerge{m->ids, m->ilam[c3].p, m->iEln[c3].p, m->ibeta[c3].p, m->fcells.p};
@@ -2526,6 +2571,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
                 hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms, im);
             })
             MMM_LAUNCH_CHECK(ctx);
+            m->aexp_for = ms.pro ? t + 1 : -1;
             if (do_ll) m->n_hist++;
             m->t = t;
             m->ll_pending = true;
@@ -2621,6 +2667,7 @@ int prepare_call(mmm_lda* m)
 {
     if (int rc = mmm_ctx_usable(m->ctx, "LDA call")) return rc;
     MMM_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    m->aexp_for = -1;      // whatever this call does to the state, its first pass forms its own prologue
     return sync_ctl(m);
 }
 
@@ -2774,6 +2821,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const size_t VKp = (size_t)((V + 15) & ~15) * K;       // rows padded to 16 (k_lda_reduce_ll_mstep)
     A(partial, wide ? 1 : (size_t)m->grid_e * VKp); A(stats[0], VKp + 16); A(stats[1], VKp + 16); A(scratch, VK + 16); A(llpart, (size_t)grid_max); A(llpart2, 1024); A(elbopart, (size_t)m->grid_s * 5 + 8);
     A(ctl, 1); A(cells, 2 * 1024);
+    if (m->single_step && !ilda) A(aexp_next, KD);
     if (ilda) {
         A(fcells, (size_t)2 * 512 * 16);
         A(features, (size_t)I * V);

@@ -191,6 +191,32 @@ def test_config_2_at_its_own_size_against_the_oracle(mmm, oracle):
     assert g2.elbo == pytest.approx(o2.elbo_value, rel=1e-7)
 
 
+@pytest.mark.parametrize("D,K", [(10000, 10), (4000, 7), (12000, 12), (300, 4)])
+def test_prologue_beside_the_previous_reduction_changes_no_bit(mmm, tuning, D, K):
+    """Single-step build: Elntheta_{t+1} and exp(Elntheta_{t+1}) are formed by extra blocks of pass t's merged launch (same functions, same
+    lanes) and the E-step kernel of pass t+1 starts at its term phase.  Against the build in which every pass forms its own
+    (MMM_OFF_LDA_EARLY_PROLOGUE): every bit of ll, gamma, lambda, Elntheta, phi equal -- over passes enqueued in one call, over calls
+    (the first pass of a call always forms its own), and when the stopping rule ends the fit in mid-chunk."""
+    V = 96
+    X, lam0 = np_ref.synth_lda(D, V, K, seed=77 + K)
+    res = []
+    for off in (False, True):
+        tuning(disable=("lda_early_prologue",) if off else ())
+        g = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+        assert g.geometry()["single_step"] == 1
+        mmm.lib().mmm_lda_iterate(g._h, 5)
+        g1 = g.γ.copy()
+        mmm.lib().mmm_lda_iterate(g._h, 1); mmm.lib().mmm_lda_iterate(g._h, 7)
+        st = (g1, g.γ.copy(), g.λ.copy(), g.Elnθ.copy(), g.phi_flat().copy())
+        g2 = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
+        ll = mmm.fit(g2, maxiter=200, tol=1e-4, verbose=False)
+        res.append(st + (np.asarray(ll), g2.γ.copy(), g2.λ.copy(), g2.Elnθ.copy(), np.float64(g2.elbo)))
+        tuning()
+    assert len(res[0][5]) < 200          # the rule fired
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("D,V,K", [(70, 50, 16), (50, 96, 20), (40, 30, 32), (45, 96, 13)])
 def test_wide_topic_counts_use_wider_lane_groups(mmm, oracle, tuning, D, V, K):
     """K >= 16 runs 32- or 64-lane document groups (K + 1 lanes are needed for the digamma step); K = 13 pads to KP = 16.
