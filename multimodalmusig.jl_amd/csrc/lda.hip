@@ -800,7 +800,10 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     // the first step's document loads go out before the table is staged (as in the E-step kernel).  (Splitting a document
     // group's chunks over 2 or 4 waves -- more, lighter blocks on the CUs the reduction leaves idle -- was slower: 29.7 / 33.6
     // vs 26.6 us per iteration; the launch is bound by block dispatch and table staging, not by the sweep's arithmetic.)
-    const int wslot = lb * 16 + wid, nslots = nlb * 16;
+    // wave w of block lb is wave slot w * nlb + lb: the documents fill wave 0 of every block, then wave 1, ... -- a corpus of fewer
+    // than 64 nlb documents leaves every block the same number of busy waves (the sweep is issue-bound per CU: 157 blocks of 16 busy
+    // waves were 0.6 us slower at BASELINE config 2 than 192 blocks of 13)
+    const int wslot = wid * nlb + lb, nslots = nlb * 16;
     int base = wslot * G;
     int d = base + g;
     bool valid = d < D;
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         if constexpr (KP <= 12) {
             if (ms.pro) {
                 const int lane = tid & 63, l = lane & 15;
-                pd = (lb * 16 + (tid >> 6)) * 4 + (lane >> 4);
+                pd = ((tid >> 6) * n_ll + lb) * 4 + (lane >> 4);          // lda_ll_block's wave slots
                 gnx = (pd < c.D && l < c.K) ? ms.pro_gamma[(size_t)pd * c.K + l] : (l < c.K ? 1.0 : 0.0);
             }
         }
@@ -2521,7 +2524,10 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
         const int docs_per_ll_block = 16 * (MMM_WAVE / (m->KP <= 15 ? 16 : (m->KP <= 31 ? 32 : 64)));
-        r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((m->D + docs_per_ll_block - 1) / docs_per_ll_block, 512)) : 0;
+        // as many ll blocks as can be resident beside the reduce blocks (cut to the launch's residency below), at least one busy wave each
+        const int waves_ll = (m->D + docs_per_ll_block / 16 - 1) / (docs_per_ll_block / 16);
+        const int blocks_ll = (m->D + docs_per_ll_block - 1) / docs_per_ll_block;      // split launches (no residency bound): full blocks
+        r.n_ll = (ll_in_k2 && do_ll) ? std::max(1, std::min((merged || via_cells) ? waves_ll : blocks_ll, 512)) : 0;
         if (!merged && via_cells && r.n_ll > 0) {      // RCCL transport: wave 1 of reduce block 0 waits for the ll blocks' cells
             if (m->cap_m < 0) {
                 MMM_KP_SWITCH(m, {
