@@ -241,8 +241,11 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         const double q = dev_div(grad * sigma, v);
         double dx = dev_div(q * sigma, -1.0 - dev_sqrt(fabs(1.0 - q * q)));
         double xc = x + dx;
-        if (has_lb && xc < lb) xc = lb;
-        if (xc > x + 0.9 * sigma) xc = x + 0.9 * sigma; else if (xc < x - 0.9 * sigma) xc = x - 0.9 * sigma;
+        // the three clamps by v_max / v_min (one instruction each instead of a compare and two selects): the same value as NLopt's
+        // `if (xc < lb) xc = lb; ...` for every finite xc (lo <= hi; a NaN candidate, which only a non-finite objective produces, would be
+        // replaced by the bound instead of kept)
+        if (has_lb) xc = dev_max_raw(xc, lb);
+        xc = dev_min_raw(dev_max_raw(xc, x - 0.9 * sigma), x + 0.9 * sigma);
         if (!act) xc = x;
         dx = xc - x;
         const double dx2 = dx * dx;
@@ -943,16 +946,18 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
             const double qq = dev_div(grad[q] * sigma[q], v);                 // = u / (v sigma) of NLopt's formula; u / v = qq sigma (see mma_group)
             double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
             double c = x[q] + dx;
-            c = (has_lb && c < lb) ? lb : c;
+            if (has_lb) c = dev_max_raw(c, lb);                  // (the clamps by v_max / v_min: see mma_group)
             const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
-            c = c > hi ? hi : (c < lo ? lo : c);
+            c = dev_min_raw(dev_max_raw(c, lo), hi);
             c = (fresh || ((CplGeom<MKT, LPD>::ACT < LPD) && !obj.on)) ? x[q] : c;      // a new document: evaluate its start point; a lane without coordinates stays at 0
             xcur[q] = c;
             dx = c - x[q];
             const double dx2 = dx * dx;
             const double denominv = dev_div(1.0, sigma2 - dx2);
-            gls += (grad[q] * (sigma2 * dx) + (fabs(grad[q]) * sigma[q] + 0.5 * rho) * dx2) * denominv;
-            wls += 0.5 * dx2 * denominv;
+            // (q = 0 assigns: 0 + t = t in every bit but the sign of a zero, which no comparison below can see)
+            const double gt = (grad[q] * (sigma2 * dx) + (fabs(grad[q]) * sigma[q] + 0.5 * rho) * dx2) * denominv, wt = 0.5 * dx2 * denominv;
+            gls = q == 0 ? gt : gls + gt;
+            wls = q == 0 ? wt : wls + wt;
             if (SB) __builtin_amdgcn_sched_barrier(0);       // one coordinate at a time (the interleaved chains of all coordinates need more registers)
         }
         const double gval = fbest + qsum<LPD>(gls);

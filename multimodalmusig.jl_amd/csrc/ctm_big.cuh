@@ -174,8 +174,8 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
                 const double qq = dev_div(grad[q] * sigma[q], v);             // see mma_group (ctm.hip): one quotient for u / (v sigma) and u / v
                 double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
                 double c = x[q] + dx;
-                if (has_lb && c < lb) c = lb;
-                if (c > x[q] + 0.9 * sigma[q]) c = x[q] + 0.9 * sigma[q]; else if (c < x[q] - 0.9 * sigma[q]) c = x[q] - 0.9 * sigma[q];
+                if (has_lb) c = dev_max_raw(c, lb);                  // (the clamps by v_max / v_min: see mma_group)
+                c = dev_min_raw(dev_max_raw(c, x[q] - 0.9 * sigma[q]), x[q] + 0.9 * sigma[q]);
                 xc[q] = c;
                 dx = c - x[q];
                 const double dx2 = dx * dx;
