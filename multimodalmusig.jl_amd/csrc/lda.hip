@@ -803,7 +803,8 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
     // wave w of block lb is wave slot w * nlb + lb: the documents fill wave 0 of every block, then wave 1, ... -- a corpus of fewer
     // than 64 nlb documents leaves every block the same number of busy waves (the sweep is issue-bound per CU: 157 blocks of 16 busy
     // waves were 0.6 us slower at BASELINE config 2 than 192 blocks of 13)
-    const int wslot = wid * nlb + lb, nslots = nlb * 16;
+    // (corpora of more than one step per wave keep a block's waves on neighbouring documents)
+    const int wslot = ((int64_t)nlb * 16 * G >= (int64_t)D) ? wid * nlb + lb : lb * 16 + wid, nslots = nlb * 16;
     int base = wslot * G;
     int d = base + g;
     bool valid = d < D;

@@ -2,7 +2,8 @@
 # Regenerates the measured evidence of profiles/ for the current build on the GPU box (one MI355X): bench lines, rocprofv3 kernel summaries,
 # counter passes.  Everything lands under gpurun_out/evidence/; tools/collect_evidence.py then copies the summaries into profiles/.
 # usage (on the GPU box, from the repository root): bash tools/refresh_evidence.sh [bench|pmc]
-# optional argument: "bench" (bench lines + kernel summaries), "pmc" (counter passes + their summaries) or nothing (both; > 20 minutes)
+# optional argument: "bench" (bench lines + kernel summaries), "pmc" (counter passes + their summaries) or nothing (counters first, then the bench
+# lines, which attach them; > 20 minutes)
 set -u
 STAGE=${1:-all}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -10,23 +11,6 @@ E=$R/gpurun_out/evidence
 P=$E/pmc
 mkdir -p $E
 cd $R
-if [ "$STAGE" != "pmc" ]; then
-echo "== bench lines"
-python3 bench.py > $E/bench_default.json 2> $E/bench_default.err; echo "default (cfg 2 + also cfg 4, 5) done"
-for c in 4 5; do python3 bench.py --config $c > $E/bench_cfg$c.json 2> $E/bench_cfg$c.err; echo "cfg $c done"; done
-python3 bench.py --gpus 2 --no-also --no-cpu-baseline > $E/bench_2ranks_one_card.json 2> $E/bench_2ranks_one_card.err; echo "2 self-launched ranks done"
-python3 bench.py --gpus 2 > $E/bench_2ranks_one_card_default.json 2> $E/bench_2ranks_one_card_default.err; echo "2 self-launched ranks, default line done"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_cfg2_steps20.json 2> /dev/null
-: > $E/lda_scaling.jsonl
-for D in 10000 40000 160000 640000; do python3 bench.py --docs $D --no-cpu-baseline >> $E/lda_scaling.jsonl 2> /dev/null; done
-python3 bench.py --docs 640000 --no-cpu-baseline --lda-build sparse > $E/lda_640k_csr.json 2> /dev/null
-echo "== kernel summaries"
-cd /tmp && export TMPDIR=/tmp
-for c in 2 4 5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $E/ks_cfg$c -o cfg$c -- python3 $R/bench.py --config $c --no-cpu-baseline --no-also --repeats 3 > $E/ks_cfg$c.json 2> $E/ks_cfg$c.err
-done
-rocprofv3 --kernel-trace --stats --output-format csv -d $E/ks_lda640k -o lda640k -- python3 $R/bench.py --docs 640000 --no-cpu-baseline --repeats 3 > $E/ks_lda640k.json 2> $E/ks_lda640k.err
-fi
 if [ "$STAGE" != "bench" ]; then
 echo "== counter passes"
 cd $R
@@ -47,6 +31,26 @@ python3 tools/pmc_summary.py $P cfg4 k_ctm_moments > $E/pmc_cfg4_moments.txt
 python3 tools/pmc_summary.py $P cfg5 k_ctm_solve_cpl --json $E/traffic_ctm_solve_cfg5.json > $E/pmc_cfg5_solve.txt
 python3 tools/pmc_summary.py $P cfg5 "k_ctm_theta_dense<10, 6>" > $E/pmc_cfg5_theta.txt
 python3 tools/pmc_summary.py $P cfg5 k_ctm_loglik > $E/pmc_cfg5_loglik.txt
+# the bench lines below attach a counter file only if it sits under profiles/ and its hash matches the sources: copy the fresh summaries there first
+rm -rf $P/*/
+python3 tools/collect_evidence.py > /dev/null 2>&1
+fi
+if [ "$STAGE" != "pmc" ]; then
+echo "== bench lines"
+python3 bench.py > $E/bench_default.json 2> $E/bench_default.err; echo "default (cfg 2 + also cfg 4, 5) done"
+for c in 4 5; do python3 bench.py --config $c > $E/bench_cfg$c.json 2> $E/bench_cfg$c.err; echo "cfg $c done"; done
+python3 bench.py --gpus 2 --no-also --no-cpu-baseline > $E/bench_2ranks_one_card.json 2> $E/bench_2ranks_one_card.err; echo "2 self-launched ranks done"
+python3 bench.py --gpus 2 > $E/bench_2ranks_one_card_default.json 2> $E/bench_2ranks_one_card_default.err; echo "2 self-launched ranks, default line done"
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_cfg2_steps20.json 2> /dev/null
+: > $E/lda_scaling.jsonl
+for D in 10000 40000 160000 640000; do python3 bench.py --docs $D --no-cpu-baseline >> $E/lda_scaling.jsonl 2> /dev/null; done
+python3 bench.py --docs 640000 --no-cpu-baseline --lda-build sparse > $E/lda_640k_csr.json 2> /dev/null
+echo "== kernel summaries"
+cd /tmp && export TMPDIR=/tmp
+for c in 2 4 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $E/ks_cfg$c -o cfg$c -- python3 $R/bench.py --config $c --no-cpu-baseline --no-also --repeats 3 > $E/ks_cfg$c.json 2> $E/ks_cfg$c.err
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $E/ks_lda640k -o lda640k -- python3 $R/bench.py --docs 640000 --no-cpu-baseline --repeats 3 > $E/ks_lda640k.json 2> $E/ks_lda640k.err
 fi
 # the raw counter tables are large: only the summaries travel back
 rm -rf $P/*/ $E/ks_*/*_kernel_trace.csv $E/ks_*/*agent_info.csv $E/ks_*/*domain_stats.csv
