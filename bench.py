@@ -380,7 +380,9 @@ def csrc_sha16(model):
     """hash of the sources the kernels of one model family are built from (the counter files record it, tools/pmc_summary.py)"""
     import hashlib
     d = os.path.join(ROOT, "multimodalmusig.jl_amd", "csrc")
-    files = ["dev_math.h", "mmm_arith.h", "mmm_logtab.h", "mmm_internal.h"] + (["lda.hip"] if model == "lda" else ["ctm.hip", "ctm_big.cuh"])
+    import glob
+    files = ["dev_math.h", "mmm_arith.h", "mmm_logtab.h", "mmm_exptab.h", "mmm_internal.h"] + sorted(
+        os.path.basename(f) for f in glob.glob(os.path.join(d, ("lda" if model == "lda" else "ctm") + "*.[hc]*")))      # lda.hip + lda_*.cuh | ctm.hip + ctm_*.cuh
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(d, f), "rb") as fh:

@@ -210,7 +210,11 @@ def test_prologue_beside_the_previous_reduction_changes_no_bit(mmm, tuning, D, K
         st = (g1, g.γ.copy(), g.λ.copy(), g.Elnθ.copy(), g.phi_flat().copy())
         g2 = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)
         ll = mmm.fit(g2, maxiter=200, tol=1e-4, verbose=False)
-        res.append(st + (np.asarray(ll), g2.γ.copy(), g2.λ.copy(), g2.Elnθ.copy(), np.float64(g2.elbo)))
+        g3 = mmm.LDA(K, 0.1, 0.1, V, X, λ0=lam0)          # a fit that ends by maxiter, its ELBO, then more passes on the same handle
+        mmm.fit(g3, maxiter=6, tol=0.0, verbose=False)
+        e3 = np.float64(g3.elbo)
+        mmm.lib().mmm_lda_iterate(g3._h, 3)
+        res.append(st + (np.asarray(ll), g2.γ.copy(), g2.λ.copy(), g2.Elnθ.copy(), np.float64(g2.elbo), e3, g3.γ.copy(), g3.Elnθ.copy(), g3.λ.copy()))
         tuning()
     assert len(res[0][5]) < 200          # the rule fired
     for a, b in zip(*res):
