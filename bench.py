@@ -557,10 +557,13 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
             # registers, the topic table (7.7 KB) is L2-resident and excluded.  (The ll of the previous pass, which re-reads X and
             # gamma_{t-1}, runs in extra blocks of the reduce launch and is not part of this kernel.)
             # As implemented the kernel may read rows of counts instead of (term,count) pairs: 16 SL slots of 2 or 4 bytes per document.
-            algo_bytes = 8.0 * nnz + 24.0 * K * D
             geo = model.geometry()
+            # single-step build since round 4: Elntheta_t / exp(Elntheta_t) are formed inside the PREVIOUS pass's merged launch; this kernel reads
+            # exp(Elntheta_t) and writes gamma_{t+1} -- 2 x 8 B x K per document; the gamma_t read and the Elntheta_t write are the other launch's
+            per_doc = 16.0 if geo.get("prologue_moved") else 24.0
+            algo_bytes = 8.0 * nnz + per_doc * K * D
             row_bytes = geo.get("row_bytes", 0)
-            impl_bytes = (float(row_bytes) * D if row_bytes else 8.0 * nnz) + 24.0 * K * D
+            impl_bytes = (float(row_bytes) * D if row_bytes else 8.0 * nnz) + per_doc * K * D
             kname = ("k_lda_estep_dense%s<%d,%d> (rows of counts)" % ("32" if geo["dense"] == 2 else "", geo["KP"], geo["SL"] // (2 if geo["dense"] == 2 else 1))) if geo["dense"] else \
                     ("k_lda_estep<%d,%d,..,%s>" % (geo["KP"], geo["L"], "single step" if geo["single_step"] else "grid stride"))
             achieved = algo_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -571,8 +574,10 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
                                "algorithmic_bytes_per_launch": algo_bytes,
                                "algorithmic_bytes_as_implemented": impl_bytes, "achieved_as_implemented": achieved_impl,
                                "frac_as_implemented": achieved_impl / HBM_PEAK_GBS,
-                               "bytes_model": "SURVEY 8d: 8 B x nnz + 24 B x K x D.  As implemented: %s + 24 B x K x D" %
-                                              (("%d B per document (rows of counts / padded rows)" % row_bytes) if row_bytes else "8 B x nnz"),
+                               "bytes_model": "SURVEY 8d: 8 B x nnz + %d B x K x D%s.  As implemented: %s + %d B x K x D" %
+                                              (int(per_doc), " (exp(Elntheta_t) read, gamma_{t+1} written; the gamma_t read and the Elntheta_t write moved into the "
+                                               "previous pass's merged launch with the prologue: not this kernel's bytes)" if per_doc == 16.0 else "",
+                                               ("%d B per document (rows of counts / padded rows)" % row_bytes) if row_bytes else "8 B x nnz", int(per_doc)),
                                "event_span_1_launch_us": span1, "event_span_2_launches_us": span2,
                                "timing": "HIP events on the library's stream around the kernel, in repeats of the timed K steps: span with two "
                                          "back-to-back launches minus span with one (an event pair around a single launch adds ~4 us)"}

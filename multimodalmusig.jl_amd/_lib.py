@@ -76,6 +76,7 @@ _SIGS = {
     "mmm_lda_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_lda_geometry": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "mmm_lda_row_bytes": (C.c_int, [vp]),
+    "mmm_lda_prologue_moved": (C.c_int, [vp]),
     "mmm_lda_fit": (C.c_int, [vp, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "mmm_solver_opts_default": (None, [C.POINTER(SolverOpts)]),
     "mmm_lda_infer": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1210,6 +1210,8 @@ int mmm_lda_row_bytes(const mmm_lda* m)
     return 0;
 }
 
+int mmm_lda_prologue_moved(const mmm_lda* m) { return (m && m->aexp_for >= 0) ? 1 : 0; }
+
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)
 {
     if (!m || !n) return MMM_ERR_ARG;

@@ -134,7 +134,7 @@ class LDA:
         g = (C.c_int * 8)()
         check(lib().mmm_lda_geometry(self._h, g), self.ctx.h, "geometry")
         return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "single_step": g[3], "wide": g[4], "dense": g[5], "SL": g[6], "KP": g[7],
-                "row_bytes": int(lib().mmm_lda_row_bytes(self._h))}
+                "row_bytes": int(lib().mmm_lda_row_bytes(self._h)), "prologue_moved": int(lib().mmm_lda_prologue_moved(self._h))}
 
     def close(self):
         if self._h:

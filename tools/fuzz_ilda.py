@@ -38,7 +38,7 @@ for case in range(n):
         ll_g = mmm.fit(g, maxiter=it, tol=0.0, verbose=False); ll_o = o.fit(maxiter=it, tol=0.0)
         err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-300))
         le = max(np.max(np.abs(g.λ[i] - o.mat(o.lam, i)) / np.abs(o.mat(o.lam, i))) for i in range(I))
-        el = abs(g.elbo - o.elbo_value) / abs(o.elbo_value)
+        el = abs(g.elbo - o.elbo_value) / max(abs(o.elbo_value), 1e-3)
         ok = err < 1e-9 and le < 1e-7 and el < 1e-8
         g.close()
     except Exception as e:      # noqa: BLE001

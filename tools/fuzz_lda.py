@@ -33,7 +33,7 @@ for case in range(n):
         #  ABSOLUTE 1e-12 where the ll itself is 1e-16)
         err = np.max(np.abs(ll_g - ll_o) / np.maximum(np.abs(ll_o), 1e-3)) if len(ll_g) == len(ll_o) else np.inf
         lam_err = np.max(np.abs(g.λ - o.lam.reshape(V, K, order="F")) / np.abs(o.lam.reshape(V, K, order="F")))
-        el = abs(g.elbo - o.elbo_value) / abs(o.elbo_value)
+        el = abs(g.elbo - o.elbo_value) / max(abs(o.elbo_value), 1e-3)      # (V = K = 1: every ELBO term is exactly 0)
         ok = err < 1e-9 and lam_err < 1e-8 and el < 1e-8
         g.close()
     except Exception as e:      # noqa: BLE001
