@@ -207,8 +207,9 @@ int mmm_lda_geometry(const mmm_lda* m, int out[8]);
  * slots per lane; padded (term,count) rows: 8 x V); 0 when it sweeps the CSR arrays (8 bytes per nonzero + offsets).  bench.py's
  * "algorithmic bytes as implemented". */
 int mmm_lda_row_bytes(const mmm_lda* m);
-/* 1 when the most recent fused pass formed the NEXT pass's Elntheta / exp(Elntheta) inside its merged launch (single-step build: the E-step
- * kernel of a pass then reads exp(Elntheta) and writes gamma only -- bench.py counts its bytes accordingly), else 0. */
+/* 1 once fused passes of this handle have formed the NEXT pass's Elntheta / exp(Elntheta) inside their merged launch (single-step build: the
+ * E-step kernel of every pass but the first of a call then reads exp(Elntheta) and writes gamma only -- bench.py counts its bytes
+ * accordingly), else 0. */
 int mmm_lda_prologue_moved(const mmm_lda* m);
 /* fit!(model; maxiter, tol) -- LDA.jl:198-224: iterate until |dll|/|ll| < tol after > 10 passes, then ELBO. */
 int mmm_lda_fit(mmm_lda* m, int maxiter, double tol, double* ll_hist, int* n_iter, int* converged,

@@ -232,6 +232,7 @@ struct mmm_lda {
     DevBuf<double> aexp;                // wide: exp(Elntheta_t), D x KP, written by the document sweep for the term sweep
     DevBuf<double> aexp_next;           // single-step build: exp(Elntheta_{t+1}), D x K, written by the merged launch of pass t (its prologue blocks)
     int aexp_for = -1;                  // the pass whose Elntheta / aexp_next the last merged launch of THIS call has formed (prepare_call resets it)
+    bool pro_used = false;              // some merged launch of this handle has run a next pass's prologue (mmm_lda_prologue_moved)
     DevBuf<double> tabT;                // wide: [2][V][KP] term-major copies of the pass's exp(Elnbeta) and beta tables
     int stats_waves = 1;                // waves per term block of k_lda_stats_terms
     bool attr_big = false, attr_bigs = false;
@@ -622,6 +623,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             })
             MMM_LAUNCH_CHECK(ctx);
             m->aexp_for = ms.pro ? t + 1 : -1;
+            if (ms.pro) m->pro_used = true;
             if (do_ll) m->n_hist++;
             m->t = t;
             m->ll_pending = true;
@@ -1210,7 +1212,7 @@ int mmm_lda_row_bytes(const mmm_lda* m)
     return 0;
 }
 
-int mmm_lda_prologue_moved(const mmm_lda* m) { return (m && m->aexp_for >= 0) ? 1 : 0; }
+int mmm_lda_prologue_moved(const mmm_lda* m) { return (m && m->pro_used) ? 1 : 0; }
 
 int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)
 {
