@@ -565,6 +565,10 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             // every reduce block waits for the blocks of its topic, wave 1 of block 0 for the ll blocks: all of them must fit
             if (cap < (Vp * m->K + 15) / 16 + 1) merged = false;
         }
+        // Single-step build: two logical reduce blocks (16 entries each) per physical block.  The launch is bounded by its ll blocks, whose
+        // sweep is issue-bound per SIMD: at BASELINE config 2, 60 + 192 resident blocks leave 13 busy waves per ll block (one SIMD with four),
+        // 30 + 209 leave 12 (three everywhere) -- merged launch 7.7 -> 6.8 us (measured at 9,216 documents before this was built)
+        const int epb = (merged && m->single_step && !m->ilda && ((Vp * m->K) / 16) % 2 == 0) ? 2 : 1;
         if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
@@ -584,7 +588,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             cap = m->cap_m;
         }
         if (r.n_ll > 0 && (merged || via_cells)) {
-            const int nred_ = (r.VK + 15) / 16;
+            const int nred_ = ((r.VK + 15) / 16) / (merged ? epb : 1);
             if (cap - nred_ < 1) return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "LDA: the reduce launch cannot hold its %d reduce blocks and one ll block at once (%d resident)", nred_, cap);
             r.n_ll = std::min(r.n_ll, cap - nred_);       // the ll blocks stride over the documents: fewer blocks, same sums per block id
         }
@@ -605,7 +609,8 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         if (merged) {
             const size_t lds = lds_red;
             MergeArgs ms{m->V, m->eta, m->ring(m->lambda), m->ring(m->Elnbeta), m->ring(m->expElnbeta), m->ring(m->beta), m->cells.p, ++m->kseq, nred, 0};
-            ms.ll_join = (!mmm_off(m->tune, MMM_OFF_LDA_LL_JOIN) && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + nred - 1 <= 512) ? 1 : 0;
+            ms.epb = epb; ms.nredp = nred / epb;
+            ms.ll_join = (!mmm_off(m->tune, MMM_OFF_LDA_LL_JOIN) && r.n_ll > 0 && (int64_t)m->D > (int64_t)r.n_ll * docs_per_ll_block && r.n_ll + ms.nredp - 1 <= 512) ? 1 : 0;
             ms.n_ll = r.n_ll;
             // The next pass's prologue beside this pass's reduction, in the ll blocks: single-step build (every wave of the E-step kernel walks
             // its chain once, the prologue is 2 us of it), every document in exactly one ll block's single step, plain LDA
@@ -619,7 +624,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
                 auto k = m->ilda ? k_lda_reduce_ll_mstep<KPV, false, true> : (r.p2p ? k_lda_reduce_ll_mstep<KPV, true, false> : k_lda_reduce_ll_mstep<KPV, false, false>);
                 const int ai = m->ilda ? 2 : r.p2p;
                 if (!m->attr_mm[ai]) { if ((rc = set_lds(ctx, k, lds))) return rc; m->attr_mm[ai] = true; }
-                hipLaunchKernelGGL(k, dim3(nred + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms, im);
+                hipLaunchKernelGGL(k, dim3(ms.nredp + r.n_ll), dim3(16, 64), lds, ctx->stream, r, m->dev(), m->gamma[(t + 2) % 3].p, m->beta[(t + 2) % 3].p, ms, im);
             })
             MMM_LAUNCH_CHECK(ctx);
             m->aexp_for = ms.pro ? t + 1 : -1;

@@ -344,7 +344,8 @@ struct MergeArgs {
     int ll_join;                    // large corpora (the ll blocks loop over their documents): the reduce blocks 1.. take a share of the ll sweep
                                     // once their 16 entries are done -- the launch holds only as many blocks as are resident at once (61 of the
                                     // 256 at K = 10, V = 96 are reduce blocks, busy for ~6 us of a ~200 us sweep at 640k documents)
-    int n_ll;                       // ll blocks [nred, nred + n_ll)
+    int n_ll;                       // ll blocks [nredp, nredp + n_ll)
+    int epb, nredp;                 // logical reduce blocks (16 entries) per physical block: 1 or 2; physical reduce blocks = nred / epb
     // pro: the ll blocks also form Elntheta_{t+1} = psi(gamma_{t+1}) - psi(sum) and a = exp(Elntheta_{t+1}) (LDA.jl:78-80) of their documents
     // for the NEXT pass's single-step E-step kernel, after their numerator has left (one step covers the corpus: n_ll x 64 >= D)
     int pro;
@@ -360,16 +361,16 @@ template <int KP, bool P2P, bool ILDA>
 __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaDev c, const double* gprev, const double* bprev, MergeArgs ms, IldaMerge im)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double sm[64][17];
+    __shared__ double sm2[2][64][17];
     const int stop = r.ctl->stop;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
     MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 0);                         // reduce block 1, wave 0
     MMM_RSTAMP(blockIdx.x == 0 && tid == 64, 8);                        // tail wave
-    MMM_RSTAMP((int)blockIdx.x == ms.nred && tid == 0, 16);              // first ll block
-    if ((int)blockIdx.x >= ms.nred) {        // ---- ll block: numerator of pass t-1 into its cell
+    MMM_RSTAMP((int)blockIdx.x == ms.nredp && tid == 0, 16);             // first ll block
+    if ((int)blockIdx.x >= ms.nredp) {       // ---- ll block: numerator of pass t-1 into its cell
         if (stop) return;
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
-        const int lb = (int)blockIdx.x - ms.nred, n_ll = ms.n_ll;
+        const int lb = (int)blockIdx.x - ms.nredp, n_ll = ms.n_ll;
         // ms.pro: the block also runs the NEXT pass's prologue for its documents (the four of each wave, 16 lanes per document as
         // k_lda_estep<., 16, ...> has them): gamma_{t+1} is requested before the sweep and used after the block's numerator has left --
         // the pass tail (wave 1 of block 0, the end of this launch's critical path) does not wait a cycle longer for it
@@ -382,8 +383,8 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
                 gnx = (pd < c.D && l < c.K) ? ms.pro_gamma[(size_t)pd * c.K + l] : (l < c.K ? 1.0 : 0.0);
             }
         }
-        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nred - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
-        MMM_RSTAMP((int)blockIdx.x == ms.nred && tid == 0, 17);
+        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nredp - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        MMM_RSTAMP((int)blockIdx.x == ms.nredp && tid == 0, 17);
         if constexpr (KP <= 12) {
             if (ms.pro) {          // Elntheta_{t+1}, exp(Elntheta_{t+1}) (LDA.jl:78-80): the operations of the E-step kernel's prologue
                 const int lane = tid & 63, g = lane >> 4, l = lane & 15, K = c.K;
@@ -396,27 +397,38 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         }
         return;
     }
-    // ---- reduce block: 16 entries of the statistics (as lda_reduce_block)
-    const int rb = (int)blockIdx.x;             // reduce block
+    // ---- reduce block: epb (1 or 2) groups of 16 entries of the statistics (each as lda_reduce_block).  With two groups the block is two of
+    //      the `nred` logical reduce blocks, 2 rbp and 2 rbp + 1: every thread sums both groups' partials, and rows 0 and 1 of wave 0 (ty = 0 / 1)
+    //      finish one group each in lock step -- same sums, same cells, half the CUs (the others go to the ll sweep, which bounds the launch)
+    const int rbp = (int)blockIdx.x, epb = ms.epb;      // physical reduce block
+    const int rb = rbp * epb + (ty < epb ? ty : 0);     // the logical reduce block of this thread's row in the final stage
     const int e = rb * 16 + tx;
-    double acc = 0.0;
-    for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e];
+    double acc = 0.0, acc1 = 0.0;
+    {
+        const int e0 = rbp * epb * 16 + tx;
+        for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e0];
+        if (epb == 2) for (int sl = ty; sl < r.nslab; sl += 64) acc1 += r.partial[(size_t)sl * r.VK + e0 + 16];
+    }
     if (stop) {      // a no-op pass still keeps the mailbox rendezvous of its sequence number (p2p.hip header): element 0, value unused
-        if (P2P && rb == 0 && tid == 0) { p2p_send(r.px, r.p2p_seq, 0, 0.0); (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0); }
+        if (P2P && rbp == 0 && tid == 0) { p2p_send(r.px, r.p2p_seq, 0, 0.0); (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0); }
         return;
     }
     MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 1);                         // partial loads done
-    sm[ty][tx] = acc;
+    sm2[0][ty][tx] = acc; sm2[1][ty][tx] = acc1;
     __syncthreads();
     if (ty < 8) {
-        double v = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v += sm[ty * 8 + j][tx];
-        sm[ty * 8][tx] = v;
+        for (int h = 0; h < 2; ++h) {
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += sm2[h][ty * 8 + j][tx];
+            sm2[h][ty * 8][tx] = v;
+        }
     }
     __syncthreads();
+    double (*sm)[17] = sm2[ty < epb ? ty : 0];
     MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 2);                         // tree done
-    if (ty == 0) {                           // lanes 0..15 of wave 0
+    if (ty < epb) {                          // lanes 0..15 (and 16..31: the block's second group) of wave 0
         double v = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += sm[j * 8][tx];
@@ -481,14 +493,14 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         MMM_RSTAMP(blockIdx.x == 1 && tid == 0, 4);                     // M-step stores done
         }
     }
-    if (ms.ll_join && rb > 0) {              // (uniform per block; block 0 keeps the pass tail)
+    if (ms.ll_join && rbp > 0) {             // (uniform per block; block 0 keeps the pass tail)
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
-        const int n_ll = ms.n_ll, lb = n_ll + rb - 1;
-        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + ms.nred - 1, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
+        const int n_ll = ms.n_ll, lb = n_ll + rbp - 1;
+        lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + ms.nredp - 1, smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
         return;
     }
-    if (rb == 0 && ty >= 4 && ty < 8) {      // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
-        const int lane = tid & 63, n_ll = ms.n_ll + (ms.ll_join ? ms.nred - 1 : 0);
+    if (rbp == 0 && ty >= 4 && ty < 8) {     // wave 1 of block 0: ll numerator of pass t-1, stopping rule, pass counter
+        const int lane = tid & 63, n_ll = ms.n_ll + (ms.ll_join ? ms.nredp - 1 : 0);
         // what the tail needs from memory is fetched before the wait, not after it (lda_pass_tail's dependent loads)
         const int n = r.ctl->n_hist;
         const double prev = (r.do_ll && n > 0) ? r.ll_hist[n - 1] : 0.0;
