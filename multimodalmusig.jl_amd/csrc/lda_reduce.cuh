@@ -134,7 +134,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
             const unsigned dnl = validn ? (unsigned)dn : dl;
             const double Sp = group_sum<L>(gp);
             lds_wave_sync();
-            if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+            if (l < KP) myT[l] = (l < K) ? dev_div(gp, Sp) : 0.0;      // (the bits of gp / Sp: both are normal numbers)
             lds_wave_sync();
             double tv[KP];
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
             }
             const double Sp = group_sum<L>(gp);
             lds_wave_sync();
-            if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+            if (l < KP) myT[l] = (l < K) ? dev_div(gp, Sp) : 0.0;      // (the bits of gp / Sp: both are normal numbers)
             lds_wave_sync();
             double tv[KP];
 #pragma unroll
@@ -218,7 +218,7 @@ __device__ void lda_ll_block(const LdaDev& c, const double* __restrict__ gprev, 
         const int2* __restrict__ tcd = c.tc + start;
         const double Sp = group_sum<L>(gp);
         lds_wave_sync();
-        if (l < KP) myT[l] = (l < K) ? gp / Sp : 0.0;
+        if (l < KP) myT[l] = (l < K) ? dev_div(gp, Sp) : 0.0;      // (the bits of gp / Sp: both are normal numbers)
         lds_wave_sync();
         double tv[KP];
 #pragma unroll
