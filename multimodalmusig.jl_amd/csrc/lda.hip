@@ -170,6 +170,15 @@ __device__ unsigned long long g_lda_stamps[16];
     } while (0)
 // stamps of the merged reduce + ll + M-step launch: s_memrealtime (100 MHz) of one chosen wave per role
 __device__ unsigned long long g_red_stamps[32];
+// start / numerator-posted time of every ll block of the last merged launch (s_memrealtime): where the launch's tail comes from
+__device__ unsigned long long g_ll_times[2][512];
+#define MMM_LLSTAMP(which, lb)                                                                               \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                            \
+        if (threadIdx.x == 0 && threadIdx.y == 0 && (lb) < 512) g_ll_times[which][lb] = r_;                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
 #define MMM_RSTAMP(cond, i)                                                                                  \
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
@@ -181,6 +190,7 @@ __device__ unsigned long long g_red_stamps[32];
 #else
 #define MMM_STAMP(i) do { } while (0)
 #define MMM_RSTAMP(cond, i) do { } while (0)
+#define MMM_LLSTAMP(which, lb) do { } while (0)
 #endif
 
 #include "lda_estep.cuh"
@@ -568,7 +578,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
         // Single-step build: two logical reduce blocks (16 entries each) per physical block.  The launch is bounded by its ll blocks, whose
         // sweep is issue-bound per SIMD: at BASELINE config 2, 60 + 192 resident blocks leave 13 busy waves per ll block (one SIMD with four),
         // 30 + 209 leave 12 (three everywhere) -- merged launch 7.7 -> 6.8 us (measured at 9,216 documents before this was built)
-        const int epb = (merged && m->single_step && !m->ilda && ((Vp * m->K) / 16) % 2 == 0) ? 2 : 1;
+        const int epb = (merged && m->single_step && !m->dense && !m->ilda && ((Vp * m->K) / 16) % 2 == 0) ? 2 : 1;
         if (merged) r.VK = Vp * m->K;
         r.llpart2 = m->llpart2.p; r.ll_in_k2 = ll_in_k2 ? 1 : 0;
         r.ll_cells = via_cells ? m->cells.p + 2 * 512 : nullptr; r.ll_seq = via_cells ? ++m->kseq : 0;
@@ -614,7 +624,7 @@ int fused_passes(mmm_lda* m, int n_iter, double tol, int conv_base)
             ms.n_ll = r.n_ll;
             // The next pass's prologue beside this pass's reduction, in the ll blocks: single-step build (every wave of the E-step kernel walks
             // its chain once, the prologue is 2 us of it), every document in exactly one ll block's single step, plain LDA
-            ms.pro = (m->single_step && !m->ilda && m->KP <= 12 && m->L == 16 && m->aexp_next.p && r.n_ll > 0 && !ms.ll_join &&
+            ms.pro = (m->single_step && !m->dense && !m->ilda && m->KP <= 12 && m->L == 16 && m->aexp_next.p && r.n_ll > 0 && !ms.ll_join &&
                       (int64_t)r.n_ll * docs_per_ll_block >= (int64_t)m->D && !mmm_off(m->tune, MMM_OFF_LDA_EARLY_PROLOGUE)) ? 1 : 0;
             ms.pro_gamma = m->gamma[(t + 1) % 3].p; ms.pro_Eln = m->Elntheta[(t + 1) % 3].p; ms.pro_a = m->aexp_next.p;
             const int c3 = t % 3;
@@ -764,6 +774,10 @@ static int run_chunks_pipelined(mmm_lda* m, int maxiter, int* enq_out, Enqueue e
 extern "C" int mmm_diag_lda_stamps(unsigned long long out[16])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lda_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+extern "C" int mmm_diag_ll_times(unsigned long long out[1024])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ll_times), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -2;
 }
 extern "C" int mmm_diag_red_stamps(unsigned long long out[32])
 {

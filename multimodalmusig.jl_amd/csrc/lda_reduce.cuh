@@ -371,6 +371,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         if (stop) return;
         constexpr int L = KP <= 15 ? 16 : (KP <= 31 ? 32 : 64);
         const int lb = (int)blockIdx.x - ms.nredp, n_ll = ms.n_ll;
+        MMM_LLSTAMP(0, lb);
         // ms.pro: the block also runs the NEXT pass's prologue for its documents (the four of each wave, 16 lanes per document as
         // k_lda_estep<., 16, ...> has them): gamma_{t+1} is requested before the sweep and used after the block's numerator has left --
         // the pass tail (wave 1 of block 0, the end of this launch's critical path) does not wait a cycle longer for it
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
         }
         lda_ll_block<KP, L>(c, gprev, bprev, nullptr, lb, n_ll + (ms.ll_join ? ms.nredp - 1 : 0), smem, ms.cells + 2 * (ms.nred + lb), ms.seq);
         MMM_RSTAMP((int)blockIdx.x == ms.nredp && tid == 0, 17);
+        MMM_LLSTAMP(1, lb);
         if constexpr (KP <= 12) {
             if (ms.pro) {          // Elntheta_{t+1}, exp(Elntheta_{t+1}) (LDA.jl:78-80): the operations of the E-step kernel's prologue
                 const int lane = tid & 63, g = lane >> 4, l = lane & 15, K = c.K;
@@ -406,8 +408,13 @@ __global__ __launch_bounds__(1024) void k_lda_reduce_ll_mstep(ReduceArgs r, LdaD
     double acc = 0.0, acc1 = 0.0;
     {
         const int e0 = rbp * epb * 16 + tx;
-        for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e0];
-        if (epb == 2) for (int sl = ty; sl < r.nslab; sl += 64) acc1 += r.partial[(size_t)sl * r.VK + e0 + 16];
+        // (one loop for both groups: all of a thread's loads leave together -- as two loops the second group's waited for the first's:
+        // partial sums in hand after 3.1 instead of 1.9 us; with the mailbox exchange on this chain that would be the launch's critical path)
+        if (epb == 2) {
+            for (int sl = ty; sl < r.nslab; sl += 64) { acc += r.partial[(size_t)sl * r.VK + e0]; acc1 += r.partial[(size_t)sl * r.VK + e0 + 16]; }
+        } else {
+            for (int sl = ty; sl < r.nslab; sl += 64) acc += r.partial[(size_t)sl * r.VK + e0];
+        }
     }
     if (stop) {      // a no-op pass still keeps the mailbox rendezvous of its sequence number (p2p.hip header): element 0, value unused
         if (P2P && rbp == 0 && tid == 0) { p2p_send(r.px, r.p2p_seq, 0, 0.0); (void)p2p_recv_sum(r.px, r.p2p_seq, 0, 0.0); }
