@@ -409,10 +409,37 @@ def load_pmc(tname, model, kernel_prefix):
     return None, None, "no counter file for %s under profiles/" % tname
 
 
-def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline, cpu_target_s=None, every_transport=False, probe=True):
+def make_corpus(cfg_id, D, seed):
+    """SURVEY section 8d generator: (X, init) of one configuration at D documents"""
+    import numpy as np
+    import np_ref
+    key = (cfg_id, D, seed)
+    if key in _CORPORA:
+        return _CORPORA[key]
+    cfg = CONFIGS[cfg_id]
+    K, V = cfg["K"], cfg["V"]
+    if cfg["model"] == "lda":
+        X, init = np_ref.synth_lda(D, V, K, seed=seed)
+    else:
+        X, init = np_ref.synth_mm(D, V, K, seed=seed)
+        if cfg["model"] == "immctm":
+            GM = sum(K[i] * int(f.max(axis=0).sum()) for i, f in enumerate(snv3()))
+            init = np.random.default_rng(1).integers(1, 101, size=GM).astype(np.float64)
+    if D <= 100000:      # (the shard proxy re-uses the three BASELINE corpora; the 640k-document one is used once)
+        _CORPORA[key] = (X, init)
+    return X, init
+
+
+_CORPORA = {}
+
+
+def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline, cpu_target_s=None, every_transport=False, probe=True,
+               proxy_shard=0, corpus=None):
     """Measure one configuration on the ranks of `env`; rank 0 gets the result dictionary, the others None.  every_transport (N > 1): after
     the full measurement on the current all-reduce transport, the timed regions once more on every other transport the job can run, on a
-    fresh model over the same shard, under res["transports"]."""
+    fresh model over the same shard, under res["transports"].  proxy_shard = N (one GPU): the model runs over rank 0's shard of an N-rank
+    strong run of the corpus (`shard_documents(X, N, 0)`), no communicator -- the per-GPU work of that run without its exchange
+    (shard_proxy).  corpus = (X, init): use this corpus instead of generating one."""
     np, pkg, ctx, world, rank = env.np, env.pkg, env.ctx, env.world, env.rank
     import np_ref
     cfg = CONFIGS[cfg_id]
@@ -427,15 +454,15 @@ def run_config(env, cfg_id, scaling, steps, warmup, repeats, docs, cpu_baseline,
     seed = 20261003 + (1 if cfg_id == 2 else cfg_id)
     K, V = cfg["K"], cfg["V"]
     corpus_seed = seed + (1000 * rank if scaling == "weak" else 0)
-    if cfg["model"] == "lda":
-        X, init = np_ref.synth_lda(Dcfg, V, K, seed=corpus_seed)
+    if corpus is not None:
+        X, init = corpus
     else:
-        X, init = np_ref.synth_mm(Dcfg, V, K, seed=corpus_seed)
-        if cfg["model"] == "immctm":
-            GM = sum(K[i] * int(f.max(axis=0).sum()) for i, f in enumerate(snv3()))
-            init = np.random.default_rng(1).integers(1, 101, size=GM).astype(np.float64)
+        X, init = make_corpus(cfg_id, Dcfg, corpus_seed)
     if scaling == "strong" and world > 1:
         d0, d1 = pkg.shard_documents(X, world, rank)
+        X = X[d0:d1]
+    elif proxy_shard > 1:
+        d0, d1 = pkg.shard_documents(X, proxy_shard, 0)
         X = X[d0:d1]
     D = len(X)
     if world > 1 and cfg["model"] == "lda":                  # same lambda0 everywhere: take rank 0's
@@ -742,6 +769,39 @@ def restart_sweep_brca(env, restarts=256, cpu_restarts=3):
     return res
 
 
+def shard_proxy(env, full, shards=(2, 4, 8), cfgs=(2, 4, 5)):
+    """What ONE GPU does in an N-GPU strong run of BASELINE's configurations, measured on the one GPU at hand: rank 0's nnz-balanced shard of
+    the configuration's corpus (D/2, D/4, D/8 documents) through the same timed regions, no communicator.  T(D) / T(D/N) is an UPPER BOUND
+    on the strong-scaling speed-up of that configuration at N GPUs -- the exchange (one all-reduce of 8-20 KB per iteration, folded into a
+    launch for LDA) and the slowest rank are not in it -- and NOT a measurement of it.  `full`: {cfg: result of run_config at full size}."""
+    out = {"what": "per-GPU work of an N-GPU strong run, measured on one GPU: rank 0's shard (shard_documents(X, N, 0)) of the configuration's corpus, "
+                   "no exchange; speedup_upper_bound = ms_per_step(D) / ms_per_step(D/N) -- an upper bound on strong scaling, not a measurement of it"}
+    for c in cfgs:
+        cfg = CONFIGS[c]
+        seed = 20261003 + (1 if c == 2 else c)
+        lda = cfg["model"] == "lda"
+        rows = []
+        f = full.get(c)
+        if f and "ms_per_step" in f:
+            rows.append({"n": 1, "docs": f["config"]["docs_rank0"], "ms_per_step": f["ms_per_step"], "ms_per_step_min": f["ms_per_step_min"],
+                         "kernel_us": f["iteration"]["kernel_us"]})
+        for n in shards:
+            try:
+                r = run_config(env, c, "weak", 20 if lda else 10, 5 if lda else 2, 5 if lda else 3, 0, False, probe=False, proxy_shard=n,
+                               corpus=make_corpus(c, cfg["docs"], seed))
+                row = {"n": n, "docs": r["config"]["docs_rank0"], "ms_per_step": r["ms_per_step"], "ms_per_step_min": r["ms_per_step_min"],
+                       "kernel_us": r["iteration"]["kernel_us"]}
+                if not lda:
+                    row["mma_evaluations_per_document"] = r["roofline"]["f64_valu"]["mma_evaluations_per_document"]
+                if rows and rows[0]["n"] == 1:
+                    row["speedup_upper_bound"] = rows[0]["ms_per_step"] / r["ms_per_step"]
+                rows.append(row)
+            except Exception as e:       # noqa: BLE001
+                rows.append({"n": n, "error": "%s: %s" % (type(e).__name__, e)})
+        out["cfg%d" % c] = rows
+    return out
+
+
 def compact(r):
     """the keys of a nested entry (strong / weak variants inside the one line)"""
     if r is None:
@@ -830,6 +890,11 @@ def main():
             r = attempt(lambda: restart_sweep_brca(env))
             r["wall_s_including_cpu_baseline"] = time.perf_counter() - t0
             also["restart_sweep_brca"] = r
+            full = {2: res, 4: also.get("cfg4"), 5: also.get("cfg5")}
+            t0 = time.perf_counter()
+            r = attempt(lambda: shard_proxy(env, {k: v for k, v in full.items() if v and "error" not in v}))
+            r["wall_s"] = time.perf_counter() - t0
+            also["shard_proxy"] = r
         if env.rank == 0:
             res["also"] = also
     if env.rank == 0:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MMM_VERSION 121
+#define MMM_VERSION 122
 
 enum {
     MMM_OK = 0,
@@ -91,7 +91,8 @@ enum { /* mmm_tuning_opts.disable: optimisations a test or an A/B run may switch
     MMM_OFF_CTM_KFIT = 1 << 8,          /* theta phase: 16-wide topic loops for every shape                                                        */
     MMM_OFF_CTM_FUSED_GAUSS = 1 << 9,   /* Gaussian M-step as its own launch instead of block 0 of the log-likelihood launch                       */
     MMM_OFF_CTM_LL_ROWS = 1 << 10,      /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
-    MMM_OFF_LDA_EARLY_PROLOGUE = 1 << 11 /* single-step E-step build: every pass forms its own Elntheta / exp(Elntheta) instead of the previous pass's merged launch */
+    MMM_OFF_LDA_EARLY_PROLOGUE = 1 << 11, /* single-step E-step build: every pass forms its own Elntheta / exp(Elntheta) instead of the previous pass's merged launch */
+    MMM_OFF_ALL = (1 << 12) - 1          /* every bit this build knows; mmm_ctx_set_tuning rejects others (and non-zero reserved fields) with MMM_ERR_ARG */
 };
 typedef struct {
     int lda_build;        /* MMM_BUILD_*: E-step build of LDA / ILDA handles                                                              */
@@ -105,7 +106,11 @@ typedef struct {
     int side_stream;      /* CTM fit passes on one GPU: -1 never, 0 library's choice (IMMCTM only), 1 whenever possible                   */
     int resident_cap;     /* > 0: lowers the residency bound of the merged LDA launch (tests of the fallback)                             */
     unsigned disable;     /* MMM_OFF_* bits                                                                                               */
-    int reserved[7];      /* 0                                                                                                            */
+    int solve_lanes;      /* CTM solve phase: lanes per document, 0 = the library's choice by shape and corpus size (mmm_ctm_geometry out[5]); */
+                          /* sum K = 10: 2 (x 5 coordinates) or 8 (x 2); sum K = 28: 16 (x 2) or 32 (x 1).  The layouts associate a document's  */
+                          /* sums differently (sum K = 10) -- the value pins the bits across corpus sizes                                   */
+    int solve_waves;      /* > 0: persistent solve kernels run with this many waves per SIMD (1..8) instead of the library's choice           */
+    int reserved[5];      /* 0                                                                                                            */
 } mmm_tuning_opts;
 void mmm_tuning_opts_default(mmm_tuning_opts* o);
 /* opts == NULL: back to the defaults.  Applies to handles created on ctx from now on. */
@@ -183,6 +188,9 @@ int mmm_ilda_create(mmm_ctx* ctx, int D, int V, int K, double alpha, int I, cons
 int mmm_lda_destroy(mmm_lda* m);
 int mmm_lda_get(mmm_lda* m, int field, double* host, size_t n);
 int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n);
+/* The hyper-parameters are plain mutable fields upstream (`model.α = 0.5; fit!(model)`, LDA.jl:2-12 / ILDA.jl:2-12): alpha, and eta as
+ * n_eta = 1 value (LDA) or one per feature (ILDA).  Takes effect from the next update_γ! / update_λ! on. */
+int mmm_lda_set_hyper(mmm_lda* m, double alpha, const double* eta, int n_eta);
 /* One-to-one GPU counterparts of the reference's update functions (stage API; used by the parity tests) */
 int mmm_lda_update_gamma(mmm_lda* m);   /* update_γ!  LDA.jl:82-90  (+ update_Elnθ! :78-80)  */
 int mmm_lda_update_phi(mmm_lda* m);     /* update_ϕ!  LDA.jl:69-76                           */
@@ -277,6 +285,14 @@ int mmm_ctm_objectives(mmm_ctm* m, int d, double* lambda_val, double* lambda_gra
  * solves that hit max_eval, and (optional, D ints each) per-document evaluation counts */
 int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped,
                          int* per_doc_nu, int* per_doc_lambda);
+/* Non-fatal events, COUNTED instead of raised (SURVEY section 8b "error convention": the reference ignores NLopt's return code, MMCTM.jl:141,
+ * 168, never checks for NaN, and carries on -- so does the library): out[0] = LD_MMA solves of the last E-step that hit max_eval (= n_capped
+ * above), out[1] = LD_MMA solves of the last E-step in which an objective value was not finite (a NaN / Inf in a document's λ, ν, ζ or in
+ * μ / invΣ: such a solve cannot satisfy NLopt's tests and runs into the cap), out[2] = values of the handle's log-likelihood history that
+ * are not finite (a fit whose ll is NaN never meets the stopping rule of common.jl:48-56 and runs to maxiter), out[3] = 0.  LDA / ILDA
+ * handles have no solves: out[0] = out[1] = 0. */
+int mmm_ctm_events(mmm_ctm* m, int64_t out[4]);
+int mmm_lda_events(mmm_lda* m, int64_t out[4]);
 /* Launch geometry that fixes the ORDER of the sums across documents (and so their bits): out[0] = lanes per document L,
  * [1] = theta-phase blocks, [2] = waves per theta-phase block, [3] = blocks of the moment sums, [4] = 1 when the handle
  * takes the wide-table path (term-major posting sweep instead of LDS slabs), 2 when the fused pass's theta phase runs over rows of counts

@@ -65,6 +65,7 @@ _SIGS = {
     "mmm_lda_destroy": (C.c_int, [vp]),
     "mmm_lda_get": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
     "mmm_lda_set": (C.c_int, [vp, C.c_int, f64p, C.c_size_t]),
+    "mmm_lda_set_hyper": (C.c_int, [vp, C.c_double, f64p, C.c_int]),
     "mmm_lda_update_gamma": (C.c_int, [vp]),
     "mmm_lda_update_phi": (C.c_int, [vp]),
     "mmm_lda_update_lambda": (C.c_int, [vp]),
@@ -101,6 +102,8 @@ _SIGS = {
     "mmm_ctm_geometry": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "mmm_debug_math": (C.c_int, [vp, C.c_int, C.c_size_t, f64p, vp, f64p]),
     "mmm_ctm_solver_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]),
+    "mmm_ctm_events": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+    "mmm_lda_events": (C.c_int, [vp, C.POINTER(C.c_int64)]),
     "mmm_ctm_iterate": (C.c_int, [vp, C.c_int, C.c_int]),
     "mmm_ctm_ll_history": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "mmm_ctm_fit": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -157,7 +160,7 @@ _ALL_CTX = []
 class TuningOpts(C.Structure):
     """mmm_tuning_opts (include/mmmusig.h)"""
     _fields_ = [("lda_build", C.c_int), ("ctm_build", C.c_int), ("geometry_cus", C.c_int), ("grid_blocks", C.c_int), ("waves_per_block", C.c_int),
-                ("moment_blocks", C.c_int), ("side_stream", C.c_int), ("resident_cap", C.c_int), ("disable", C.c_uint), ("reserved", C.c_int * 7)]
+                ("moment_blocks", C.c_int), ("side_stream", C.c_int), ("resident_cap", C.c_int), ("disable", C.c_uint), ("solve_lanes", C.c_int), ("solve_waves", C.c_int), ("reserved", C.c_int * 5)]
 
 
 BUILDS = {"auto": 0, "sparse": 1, "dense": 2, "wide": 3}
@@ -183,7 +186,7 @@ class Context:
         check(lib().mmm_ctx_synchronize(self.h), self.h, "mmm_ctx_synchronize")
 
     def set_tuning(self, lda_build="auto", ctm_build="auto", geometry_cus=0, grid_blocks=0, waves_per_block=0, moment_blocks=0, side_stream=0,
-                   resident_cap=0, disable=()):
+                   resident_cap=0, disable=(), solve_lanes=0, solve_waves=0):
         """mmm_ctx_set_tuning: the caller's choices for the handles created on this context FROM NOW ON (no arguments: the defaults).
         lda_build / ctm_build: "auto" | "sparse" | "dense" | "wide"; geometry_cus: size the launches as if the device had that many CUs
         (pins the association of the cross-document sums, and so the bits of a fit, across devices); disable: names of OFF."""
@@ -191,6 +194,7 @@ class Context:
         t.lda_build, t.ctm_build = BUILDS[lda_build], BUILDS[ctm_build]
         t.geometry_cus, t.grid_blocks, t.waves_per_block, t.moment_blocks = int(geometry_cus), int(grid_blocks), int(waves_per_block), int(moment_blocks)
         t.side_stream, t.resident_cap = int(side_stream), int(resident_cap)
+        t.solve_lanes, t.solve_waves = int(solve_lanes), int(solve_waves)
         d = 0
         for name in ([disable] if isinstance(disable, str) else disable):
             d |= OFF[name]

@@ -143,6 +143,10 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
     return n * sizeof(double);
 }
 
+// shard sizes (documents, on a 256-CU device) below which the solve phase takes more lanes per document (create_impl; measured: profiles/r05_solve_layouts.jsonl)
+constexpr int kSolve10Lanes8Below = 75000;      // sum K = 10: 2 lanes x 5 coordinates -> 8 lanes x 2
+constexpr int kSolve28Lanes32Below = 9000;        // sum K = 28: 16 lanes x 2 coordinates -> 32 lanes x 1
+
 size_t solve_lds(const mmm_ctm* m)
 {
     if (m->persist) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
@@ -221,6 +225,11 @@ int launch_phase(mmm_ctm* m, const CtmEArgs& a, size_t lds, int grid, int waves,
             // launches with documents claimed on demand -- did not beat these and are gone from the source.
             if (m->dm.MK == 10 && m->Ls == 2) return go(k_ctm_solve_cpl<10, 2, 2, false>);
             if (m->dm.MK == 28 && m->Ls == 16) return go(k_ctm_solve_cpl<28, 16, 3, false>);
+            // round 5, small shards (what one GPU of an N-GPU strong run holds): more lanes per document, so that the chip still has a wave per
+            // SIMD and a document's chain of evaluations is shorter -- sum K = 10: 8 lanes, 5 of them x 2 coordinates (8 slots per wave instead
+            // of 32); sum K = 28: 32 lanes x 1 coordinate (2 slots instead of 4)
+            if (m->dm.MK == 10 && m->Ls == 8) return go(k_ctm_solve_cpl<10, 8, 3, false>);
+            if (m->dm.MK == 28 && m->Ls == 32) return go(k_ctm_solve_cpl<28, 32, 4, false>);
             return mmm_fail(ctx, MMM_ERR_UNSUPPORTED, "no multi-coordinate solve build for sum K = %d", m->dm.MK);
         }
         if (m->Ls != m->L) {       // packed groups: sum K lanes per document
@@ -803,18 +812,35 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         // SIMD, no scratch: BASELINE config 4 solve phase 1,096 -> 974 us at pass 20, 794 -> 757 us at pass 60 -- and the sums of a document
         // are associated exactly as the 32-lane butterfly associates them, so not a bit changes).  MMM_OFF_CTM_CPL switches the path off
         // (one coordinate per lane, lock step: k_ctm_estep<L, 1>).
-        if (!mmm_off(ctx->tune, MMM_OFF_CTM_CPL)) {
-            if (dm.MK == 10) { m->Ls = 2; m->cpl = 5; }
-            else if (dm.MK == 28) { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }      // 14 of 16 lanes x 2 coordinates, 3 waves per SIMD
-            if (m->cpl > 1) m->persist = true;
+        const int want = ctx->tune.solve_lanes;      // 0: by shape and corpus size
+        const bool lockstep10 = dm.MK == 10 && want == 16;      // sum K = 10 with solve_lanes = 16: the packed / 16-lane lock-step build (A/B)
+        if (!mmm_off(ctx->tune, MMM_OFF_CTM_CPL) && !lockstep10) {
+            // Which layout: the full-size configurations keep the layouts of rounds 2-3 (most documents per wave trip); a SHARD -- D small
+            // enough that those layouts leave SIMDs without a wave or slots without a document -- takes more lanes per document
+            // (profiles/r05_shard_sizes.jsonl: sum K = 10 at 12,505 documents 2 x 5 -> 8 x 2; sum K = 28 at 6,249 documents 16 x 2 -> 32 x 1).
+            if (dm.MK == 10) {
+                const bool wide8 = want == 8 || (want == 0 && (int64_t)D * R < kSolve10Lanes8Below * (ncu / 256.0));      // (a restart batch fills the chip with its replicas)
+                if (wide8) { m->Ls = 8; m->cpl = 2; m->lam_occ = 3; } else { m->Ls = 2; m->cpl = 5; m->lam_occ = 2; }
+                m->persist = true;
+            } else if (dm.MK == 28) {
+                const bool wide32 = want == 32 || (want == 0 && (int64_t)D * R < kSolve28Lanes32Below * (ncu / 256.0));
+                if (wide32) { m->Ls = 32; m->cpl = 1; m->lam_occ = 4; } else { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }
+                m->persist = true;
+            }
         }
     }
     if (m->big) { m->Ls = 64; m->cpl = kBigSlots; m->persist = false; }      // ctm_big.cuh: lane l holds coordinates l + 64 q
     const int Gs = MMM_WAVE / m->Ls;
     m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ncu * 8));
-    // k_ctm_solve_cpl: as many waves as are resident at once (2 per SIMD), each with a contiguous range of documents that its
-    // slots work through (a finished slot takes the range's next document)
-    if (m->persist) m->grid_v = std::max(1, std::min((D + m->waves_s * Gs - 1) / (m->waves_s * Gs), ncu * (m->Ls == 16 ? m->lam_occ : 2)));
+    // k_ctm_solve_cpl: persistent waves, each with a contiguous range of documents that its slots work through (a finished slot takes the
+    // range's next document): as many as are resident at once (lam_occ per SIMD), fewer when every document has a slot of its own.  (Round 5
+    // measured whole numbers of waves per SIMD with more documents than slots each for small shards: slower -- 6,249 documents of config 4:
+    // 200 us with one wave per SIMD against 188; the phase is issue-bound per SIMD and a half-filled wave costs a full trip.)
+    if (m->persist) {
+        const int blocks_full = (D + m->waves_s * Gs - 1) / (m->waves_s * Gs);      // every document a slot of its own
+        m->grid_v = std::max(1, std::min(blocks_full, ncu * m->lam_occ));
+        if (ctx->tune.solve_waves > 0) m->grid_v = std::max(1, std::min(blocks_full, ncu * ctx->tune.solve_waves));
+    }
     // moment sums: whole 32-document tiles per block (a short last tile is padded to 32 and costs as much as a full one), at most 1024 blocks
     {
         const int tiles_per_block = std::max(1, (D + 32 * 1024 - 1) / (32 * 1024));
@@ -1247,13 +1273,47 @@ int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda,
         MMM_HIP(ctx, hipMemcpyAsync(b.data(), m->nev_lam.p + (size_t)m->sel * D, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
     }
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (a stored value: evaluations | MMM_NEV_NONFINITE, negated when the cap was hit -- nev_code in ctm_estep.cuh)
     int64_t sa = 0, sb = 0, cap = 0;
-    for (int d = 0; d < D; ++d) { if (a[d] < 0) { ++cap; sa -= a[d]; } else sa += a[d]; if (b[d] < 0) { ++cap; sb -= b[d]; } else sb += b[d]; }
+    for (int d = 0; d < D; ++d) {
+        for (int* v : {&a[d], &b[d]}) {
+            const bool capped = *v < 0;
+            const int n = (capped ? -*v : *v) & ~MMM_NEV_NONFINITE;
+            if (capped) ++cap;
+            (v == &a[d] ? sa : sb) += n;
+            *v = capped ? -n : n;
+        }
+    }
     if (n_eval_nu) *n_eval_nu = sa;
     if (n_eval_lambda) *n_eval_lambda = sb;
     if (n_capped) *n_capped = cap;
     if (per_doc_nu && D) memcpy(per_doc_nu, a.data(), sizeof(int) * D);
     if (per_doc_lambda && D) memcpy(per_doc_lambda, b.data(), sizeof(int) * D);
+    return MMM_OK;
+}
+
+int mmm_ctm_events(mmm_ctm* m, int64_t out[4])
+{
+    if (!m || !out) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    if (rc) return rc;
+    const int D = m->dm.D, M = m->dm.M, nh = m->n_hist[m->sel];
+    std::vector<int> a((size_t)D), b((size_t)D);
+    std::vector<double> ll((size_t)nh * M);
+    if (D) {
+        MMM_HIP(ctx, hipMemcpyAsync(a.data(), m->nev_nu.p + (size_t)m->sel * D, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+        MMM_HIP(ctx, hipMemcpyAsync(b.data(), m->nev_lam.p + (size_t)m->sel * D, sizeof(int) * D, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (nh) MMM_HIP(ctx, hipMemcpyAsync(ll.data(), m->ll_hist.p + (size_t)m->sel * m->cap_hist * M, sizeof(double) * nh * M, hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int d = 0; d < D; ++d)
+        for (int v : {a[d], b[d]}) {
+            if (v < 0) { ++out[0]; v = -v; }
+            if (v & MMM_NEV_NONFINITE) ++out[1];
+        }
+    for (double v : ll) if (!std::isfinite(v)) ++out[2];
     return MMM_OK;
 }
 

@@ -162,6 +162,7 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
 #pragma unroll
     for (int q = 0; q < kBigSlots; ++q) { sigma[q] = 1.0; xc[q] = x[q]; xprev[q] = x[q]; xprevprev[q] = x[q]; }
     int k = 1, nev = 1;
+    bool nonfin = !isfinite(fbest);
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
     for (;;) {
         double gl = 0.0, wl = 0.0;
@@ -188,13 +189,14 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
         const double wval = wave_sum(wl);
         const double fcur = obj.eval(xc, gcur);
         ++nev;
+        nonfin = nonfin || !isfinite(fcur);
         const bool inner_done = gval >= fcur;
         if (fcur < fbest) {
             fbest = fcur;
 #pragma unroll
             for (int q = 0; q < kBigSlots; ++q) { x[q] = xc[q]; grad[q] = gcur[q]; }
         }
-        if (nev >= cap) return -nev;
+        if (nev >= cap) return nev_code(nev, true, nonfin);
         if (!inner_done) {
             if (fcur > gval) rho = fmin(10.0 * rho, 1.1 * (rho + dev_div(fcur - gval, wval)));
             continue;
@@ -217,7 +219,7 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
             }
             stop = __ballot(bad) == 0ull;
         }
-        if (stop) return nev;
+        if (stop) return nev_code(nev, false, nonfin);
         rho = fmax(0.1 * rho, 1e-5);
 #pragma unroll
         for (int q = 0; q < kBigSlots; ++q) {
@@ -448,8 +450,8 @@ __device__ void block_inverse_big(int n, double* A, double* Ainv, double* logdet
         if (tid == 0) {
             double b = -1.0; int pr = n;
             for (int i = 0; i < nt && i < n - c; ++i) if (s_best[i] > b || (s_best[i] == b && s_row[i] < pr)) { b = s_best[i]; pr = s_row[i]; }
-            s_p = pr;
-            if (!(b > 0.0)) *singular = 1;
+            s_p = pr < n ? pr : c;      // (no row compares greater only if the column holds NaNs: keep the row, as the LDS version does)
+            if (b == 0.0) *singular = 1;      // (a NaN column is not an error upstream: see block_inverse_wide)
             *logdet += log(b);
         }
         __syncthreads();

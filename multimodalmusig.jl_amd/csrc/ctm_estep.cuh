@@ -167,9 +167,18 @@ __device__ __forceinline__ void stage_solve_tabs(double* tabs)
     for (int i = threadIdx.x; i < MMM_EXPTAB_N + MMM_LOGTAB_N; i += blockDim.x) tabs[i] = i < MMM_EXPTAB_N ? g_mmm_exptab[i] : g_mmm_logtab[i - MMM_EXPTAB_N];
 }
 
+// What a solve leaves in nev_nu / nev_lam: its number of objective evaluations, bit 30 set when an objective value was not finite in any of
+// them (the reference ignores NLopt's return code and never looks for NaN -- MMCTM.jl:141,168 --: such events are COUNTED, mmm_ctm_events),
+// the whole negated when the evaluation cap was hit.
+#define MMM_NEV_NONFINITE (1 << 30)
+__device__ __forceinline__ int nev_code(int nev, bool capped, bool nonfinite)
+{
+    const int v = nev | (nonfinite ? MMM_NEV_NONFINITE : 0);
+    return capped ? -v : v;
+}
+
 // NLopt LD_MMA, zero constraints, for the L-lane group of the calling lane (lane l holds coordinate l).  All lanes of the
-// wave execute every trip; a finished group keeps its state through selects.  Returns the number of objective
-// evaluations (negative: the evaluation cap was hit).
+// wave execute every trip; a finished group keeps its state through selects.  Returns nev_code(evaluations, cap hit, non-finite objective).
 template <int L, int LP, class Obj>
 __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb, double lb, const SolveOpts& o, const PackCtx& pc)
 {
@@ -179,6 +188,7 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
     double xcur = x, xprev = x, xprevprev = x;
     int k = 1, nev = 1;
     bool done = false, capped = false;
+    bool nonfin = !isfinite(fbest);
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
     while (!__all(done)) {
         // closed-form minimiser of the separable approximation (dual problem is trivial for m = 0)
@@ -209,6 +219,7 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         if (!done) {
             ++nev;
             xcur = xc;
+            nonfin = nonfin || !isfinite(fcur);
             inner_done = gval >= fcur;
             if (fcur < fbest) { fbest = fcur; x = xc; grad = gcur; }
             if (nev >= cap) { done = true; capped = true; inner_done = false; }
@@ -245,7 +256,7 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
             }
         }
     }
-    return capped ? -nev : nev;
+    return nev_code(nev, capped, nonfin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -882,6 +893,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
     float sprev[CPL];
     double rho = 1.0, fbest = 0.0;
     int k = 1, nev = 0;
+    bool nonfin = false;      // an objective value of the slot's document was not finite
     obj.load(dc, have ? d : -1, x);
 #pragma unroll
     for (int q = 0; q < CPL; ++q) { sigma[q] = 1.0; grad[q] = 0.0; xcur[q] = x[q]; xprev[q] = x[q]; sprev[q] = 0.f; }
@@ -912,6 +924,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
         const double gval = fbest + qsum<LPD>(gls);
         const double wval = qsum<LPD>(wls);
         const double fcur = obj.eval(xcur, gcur);
+        nonfin = (fresh ? false : nonfin) || (have && !isfinite(fcur));
         const bool live = have && !fresh;
         bool inner_done = live && gval >= fcur;
         const bool take = fresh || (live && fcur < fbest);        // accepted before the cap is looked at, as in mma_group
@@ -966,7 +979,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
         if (__any(finished)) {
             if (finished) {
                 obj.store(dc, d, x);
-                if (nev_out && l == 0) nev_out[d] = capped ? -nev : nev;
+                if (nev_out && l == 0) nev_out[d] = nev_code(nev, capped, nonfin);
             }
             // the finished slots take the next documents of the range, in slot order
             const unsigned long long fm = __ballot(finished && l == 0);
@@ -1017,9 +1030,11 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         __syncthreads();
     }
     // the wave's documents: a contiguous range
+    // (balanced: the first D % nwaves waves take one document more -- with ceil(D / nwaves) per wave a launch of one wave per SIMD over a small
+    // shard left its last waves without documents)
     const int nwaves = gridDim.x * NW, w = blockIdx.x * NW + wid;
-    const int per = (D + nwaves - 1) / nwaves;
-    const int r0 = min(D, w * per), r1 = min(D, r0 + per);
+    const int base = D / nwaves, rem = D % nwaves;
+    const int r0 = w * base + min(w, rem), r1 = r0 + base + (w < rem ? 1 : 0);
     static_assert(CPL <= 7, "modality indices are packed 4 bits each into one int");
     int modpack = 0;
 #pragma unroll

@@ -281,7 +281,9 @@ __device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logde
             const int p = eq ? (int)__builtin_ctzll(eq) : c;        // (no lane compares equal only if the column holds NaNs)
             if (tid == p) { *s_piv = p; s_pv[0] = a; }
             if (tid == c) s_pv[1] = a;
-            if (tid == 0) { s_best[c] = best; if (!(best > 0.0)) *singular = 1; }
+            // an exactly zero pivot column is LAPACK's SingularException upstream (`inv(Σ)`, MMCTM.jl:211); a NaN one is not -- the reference
+            // carries on with a NaN inverse, and so does this (counted: mmm_ctm_events)
+            if (tid == 0) { s_best[c] = best; if (best == 0.0) *singular = 1; }
         }
         __syncthreads();
         const int p = *s_piv;

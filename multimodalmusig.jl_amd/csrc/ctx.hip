@@ -46,6 +46,10 @@ int mmm_ctx_create(int device_id, mmm_ctx** out)
 static void ctx_teardown(mmm_ctx* ctx)
 {
     (void)hipSetDevice(ctx->device);
+    // nothing in flight may still touch the events or the pinned block freed below -- whoever the caller is (the last model's destroy has
+    // synchronised already; this does not depend on it)
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pin_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pin_ctl) (void)hipHostFree(ctx->pin_ctl);
@@ -194,6 +198,13 @@ int mmm_ctx_set_tuning(mmm_ctx* ctx, const mmm_tuning_opts* opts)
               "mmm_ctx_set_tuning: unknown build (lda_build %d, ctm_build %d)", t.lda_build, t.ctm_build);
     MMM_CHECK(ctx, t.geometry_cus >= 0 && t.grid_blocks >= 0 && t.waves_per_block >= 0 && t.moment_blocks >= 0 && t.resident_cap >= 0 && t.side_stream >= -1 && t.side_stream <= 1,
               "mmm_ctx_set_tuning: negative size or side_stream outside -1..1");
+    // a caller built against a newer header must not have its choices dropped in silence
+    MMM_CHECK(ctx, (t.disable & ~(unsigned)MMM_OFF_ALL) == 0, "mmm_ctx_set_tuning: unknown bits 0x%x in `disable` (this build knows 0x%x)", t.disable & ~(unsigned)MMM_OFF_ALL,
+              (unsigned)MMM_OFF_ALL);
+    for (int r : t.reserved) MMM_CHECK(ctx, r == 0, "mmm_ctx_set_tuning: a reserved field is %d, not 0 (a newer header's option?)", r);
+    MMM_CHECK(ctx, t.solve_lanes == 0 || t.solve_lanes == 2 || t.solve_lanes == 8 || t.solve_lanes == 16 || t.solve_lanes == 32,
+              "mmm_ctx_set_tuning: solve_lanes %d (0, 2, 8, 16 or 32)", t.solve_lanes);
+    MMM_CHECK(ctx, t.solve_waves >= 0 && t.solve_waves <= 8, "mmm_ctx_set_tuning: solve_waves %d (0..8)", t.solve_waves);
     ctx->tune = t;
     return MMM_OK;
 }

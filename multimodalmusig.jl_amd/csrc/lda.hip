@@ -1101,6 +1101,24 @@ int mmm_lda_set(mmm_lda* m, int field, const double* host, size_t n)
     return MMM_OK;
 }
 
+int mmm_lda_set_hyper(mmm_lda* m, double alpha, const double* eta, int n_eta)
+{
+    if (!m) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prepare_call(m);
+    if (rc) return rc;
+    MMM_CHECK(ctx, eta && n_eta == (m->ilda ? m->ids.I : 1), "mmm_lda_set_hyper: expected %d eta value(s), got %d", m->ilda ? m->ids.I : 1, n_eta);
+    bool same = alpha == m->alpha && eta[0] == m->eta;
+    if (m->ilda) for (int i = 0; i < n_eta; ++i) same = same && eta[i] == m->ids.eta[i];
+    if (same) return MMM_OK;
+    // gamma_{t+1}, which the last fused pass has formed with the old alpha, is dropped: the next pass starts from phi (LDA.jl:82-90)
+    if ((rc = materialise_phi(m)) || (rc = flush_ll(m, nullptr))) return rc;
+    m->gnext_valid = false; m->phi_from_prev = false;
+    m->alpha = alpha; m->eta = eta[0];
+    if (m->ilda) for (int i = 0; i < n_eta; ++i) m->ids.eta[i] = eta[i];
+    return MMM_OK;
+}
+
 int mmm_lda_update_gamma(mmm_lda* m)
 {
     if (!m) return MMM_ERR_ARG;
@@ -1246,6 +1264,21 @@ int mmm_lda_ll_history(mmm_lda* m, double* ll, int max_n, int* n)
     // error here, not a silently wrong last row)
     if ((rc = mmm_p2p_check(ctx))) return rc;
     *n = cnt;
+    return MMM_OK;
+}
+
+int mmm_lda_events(mmm_lda* m, int64_t out[4])
+{
+    if (!m || !out) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prepare_call(m);
+    if (rc || (rc = flush_ll(m, nullptr))) return rc;
+    std::vector<double> ll((size_t)std::max(m->n_hist, 0));
+    if (!ll.empty()) MMM_HIP(ctx, hipMemcpyAsync(ll.data(), m->ll_hist.p, sizeof(double) * ll.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = mmm_p2p_check(ctx))) return rc;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (double v : ll) if (!std::isfinite(v)) ++out[2];
     return MMM_OK;
 }
 

@@ -100,6 +100,7 @@ class _CTM:
                                          tp, cp, ptr[0], ptr[1], ptr[2], gamma0.ravel(), C.byref(self._opts), C.byref(self._h)),
               self.ctx.h, "mmm_ctm_create_batch")
         _lib.track(self)
+        self._alpha_dev = np.ascontiguousarray(alpha_flat, dtype=np.float64).ravel().copy()
         self.restart_ll = None; self.restart_elbo = None; self.restart_converged = None; self.restart_iters = None
 
     # ---- restart batch (scripts/run_mmctm.jl:77-134) -------------------------------------------------------------------
@@ -110,9 +111,21 @@ class _CTM:
         self._refresh_alpha()
         return self
 
+    def _push_alpha(self):
+        """`model.α` is a plain mutable field upstream (MMCTM.jl:12, IMMCTM.jl:11): what the caller has assigned since the last refresh goes
+        to the device before any function that reads it (fit!, update_γ!, update_α!, the ELBO) -- of the selected restart in a batch."""
+        flat = np.ascontiguousarray(np.concatenate([np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in self.α]) if self._immctm
+                                    else np.asarray(self.α, dtype=np.float64)).ravel()
+        if flat.size != self._nalpha:
+            raise ValueError("model.α holds %d values, expected %d" % (flat.size, self._nalpha))
+        if not np.array_equal(flat, getattr(self, "_alpha_dev", None)):
+            self._set("alpha", flat)
+            self._alpha_dev = flat.copy()
+
     def _refresh_alpha(self):
         """model.α mirrors the device value of the selected restart (it changes under update_α! / autoα)."""
         a = self._get("alpha")
+        self._alpha_dev = a.copy()
         if self._immctm:
             off = np.concatenate([[0], np.cumsum(self.I)])
             self.α = [a[off[m]:off[m + 1]].copy() for m in range(self.M)]
@@ -228,6 +241,13 @@ class _CTM:
         if per_doc:
             r["per_doc_nu"], r["per_doc_lambda"] = pn, pl
         return r
+
+    def events(self):
+        """Non-fatal events, counted as the reference would carry on (mmm_ctm_events): LD_MMA solves of the last E-step that hit the evaluation
+        cap / met a non-finite objective value, and non-finite values in the log-likelihood history."""
+        out = (C.c_int64 * 4)()
+        check(lib().mmm_ctm_events(self._h, out), self.ctx.h, "events")
+        return {"n_capped": int(out[0]), "n_nonfinite": int(out[1]), "n_nonfinite_ll": int(out[2])}
 
     def geometry(self):
         """Launch geometry that fixes the order of the sums across documents (mmm_ctm_geometry)."""
@@ -455,6 +475,7 @@ def update_Σ(model):              # MMCTM.jl:204-212
 
 
 def update_γ_ctm(model):          # MMCTM.jl:224-242 / IMMCTM.jl:199-223
+    model._push_alpha()
     _call(model, "mmm_ctm_update_gamma", "update_γ!")
 
 
@@ -463,6 +484,7 @@ def update_Elnϕ(model):           # MMCTM.jl:214-222 / IMMCTM.jl:188-197
 
 
 def update_α(model):              # MMCTM.jl:252-269 / IMMCTM.jl:225-244
+    model._push_alpha()
     _call(model, "mmm_ctm_update_alpha", "update_α!")
     model._refresh_alpha()
 
@@ -491,6 +513,7 @@ def _fit_flags(autoα, updateΣ):
 
 def _fit_ctm(model, maxiter, tol, verbose, autoα=False, updateΣ=True):
     maxiter = 100 if maxiter is None else int(maxiter)
+    model._push_alpha()
     ll = np.zeros(maxiter * model.M); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
     check(lib().mmm_ctm_fit(model._h, maxiter, float(tol), _fit_flags(autoα, updateΣ), ll.ctypes.data, C.byref(ni), C.byref(cv), C.byref(el)),
           model.ctx.h, "fit!(::%s)" % type(model).__name__)

@@ -6,6 +6,12 @@
 # library handle; after `fit!` the fields the reference exposes (ϕ, θ, γ, λ, μ, Σ, props, elbo, ll, converged, ...) are
 # downloaded into ordinary Julia arrays of the reference's shapes.
 #
+# MUTATION IN PLACE.  Upstream the Julia arrays ARE the model: a caller may assign any field and then call any function --
+# scripts/run_mmctm.jl:124-131 overwrites `model.γ[m]`, `model.Elnϕ[m]`, `model.ϕ[m]` and calls `fit!`.  Every entry point here
+# therefore uploads, before its `ccall`, the fields the reference function READS BEFORE IT WRITES THEM (`FIT_READS` for `fit!`, every
+# field for the stage functions) and downloads afterwards what it writes.  tests/test_julia_shim_cpu.py holds the read / write sets of
+# every reference function and checks them against this file.
+#
 # The un-exported functions the reference's own test-suite drives the path through (test/lda.jl, ilda.jl, mmctm.jl, immctm.jl,
 # common.jl: `MultiModalMuSig.update_ϕ!(model)`, `update_ζ!(model, d)`, `calculate_sumθ(model, d)`, `λ_objective(...)`,
 # `calculate_modality_loglikelihood(...)`, `calculate_ElnPβ(model)`, ...) are all defined here under the same names and
@@ -24,6 +30,7 @@
 module MultiModalMuSigHIP
 
 using DataFrames
+using Random
 
 export IMMCTM, MMCTM, ILDA, LDA, fit!, format_counts_lda, format_counts_ctm, format_counts_mmctm
 
@@ -46,11 +53,12 @@ end
 # (0 auto, 1 sparse, 2 dense, 3 wide), a pinned launch geometry (`geometry_cus`: same bits on any gfx950 device), the side stream, ...
 struct TuningOpts
     lda_build::Cint; ctm_build::Cint; geometry_cus::Cint; grid_blocks::Cint; waves_per_block::Cint; moment_blocks::Cint
-    side_stream::Cint; resident_cap::Cint; disable::Cuint; reserved::NTuple{7,Cint}
+    side_stream::Cint; resident_cap::Cint; disable::Cuint; solve_lanes::Cint; solve_waves::Cint; reserved::NTuple{5,Cint}
 end
 function set_tuning!(ctx::Context; lda_build=0, ctm_build=0, geometry_cus=0, grid_blocks=0, waves_per_block=0, moment_blocks=0, side_stream=0,
-                     resident_cap=0, disable=0)
-    t = Ref(TuningOpts(lda_build, ctm_build, geometry_cus, grid_blocks, waves_per_block, moment_blocks, side_stream, resident_cap, disable, ntuple(i -> Cint(0), 7)))
+                     resident_cap=0, disable=0, solve_lanes=0, solve_waves=0)
+    t = Ref(TuningOpts(lda_build, ctm_build, geometry_cus, grid_blocks, waves_per_block, moment_blocks, side_stream, resident_cap, disable, solve_lanes, solve_waves,
+                       ntuple(i -> Cint(0), 5)))
     rc = ccall((:mmm_ctx_set_tuning, LIB), Cint, (Ptr{Cvoid}, Ref{TuningOpts}), ctx.h, t)
     rc == 0 || error("mmm_ctx_set_tuning: " * unsafe_string(ccall((:mmm_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.h)))
     return ctx
@@ -186,15 +194,42 @@ function download!(model::LDA)
     return model
 end
 
-# Julia arrays -> device, every field (see the header comment: the arrays are the model between stage calls)
-function upload!(model::LDA)
-    for f in (:λ, :Elnβ, :β, :γ, :Elnθ, :θ) lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f)))) end
-    lda_set(model, 6, flatten_ϕ(model))
+# one field Julia array -> device.  :α / :η are the hyper-parameters (plain mutable fields upstream: `model.α = 0.5; fit!(model)`)
+function upload_field!(model::LDA, f::Symbol)
+    if f == :ϕ
+        lda_set(model, 6, flatten_ϕ(model))
+    elseif f == :α || f == :η
+        lda_set_hyper(model, model.α, Float64[model.η])
+    else
+        lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f))))
+    end
     return model
 end
 
-# fit!(model; maxiter, tol, verbose) -- LDA.jl:198-224
-function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true)
+const LDA_ALL_FIELDS = (:α, :η, :λ, :Elnβ, :β, :γ, :Elnθ, :θ, :ϕ)
+# Julia arrays -> device, every field (see the header comment: the arrays are the model between stage calls)
+function upload!(model::LDA)
+    for f in LDA_ALL_FIELDS upload_field!(model, f) end
+    return model
+end
+
+# What `fit!` reads before it writes it.  LDA.jl:198-224 / ILDA.jl:246-272: update_γ! reads ϕ and α (LDA.jl:83-87), update_ϕ! reads Elnβ
+# (:72; its Elnθ has just been written by update_γ!), update_λ! reads η (:101).  γ, Elnθ, θ, λ, β are written before anything reads them.
+# MMCTM.jl:457-494 / IMMCTM.jl:437-466: fitdoc! reads λ, ν (update_ζ! :172-181, and the start points of both LD_MMA solves), Elnϕ (update_θ!
+# :190), μ and invΣ (the objectives, common.jl:11-36); update_γ! reads α (:226); with updateΣ = false Σ and invΣ are never written and the
+# ELBO reads both; γ and ϕ are written (update_γ!, update_ϕ!) before they are read but belong to the topics a caller seeds together with
+# Elnϕ (run_mmctm.jl:126-128), so they go up with it.  ζ, θ, props are written before they are read: not uploaded.
+const FIT_READS = (LDA = (:α, :η, :Elnβ, :ϕ), ILDA = (:α, :η, :Elnβ, :ϕ),
+                   MMCTM = (:α, :μ, :Σ, :invΣ, :γ, :Elnϕ, :ϕ, :λ, :ν), IMMCTM = (:α, :μ, :Σ, :invΣ, :γ, :Elnϕ, :λ, :ν))
+function upload_fit_reads!(model)
+    for f in FIT_READS[nameof(typeof(model))] upload_field!(model, f) end
+    return model
+end
+
+# fit!(model; maxiter, tol, verbose) -- LDA.jl:198-224.  `resident = true` (not upstream) skips the upload: the caller states that no array
+# of the model has been assigned since the last call returned (a 10k x 96-term ϕ is 77 MB).
+function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true, resident=false)
+    resident || upload_fit_reads!(model)
     ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_lda_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
                 model.h, maxiter, tol, ll, n, cv, elbo), model.ctx, "mmm_lda_fit")
@@ -205,6 +240,10 @@ function fit!(model::LDA; maxiter=1000, tol=1e-4, verbose=true)
     model.converged = cv[] != 0; model.elbo = elbo[]; model.ll = ll[end]
     download!(model)
     return ll
+end
+
+function lda_set_hyper(model, α::Float64, η::Vector{Float64})
+    check(ccall((:mmm_lda_set_hyper, LIB), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Cint), model.h, α, η, length(η)), model.ctx, "mmm_lda_set_hyper")
 end
 
 function lda_set(model, field::Int, v::Vector{Float64})
@@ -319,11 +358,21 @@ end
 
 packed_factors(fs) = reduce(vcat, [vec(Matrix{Float64}(f)) for f in fs]; init=Float64[])
 
+function upload_field!(model::ILDA, f::Symbol)
+    if f == :ϕ
+        lda_set(model, 6, flatten_ϕ(model))
+    elseif f == :α || f == :η
+        lda_set_hyper(model, model.α, Vector{Float64}(model.η))
+    elseif f in (:λ, :Elnβ, :β)      # the factor arrays; the library derives its effective V x K tables from the uploaded Elnβ[i] / β[i]
+        lda_set(model, ILDA_FACTOR_FIELDS[f], packed_factors(getfield(model, f)))
+    else
+        lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f))))
+    end
+    return model
+end
+
 function upload!(model::ILDA)
-    # the factor arrays; the library derives its effective V x K tables from the uploaded Elnβ[i] / β[i]
-    for f in (:λ, :Elnβ, :β) lda_set(model, ILDA_FACTOR_FIELDS[f], packed_factors(getfield(model, f))) end
-    for f in (:γ, :Elnθ, :θ) lda_set(model, LDA_FIELDS[f], vec(Matrix{Float64}(getfield(model, f)))) end
-    lda_set(model, 6, flatten_ϕ(model))
+    for f in LDA_ALL_FIELDS upload_field!(model, f) end
     return model
 end
 
@@ -383,7 +432,8 @@ calculate_loglikelihood(X::Vector{Matrix{Int}}, model::ILDA) = calculate_loglike
 calculate_loglikelihood(model::ILDA) = calculate_loglikelihood(model.X, model.features, model.θ, model.β; ctx=model.ctx)
 
 # fit!(model; maxiter, tol, verbose) -- ILDA.jl:246-272
-function fit!(model::ILDA; maxiter=1000, tol=1e-4, verbose=true)
+function fit!(model::ILDA; maxiter=1000, tol=1e-4, verbose=true, resident=false)
+    resident || upload_fit_reads!(model)
     ll = Vector{Float64}(undef, maxiter); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_lda_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
                 model.h, maxiter, tol, ll, n, cv, elbo), model.ctx, "mmm_lda_fit")
@@ -491,7 +541,8 @@ function download!(model::MMCTM)
 end
 
 # fit!(model; maxiter, tol, verbose, autoα, updateΣ) -- MMCTM.jl:457-494
-function fit!(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true)
+function fit!(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true, resident=false)
+    resident || upload_fit_reads!(model)      # scripts/run_mmctm.jl:124-131 assigns γ[m] / Elnϕ[m] / ϕ[m] and then calls fit!
     M = model.M
     ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
@@ -533,6 +584,88 @@ function select_restart!(model::MMCTM, h::Ptr{Cvoid}, r::Int)
     old = model.h; model.h = h
     download!(model)
     model.h = old
+    return model
+end
+
+# ---- the restart driver of scripts/run_mmctm.jl:77-182 under its own names -----------------------------------------------------------
+# `fit_model(counts, K, α, V, restarts, verbose, seed, progress)` is what the script's `main` calls (:270).  Stage 1 (`fit_seed_models`,
+# :97-109: one `fit_restart` per seed under `pmap`) is ONE restart batch here; the γ₀ of restart i is what `MMCTM(K, α, V, counts)` draws
+# after `Random.seed!(seeds[i])` (:78-81), so a seed means what it means upstream.  `progress` is accepted and ignored (no worker processes).
+draw_γ0(K::Vector{Int}, V::Vector{Int}) = [[Float64.(rand(1:100, V[m])) for kk in 1:K[m]] for m in 1:length(K)]      # MMCTM.jl:60-63
+
+function fit_restart(seed, K, α, V, counts; ctx::Context=default_context())                       # run_mmctm.jl:77-84
+    Random.seed!(seed)
+    model = MMCTM(K, α, V, counts; ctx=ctx)
+    fit!(model, maxiter=1000, tol=1e-4, verbose=false, resident=true)
+    return model
+end
+
+# run_mmctm.jl:86-97 on the [restart, modality] matrix of final log-likelihoods: the best restart of every modality
+pick_optimal_modality_restarts(ll::Matrix{Float64}) = vec([x[1] for x in findmax(ll; dims=1)[2]])
+pick_optimal_modality_models(models) = models[pick_optimal_modality_restarts(permutedims(reduce(hcat, [m.ll for m in models])))]
+
+function fit_seed_models(counts, K, α, V, seeds; progress=false, ctx::Context=default_context())      # run_mmctm.jl:99-111
+    γ0s = map(seeds) do seed
+        Random.seed!(seed)
+        draw_γ0(K, V)
+    end
+    h, hist, converged, elbo = fit_restarts(K, α, V, counts, γ0s; maxiter=1000, tol=1e-4, ctx=ctx)
+    ll = permutedims(reduce(hcat, [hist[r][end] for r in 1:length(seeds)]))                         # [restart, modality]
+    opt = pick_optimal_modality_restarts(ll)
+    opt_models = map(1:length(K)) do m
+        Random.seed!(seeds[opt[m]])
+        model = MMCTM(K, α, V, counts; ctx=ctx)
+        select_restart!(model, h, opt[m])
+        model.ll = hist[opt[m]][end]; model.converged = converged[opt[m]]; model.elbo = elbo[opt[m]]
+        model
+    end
+    check(ccall((:mmm_ctm_destroy, LIB), Cint, (Ptr{Cvoid},), h), ctx, "mmm_ctm_destroy")
+    return opt_models
+end
+
+function seed_and_fit_restart(seed, opt_models; verbose=false, ctx::Context=opt_models[1].ctx)      # run_mmctm.jl:113-134
+    Random.seed!(seed)
+    K = opt_models[1].K; α = opt_models[1].α; V = opt_models[1].V; counts = opt_models[1].X
+    model = MMCTM(K, α, V, counts; ctx=ctx)
+    for m in 1:length(K)
+        model.γ[m] = deepcopy(opt_models[m].γ[m])
+        model.Elnϕ[m] = deepcopy(opt_models[m].Elnϕ[m])
+        model.ϕ[m] = deepcopy(opt_models[m].ϕ[m])
+    end
+    fit!(model, maxiter=1000, tol=1e-5, verbose=verbose)      # uploads γ, Elnϕ, ϕ (FIT_READS) before the first pass
+    return model
+end
+
+# StatsBase.denserank
+function denserank(x)
+    u = sort(unique(x))
+    return [searchsortedfirst(u, v) for v in x]
+end
+
+function pick_optimal_model(models)                                                                 # run_mmctm.jl:136-147
+    ll = permutedims(reduce(hcat, [m.ll for m in models]))
+    ranks = reduce(hcat, [Float64.(denserank(abs.(ll[:, i]))) for i in 1:size(ll, 2)])
+    return models[findmin(vec(sum(ranks, dims=2)) ./ size(ll, 2))[2]]
+end
+
+# run_mmctm.jl:149-161 fits one seeded model per seed and ranks them.  Every one of those fits starts from the same γ / Elnϕ / ϕ -- the seed
+# only feeds the constructor's random γ, which is overwritten, and `NLopt.srand`, which the deterministic LD_MMA never reads -- so they are the
+# same fit: it is run once.
+seed_and_fit_model(opt_models, seeds; progress=false) = pick_optimal_model([seed_and_fit_restart(seeds[1], opt_models)])
+
+function fit_model(counts, K, α, V, restarts, verbose, seed, progress; ctx::Context=default_context())   # run_mmctm.jl:163-182
+    Random.seed!(seed)
+    seeds = rand(1:typemax(Int), restarts)
+    seed_models = fit_seed_models(counts, K, α, V, seeds; progress=progress, ctx=ctx)
+    if verbose
+        println("Modality optimal model log-likelihoods:")
+        for m in 1:length(K) println(m, ": ", seed_models[m].ll) end
+    end
+    model = seed_and_fit_model(seed_models, seeds; progress=progress)
+    if verbose
+        println("Seeded model log-likelihoods:")
+        println(model.ll)
+    end
     return model
 end
 
@@ -617,7 +750,8 @@ function IMMCTM(k::Vector{Int}, α::Vector{Float64}, features::Vector{Matrix{Int
     return IMMCTM(k, Vector{Float64}[fill(α[m], I[m]) for m in 1:length(features)], features, X; kw...)
 end
 
-function fit!(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false)    # IMMCTM.jl:437-466
+function fit!(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, resident=false)    # IMMCTM.jl:437-466
+    resident || upload_fit_reads!(model)
     M = model.M
     ll = Vector{Float64}(undef, maxiter * M); n = Ref{Cint}(0); cv = Ref{Cint}(0); elbo = Ref{Cdouble}(0.0)
     check(ccall((:mmm_ctm_fit, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}, Ref{Cdouble}),
@@ -691,19 +825,43 @@ flat_θ(model) = reduce(vcat, [reduce(vcat, [vec(Matrix{Float64}(model.θ[d][m])
 topic_flat(model::MMCTM, nested) = Vector{Float64}(flat(nested))
 topic_flat(model::IMMCTM, nested) = Vector{Float64}(flat3(nested))
 
+# one field Julia array -> device
+function upload_field!(model::CTM, f::Symbol)
+    if f == :μ
+        ctm_set(model, 0, Vector{Float64}(model.μ))
+    elseif f == :Σ
+        ctm_set(model, 1, vec(Matrix{Float64}(model.Σ)))
+    elseif f == :invΣ
+        ctm_set(model, 2, vec(Matrix{Float64}(model.invΣ)))
+    elseif f == :γ
+        ctm_set(model, 3, topic_flat(model, model.γ))
+    elseif f == :Elnϕ
+        ctm_set(model, 4, topic_flat(model, model.Elnϕ))
+    elseif f == :ϕ
+        ctm_set(model, 5, topic_flat(model, model.ϕ))
+    elseif f == :λ
+        ctm_set(model, 6, flat_docs(model.λ))
+    elseif f == :ν
+        ctm_set(model, 7, flat_docs(model.ν))
+    elseif f == :ζ
+        ctm_set(model, 8, flat_docs(model.ζ))
+    elseif f == :props
+        ctm_set(model, 9, reduce(vcat, [reduce(vcat, model.props[d]) for d in 1:model.D]; init=Float64[]))
+    elseif f == :θ
+        ctm_set(model, 10, flat_θ(model))
+    elseif f == :α
+        ctm_set(model, 11, model isa MMCTM ? Vector{Float64}(model.α) : Vector{Float64}(reduce(vcat, model.α)))
+    else
+        error("unknown field $f")
+    end
+    return model
+end
+
+const MMCTM_ALL_FIELDS = (:α, :μ, :Σ, :invΣ, :γ, :Elnϕ, :ϕ, :λ, :ν, :ζ, :props, :θ)
+const IMMCTM_ALL_FIELDS = (:α, :μ, :Σ, :invΣ, :γ, :Elnϕ, :λ, :ν, :ζ, :θ)          # no ϕ / props fields (IMMCTM.jl:1-27)
 # Julia arrays -> device, every field (the arrays are the model between stage calls)
 function upload!(model::CTM)
-    ctm_set(model, 0, Vector{Float64}(model.μ)); ctm_set(model, 1, vec(Matrix{Float64}(model.Σ))); ctm_set(model, 2, vec(Matrix{Float64}(model.invΣ)))
-    ctm_set(model, 3, topic_flat(model, model.γ)); ctm_set(model, 4, topic_flat(model, model.Elnϕ))
-    ctm_set(model, 6, flat_docs(model.λ)); ctm_set(model, 7, flat_docs(model.ν)); ctm_set(model, 8, flat_docs(model.ζ))
-    ctm_set(model, 10, flat_θ(model))
-    if model isa MMCTM
-        ctm_set(model, 5, topic_flat(model, model.ϕ))
-        ctm_set(model, 9, reduce(vcat, [reduce(vcat, model.props[d]) for d in 1:model.D]; init=Float64[]))
-        ctm_set(model, 11, Vector{Float64}(model.α))
-    else
-        ctm_set(model, 11, Vector{Float64}(reduce(vcat, model.α)))
-    end
+    for f in (model isa MMCTM ? MMCTM_ALL_FIELDS : IMMCTM_ALL_FIELDS) upload_field!(model, f) end
     return model
 end
 
@@ -831,6 +989,20 @@ calculate_ElnPX(model::CTM) = elbo_terms(model)[2][4]
 calculate_ElnQϕ(model::CTM) = elbo_terms(model)[2][5]
 calculate_ElnQη(model::CTM) = elbo_terms(model)[2][6]
 calculate_ElnQZ(model::CTM) = elbo_terms(model)[2][7]
+
+# Non-fatal events, counted where upstream silently carries on (NLopt's return code is dropped, MMCTM.jl:141,168; nothing checks for NaN):
+# (solves of the last E-step that hit the evaluation cap, solves of the last E-step that met a non-finite objective value, non-finite
+# values in the log-likelihood history) -- mmm_ctm_events / mmm_lda_events.  Read-only: nothing is uploaded.
+function events(model::CTM)
+    out = zeros(Int64, 4)
+    check(ccall((:mmm_ctm_events, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), model.h, out), model.ctx, "mmm_ctm_events")
+    return (n_capped=out[1], n_nonfinite=out[2], n_nonfinite_ll=out[3])
+end
+function events(model::TopicModel)
+    out = zeros(Int64, 4)
+    check(ccall((:mmm_lda_events, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), model.h, out), model.ctx, "mmm_lda_events")
+    return (n_capped=out[1], n_nonfinite=out[2], n_nonfinite_ll=out[3])
+end
 
 # ---- FREE FUNCTIONS of src/common.jl and the log-likelihood helpers: caller arrays in, one `ccall` each ---------------------------
 # λ_objective(λ, ∇λ, ν, Ndivζ, sumθ, μ, invΣ) -- common.jl:11-23 (∇λ is filled in place when it has elements, as upstream)

@@ -94,6 +94,12 @@ class LDA:
     def _mat(self, name, rows, cols):
         return self._get(name).reshape(rows, cols, order="F")
 
+    def _push_hyper(self):
+        """`model.α` / `model.η` are plain mutable fields upstream (LDA.jl:7,11; ILDA.jl:8,12): what the caller has assigned goes to the
+        device before any function that reads them (mmm_lda_set_hyper does nothing when they are unchanged)."""
+        eta = np.ascontiguousarray(np.atleast_1d(np.asarray(self.η, dtype=np.float64)))
+        check(lib().mmm_lda_set_hyper(self._h, float(self.α), eta, int(eta.size)), self.ctx.h, "mmm_lda_set_hyper")
+
     # V x K fields
     λ = property(lambda s: s._mat("lambda", s.V, s.K), lambda s, v: s._set("lambda", np.asarray(v, float).ravel(order="F")))
     Elnβ = property(lambda s: s._mat("Elnbeta", s.V, s.K), lambda s, v: s._set("Elnbeta", np.asarray(v, float).ravel(order="F")))
@@ -128,6 +134,12 @@ class LDA:
     def phi_flat(self):
         """ϕ as one [nnz, K] array (document blocks concatenated)."""
         return self._get("phi").reshape(-1, self.K)
+
+    def events(self):
+        """Non-fatal events (mmm_lda_events): non-finite values in the log-likelihood history (LDA has no LD_MMA solves)."""
+        out = (C.c_int64 * 4)()
+        check(lib().mmm_lda_events(self._h, out), self.ctx.h, "events")
+        return {"n_capped": int(out[0]), "n_nonfinite": int(out[1]), "n_nonfinite_ll": int(out[2])}
 
     def geometry(self):
         """E-step build and launch geometry of the handle (mmm_lda_geometry)."""
@@ -224,6 +236,7 @@ def _call(model, fn, what):
 
 def update_γ(model):   # LDA.jl:82-90 ; MMCTM.jl:224-242 ; IMMCTM.jl:199-223
     if isinstance(model, LDA):
+        model._push_hyper()
         _call(model, "mmm_lda_update_gamma", "update_γ!")
     else:
         from . import ctm
@@ -240,6 +253,7 @@ def update_ϕ(model):   # LDA.jl:69-76 ; MMCTM.jl:244-250
 
 def update_λ(model, d=None):   # LDA.jl:100-108 ; MMCTM.jl:127-143
     if isinstance(model, LDA):
+        model._push_hyper()
         _call(model, "mmm_lda_update_lambda", "update_λ!")
     else:
         from . import ctm
@@ -283,6 +297,10 @@ def calculate_loglikelihood(model, θ=None, β=None, ctx=None):
 
 def calculate_elbo(model, terms=False):   # LDA.jl:162-172 / MMCTM.jl:372-382
     v = C.c_double(); t = np.zeros(7)
+    if isinstance(model, LDA):
+        model._push_hyper()
+    else:
+        model._push_alpha()
     fn = lib().mmm_lda_elbo if isinstance(model, LDA) else lib().mmm_ctm_elbo
     check(fn(model._h, C.byref(v), t.ctypes.data), model.ctx.h, "calculate_elbo")
     return (v.value, t) if terms else v.value
@@ -293,6 +311,7 @@ def fit(model, maxiter=None, tol=1e-4, verbose=True, **kw):
     IMMCTM.jl:437-466 (default 100).  Returns the log-likelihood history and sets converged/elbo/ll."""
     if isinstance(model, LDA):
         maxiter = 1000 if maxiter is None else int(maxiter)
+        model._push_hyper()
         ll = np.zeros(maxiter); ni = C.c_int(); cv = C.c_int(); el = C.c_double()
         check(lib().mmm_lda_fit(model._h, maxiter, float(tol), ll.ctypes.data, C.byref(ni), C.byref(cv), C.byref(el)),
               model.ctx.h, "fit!(::LDA)")

@@ -145,9 +145,11 @@ def test_shim_keeps_the_reference_api_surface():
     assert exp
     names = {n.strip() for n in exp.group(1).split(",")}
     assert {"LDA", "MMCTM", "IMMCTM", "ILDA", "fit!"} <= names
-    assert re.search(r"function fit!\(model::LDA; maxiter=1000, tol=1e-4, verbose=true\)", txt)
-    assert re.search(r"function fit!\(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true\)", txt)
-    assert re.search(r"function fit!\(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false\)", txt)
+    # the reference's keywords with the reference's defaults, in the reference's order (`resident` is this shim's one addition, default off)
+    assert re.search(r"function fit!\(model::LDA; maxiter=1000, tol=1e-4, verbose=true, resident=false\)", txt)
+    assert re.search(r"function fit!\(model::ILDA; maxiter=1000, tol=1e-4, verbose=true, resident=false\)", txt)
+    assert re.search(r"function fit!\(model::MMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, updateΣ=true, resident=false\)", txt)
+    assert re.search(r"function fit!\(model::IMMCTM; maxiter=100, tol=1e-4, verbose=true, autoα=false, resident=false\)", txt)
 
 
 def test_python_binding_table_matches_the_header(mmm):
@@ -264,3 +266,188 @@ def test_stage_calls_go_through_upload_and_write_back():
         assert all("upload!(model)" in body for _, _, _, _, body in methods[helper]), "%s does not upload the model's arrays before its ccall" % helper
     for name in ("update_ζ!", "update_θ!", "update_ν!", "update_λ!"):      # per-document forms: (model, d), document d only
         assert any(npos == 2 and "ctm_doc_stage!" in body for _, npos, _, _, body in methods[name]), name
+
+
+# ---- data flow: which fields every entry point uploads BEFORE its ccall and downloads AFTER it -------------------------------------------
+# The reference's functions work on the Julia arrays themselves, so a caller may assign any field and call any function
+# (scripts/run_mmctm.jl:124-131 assigns γ[m] / Elnϕ[m] / ϕ[m] and calls fit!).  Per reference function: the fields it READS BEFORE IT WRITES
+# THEM and the fields it WRITES, read off the reference's source (file:line in the comments).  The shim must upload a superset of the first
+# and download a superset of the second.  (Round 4's shim passed every name / arity / prototype check while fit! uploaded nothing.)
+_ALL = "ALL"
+REF_DATA_FLOW = {
+    # LDA.jl / ILDA.jl (same functions on both)
+    ("LDA", "update_ϕ!"): ({"Elnθ", "Elnβ"}, {"ϕ"}),                    # LDA.jl:69-76
+    ("LDA", "update_Elnθ!"): ({"γ"}, {"Elnθ"}),                          # :78-80
+    ("LDA", "update_γ!"): ({"α", "ϕ"}, {"γ", "Elnθ"}),                   # :82-90
+    ("LDA", "update_θ!"): ({"γ"}, {"θ"}),                                # :92-94
+    ("LDA", "update_Elnβ!"): ({"λ"}, {"Elnβ"}),                          # :96-98
+    ("LDA", "update_λ!"): ({"η", "ϕ"}, {"λ", "Elnβ"}),                   # :100-108
+    ("LDA", "update_β!"): ({"λ"}, {"β"}),                                # :110-112
+    ("LDA", "calculate_elbo"): ({"α", "η", "λ", "Elnβ", "γ", "Elnθ", "ϕ"}, set()),      # :114-172
+    # fit! LDA.jl:198-224: update_γ! first (reads ϕ, α), update_ϕ! (reads Elnβ; Elnθ was just written), update_λ! (reads η; ϕ just written)
+    ("LDA", "fit!"): ({"α", "η", "Elnβ", "ϕ"}, _ALL),
+    ("ILDA", "fit!"): ({"α", "η", "Elnβ", "ϕ"}, _ALL),                   # ILDA.jl:246-272
+    # MMCTM.jl / IMMCTM.jl
+    ("CTM", "update_ζ!"): ({"λ", "ν"}, {"ζ"}),                           # MMCTM.jl:172-181
+    ("CTM", "update_θ!"): ({"λ", "Elnϕ"}, {"θ"}),                        # :183-198
+    ("CTM", "update_ν!"): ({"ν", "λ", "ζ", "μ", "invΣ"}, {"ν"}),         # :156-170, common.jl:25-36
+    ("CTM", "update_λ!"): ({"λ", "ν", "ζ", "θ", "μ", "invΣ"}, {"λ"}),    # :127-143, common.jl:11-23
+    ("CTM", "update_μ!"): ({"λ"}, {"μ"}),                                # :200-202
+    ("CTM", "update_Σ!"): ({"λ", "ν", "μ"}, {"Σ", "invΣ"}),              # :204-212
+    ("CTM", "update_Elnϕ!"): ({"γ"}, {"Elnϕ"}),                          # :214-222
+    ("CTM", "update_γ!"): ({"α", "θ"}, {"γ", "Elnϕ"}),                   # :224-242
+    ("CTM", "update_α!"): ({"α", "Elnϕ"}, {"α"}),                        # :252-269
+    ("MMCTM", "update_ϕ!"): ({"γ"}, {"ϕ"}),                              # :244-250
+    ("MMCTM", "update_props!"): ({"λ"}, {"props"}),                      # :145-154
+    ("CTM", "calculate_sumθ"): ({"θ"}, set()),                           # :110-117
+    ("CTM", "calculate_Ndivζ"): ({"ζ"}, set()),                          # :119-125
+    ("CTM", "calculate_elbo"): ({"α", "μ", "Σ", "invΣ", "γ", "Elnϕ", "λ", "ν", "ζ", "θ"}, set()),      # :271-382
+    # fit! MMCTM.jl:457-494: fitdoc! reads λ, ν (ζ, and the start points of both solves), Elnϕ (θ), μ, invΣ (objectives); update_γ! reads α; with
+    # updateΣ = false Σ / invΣ are never written and the ELBO reads them; γ / ϕ travel with the Elnϕ a caller seeds (run_mmctm.jl:126-128)
+    ("MMCTM", "fit!"): ({"α", "μ", "Σ", "invΣ", "γ", "Elnϕ", "ϕ", "λ", "ν"}, _ALL),
+    ("IMMCTM", "fit!"): ({"α", "μ", "Σ", "invΣ", "γ", "Elnϕ", "λ", "ν"}, _ALL),      # IMMCTM.jl:437-466
+}
+_STRUCT_FIELDS = {"LDA": {"α", "η", "λ", "Elnβ", "β", "γ", "Elnθ", "θ", "ϕ"},
+                  "MMCTM": {"α", "μ", "Σ", "invΣ", "γ", "Elnϕ", "ϕ", "λ", "ν", "ζ", "props", "θ"},
+                  "IMMCTM": {"α", "μ", "Σ", "invΣ", "γ", "Elnϕ", "λ", "ν", "ζ", "θ"}}
+
+
+def _sym_tuple(text):
+    return set(re.findall(r":(" + _IDENT + r")", text))
+
+
+def _shim_constants():
+    txt = open(SHIM, encoding="utf-8").read()
+    out = {}
+    for name in ("LDA_ALL_FIELDS", "MMCTM_ALL_FIELDS", "IMMCTM_ALL_FIELDS"):
+        m = re.search(r"const " + name + r" = \(([^)]*)\)", txt)
+        assert m, name
+        out[name] = _sym_tuple(m.group(1))
+    m = re.search(r"const FIT_READS = \((.*?)\)\nfunction", txt, flags=re.S)
+    assert m, "FIT_READS"
+    out["FIT_READS"] = {k: _sym_tuple(v) for k, v in re.findall(r"(\w+) = \(([^)]*)\)", m.group(1))}
+    return out
+
+
+def _typed_methods(name, kind):
+    """bodies + signatures of the methods of `name` whose first argument is `model::<one of kinds>`"""
+    txt = open(SHIM, encoding="utf-8").read()
+    txt = "\n".join(re.sub(r"(?<!\")#(?![^\"]*\"\s*[,)]).*$", "", ln) for ln in txt.split("\n"))
+    out = []
+    for m in re.finditer(r"(?m)^(function[ \t]+)?" + re.escape(name) + r"\(model::(\w+)", txt):
+        if m.group(2) not in kind:
+            continue
+        end = _balanced(txt, txt.index("(", m.start()))
+        if m.group(1):
+            stop = re.search(r"(?m)^end\b", txt[end:])
+            body = txt[end:end + stop.start()]
+        else:
+            body = txt[end:txt.index("\n", end)]
+        out.append((m.group(2), txt[m.start():end], body))
+    return out
+
+
+def _flow_of(body, kind, consts, methods):
+    """(uploaded, downloaded) of one method body; helpers (lda_stage!, ctm_stage!, ctm_doc_stage!, elbo_terms) are followed one level"""
+    allf = consts["LDA_ALL_FIELDS"] if kind in ("LDA", "ILDA", "TopicModel") else (
+        consts["IMMCTM_ALL_FIELDS"] if kind == "IMMCTM" else consts["MMCTM_ALL_FIELDS"])
+    first_ccall = body.find("ccall(")
+    up, down = set(), set()
+    if "upload_fit_reads!(model)" in body:
+        assert 0 <= body.index("upload_fit_reads!(model)") < first_ccall, "upload after the ccall"
+        up |= consts["FIT_READS"][kind]
+    if "upload!(model)" in body:
+        up |= allf
+    m = re.search(r"(lda_stage!|ctm_stage!)\(model, .*?, \"[^\"]*\", \(([^)]*)\)\)", body, flags=re.S)
+    if m:
+        hb = methods[m.group(1)][0][4]
+        assert hb.index("upload!(model)") < hb.index("rc_of_call()") < hb.index("download_field!"), m.group(1)
+        up |= allf; down |= _sym_tuple(m.group(2))
+    m = re.search(r"ctm_doc_stage!\(model, \d, d, \"[^\"]*\", :(" + _IDENT + r")\)", body)
+    if m:
+        hb = methods["ctm_doc_stage!"][0][4]
+        assert hb.index("upload!(model)") < hb.index("ccall(") < hb.index("download_doc!"), "ctm_doc_stage!"
+        up |= allf; down.add(m.group(1))
+    if "elbo_terms(model)" in body:
+        hb = [b for _, _, _, _, b in methods["elbo_terms"]]
+        assert all(b.index("upload!(model)") < b.index("ccall(") for b in hb)
+        up |= allf
+    if "download!(model)" in body:
+        assert body.rindex("download!(model)") > first_ccall >= 0, "download before the ccall"
+        down |= allf
+    return up, down
+
+
+def test_every_entry_point_uploads_what_the_reference_function_reads_and_downloads_what_it_writes():
+    consts = _shim_constants()
+    methods = _shim_methods()
+    assert consts["LDA_ALL_FIELDS"] == _STRUCT_FIELDS["LDA"] and consts["MMCTM_ALL_FIELDS"] == _STRUCT_FIELDS["MMCTM"] and \
+        consts["IMMCTM_ALL_FIELDS"] == _STRUCT_FIELDS["IMMCTM"]
+    bad = []
+    for (kind, name), (reads, writes) in REF_DATA_FLOW.items():
+        kinds = {"LDA": ("LDA", "TopicModel"), "ILDA": ("ILDA", "TopicModel"), "CTM": ("CTM",), "MMCTM": ("MMCTM",), "IMMCTM": ("IMMCTM",)}[kind]
+        found = _typed_methods(name, kinds)
+        if name == "fit!":
+            found = [f for f in found if f[0] == kind]
+        if not found:
+            bad.append("%s(::%s): no method" % (name, kind)); continue
+        for k, sig, body in found:
+            up, down = _flow_of(body, kind if kind != "CTM" else "MMCTM", consts, methods)
+            if not reads <= up:
+                bad.append("%s(::%s) reads %s upstream, the shim uploads only %s before its ccall" % (name, k, sorted(reads), sorted(up)))
+            w = _STRUCT_FIELDS["LDA" if kind in ("LDA", "ILDA") else ("IMMCTM" if kind == "IMMCTM" else "MMCTM")] if writes == _ALL else writes
+            if kind == "CTM":
+                w = w - {"ϕ", "props"}
+            if not w <= down:
+                bad.append("%s(::%s) writes %s upstream, the shim downloads only %s after its ccall" % (name, k, sorted(w), sorted(down)))
+    assert not bad, "\n".join(bad)
+
+
+def test_fit_uploads_nothing_it_does_not_need_and_the_seeded_restart_goes_through_it():
+    """fit! must not push ζ / θ / props (written before read: a K x nnz upload for nothing), and `seed_and_fit_restart` is the reference's
+    (scripts/run_mmctm.jl:113-134): item-assign γ[m], Elnϕ[m], ϕ[m], then fit!(tol = 1e-5) WITHOUT `resident`"""
+    consts = _shim_constants()
+    for kind in ("MMCTM", "IMMCTM"):
+        assert not consts["FIT_READS"][kind] & {"ζ", "θ", "props"}
+    assert not consts["FIT_READS"]["LDA"] & {"γ", "Elnθ", "θ", "λ", "β"}
+    methods = _shim_methods()
+    for fn in ("fit_restart", "pick_optimal_modality_models", "fit_seed_models", "seed_and_fit_restart", "pick_optimal_model", "seed_and_fit_model", "fit_model"):
+        assert fn in methods, "scripts/run_mmctm.jl's %s has no counterpart in the shim" % fn
+    body = methods["seed_and_fit_restart"][0][4]
+    for f in ("γ", "Elnϕ", "ϕ"):
+        assert re.search(r"model\." + f + r"\[m\] = deepcopy\(opt_models\[m\]\." + f + r"\[m\]\)", body), f
+    call = re.search(r"fit!\(model, ([^)]*)\)", body)
+    assert call and "tol=1e-5" in call.group(1) and "maxiter=1000" in call.group(1) and "resident" not in call.group(1)
+    assert body.index("deepcopy") < body.index("fit!(model")
+    # fit_model's positional signature is the script's (run_mmctm.jl:163)
+    assert any(npos == 8 for _, npos, _, _, _ in methods["fit_model"])
+
+
+def test_field_ids_of_upload_and_download_match_the_header():
+    """`upload_field!` / `download_field!` address every field by the id the header's enum gives it"""
+    hdr = open(HDR).read()
+    ids = {}
+    m = re.search(r"MMM_CTM_MU = 0.*?MMM_CTM_ALPHA = (\d+)", hdr, flags=re.S)
+    for name, val in re.findall(r"MMM_CTM_(\w+) = (\d+)", hdr):
+        ids[name] = int(val)
+    jl = {"μ": "MU", "Σ": "SIGMA", "invΣ": "INVSIGMA", "γ": "GAMMA", "Elnϕ": "ELNPHI", "ϕ": "PHI", "λ": "LAMBDA", "ν": "NU", "ζ": "ZETA", "props": "PROPS",
+          "θ": "THETA", "α": "ALPHA"}
+    txt = open(SHIM, encoding="utf-8").read()
+    up = txt[txt.index("function upload_field!(model::CTM"):]
+    up = up[:up.index("\nend\n")]
+    for f, cname in jl.items():
+        mm = re.search(r"f == :" + f + r"\n\s*ctm_set\(model, (\d+),", up)
+        assert mm and int(mm.group(1)) == ids[cname], "upload_field!(:%s) does not use MMM_CTM_%s = %d" % (f, cname, ids[cname])
+    dn = txt[txt.index("function download_field!(model::CTM"):]
+    dn = dn[:dn.index("\nend\n")]
+    for f, cname in jl.items():
+        if f in ("γ", "Elnϕ", "ϕ"):
+            continue                      # addressed through `id = f == :γ ? 3 : (f == :Elnϕ ? 4 : 5)`
+        mm = re.search(r"f == :" + f + r"\n(.*?)(?=elseif|else\n)", dn, flags=re.S)
+        assert mm and re.search(r"ctm_get\(model, %d," % ids[cname], mm.group(1)), "download_field!(:%s)" % f
+    assert "id = f == :γ ? %d : (f == :Elnϕ ? %d : %d)" % (ids["GAMMA"], ids["ELNPHI"], ids["PHI"]) in dn
+    lda_ids = {n: int(v) for n, v in re.findall(r"MMM_LDA_(\w+) = (\d+)", hdr)}
+    mm = re.search(r"const LDA_FIELDS = \(([^)]*)\)", txt)
+    got = {k: int(v) for k, v in re.findall(r"(" + _IDENT + r")=(\d+)", mm.group(1))}
+    assert got == {"λ": lda_ids["LAMBDA"], "Elnβ": lda_ids["ELNBETA"], "β": lda_ids["BETA"], "γ": lda_ids["GAMMA"], "Elnθ": lda_ids["ELNTHETA"], "θ": lda_ids["THETA"],
+                   "ϕ": lda_ids["PHI"]}
