@@ -403,15 +403,22 @@ def test_per_document_mma_evaluation_counts(mmm, oracle, case):
     print("%s: %d documents x 12 passes, evaluations per pass nu %d lambda %d -- all equal" % (case, D, st["n_eval_nu"], st["n_eval_lambda"]))
 
 
-@pytest.mark.parametrize("off,case,expect", [(("ctm_cpl", "ctm_packed"), "imm10", (16, 1)), (("ctm_cpl",), "imm10", (10, 1)), ((), "imm10", (2, 5)),
-                                             ((), "cfg3_shape", (16, 1)), ((), "cfg4_shape", (16, 2)), (("ctm_cpl",), "cfg4_shape", (32, 1)),
+@pytest.mark.parametrize("off,case,expect", [(("ctm_cpl", "ctm_packed"), "imm10", (16, 1)), (("ctm_cpl",), "imm10", (10, 1)), (2, "imm10", (2, 5)),
+                                             ((), "imm10", (8, 2)), (8, "imm10", (8, 2)), (16, "imm10", (10, 1)),
+                                             ((), "cfg3_shape", (16, 1)), (16, "cfg4_shape", (16, 2)), (("ctm_cpl",), "cfg4_shape", (32, 1)),
+                                             ((), "cfg4_shape", (32, 1)), (32, "cfg4_shape", (32, 1)),
                                              ((), "mm33", (6, 1)), ((), "mm66", (12, 1))])
 def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, tuning, off, case, expect):
     """The solve phase has three lane layouts: one coordinate per lane in 16/32/64-lane DPP rows (mma_group), packed groups of sum K
     lanes (6 / 10 / 12; ds_bpermute tree), and several coordinates per lane (k_ctm_solve_cpl: sum K = 10 -> 2 lanes x 5, sum K = 28 ->
-    16 lanes x 2).  Each associates the sums over a document differently; the oracle mirrors the layout the handle reports (geometry
-    Ls / cpl) and the fit must stay bit-identical in all of them.  mmm_tuning_opts.disable switches a layout off per handle."""
-    tuning(disable=off)
+    16 lanes x 2; round 5, for shards: sum K = 10 -> 8 lanes x 2, sum K = 28 -> 32 lanes x 1 in the persistent kernel).  Each associates
+    the sums over a document differently; the oracle mirrors the layout the handle reports (geometry Ls / cpl) and the fit must stay
+    bit-identical in all of them.  mmm_tuning_opts.disable switches a layout off per handle, mmm_tuning_opts.solve_lanes (an int here)
+    pins one; () = the library's choice for a corpus of this size."""
+    if isinstance(off, int):
+        tuning(solve_lanes=off)
+    else:
+        tuning(disable=off)
     if case == "imm10":
         kw = dict(D=300, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
     elif case == "mm33":
@@ -473,8 +480,8 @@ def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, tuning, imm):
     kw = dict(D=301, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3) if imm else dict(D=260, K=[7, 5], V=[96, 38], seed=66, means=[900, 120])
     D, MK = kw["D"], sum(kw["K"])
     hist = {}
-    for mode in ("0", "1"):
-        tuning(side_stream=1 if mode == "1" else -1)
+    for mode in ("0", "1", "default"):
+        tuning(side_stream={"0": -1, "1": 1, "default": 0}[mode])
         X, g, o = _pair(mmm, oracle, order="device", **kw)
         ll = np.asarray(mmm.fit(g, maxiter=9, tol=0.0, verbose=False))
         for _ in range(9):
@@ -484,7 +491,8 @@ def test_side_stream_passes_equal_stream_order_passes(mmm, oracle, tuning, imm):
         assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
         hist[mode] = (ll, g.lam_matrix().copy(), g._get("gamma").copy(), np.asarray(g.props_matrix()).copy() if hasattr(g, "props_matrix") else None)
         g.close()
-    assert np.array_equal(hist["0"][0], hist["1"][0]) and np.array_equal(hist["0"][1], hist["1"][1]) and np.array_equal(hist["0"][2], hist["1"][2])
+    for mode in ("1", "default"):
+        assert np.array_equal(hist["0"][0], hist[mode][0]) and np.array_equal(hist["0"][1], hist[mode][1]) and np.array_equal(hist["0"][2], hist[mode][2]), mode
 
 
 def test_rows_of_counts_theta_phase_is_not_taken_for_sparse_or_duplicated_rows(mmm, tuning):
