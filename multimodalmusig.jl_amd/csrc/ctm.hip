@@ -1228,7 +1228,10 @@ int mmm_ctm_doc_sums(mmm_ctm* m, int d, double* sumtheta, double* Ndivzeta)
 }
 
 // update_ζ!(model, d), update_θ!(model, d), update_ν!(model, d), update_λ!(model, d): the stage kernels process every document of the shard
-// in one launch, so the per-document form runs the stage and then puts every OTHER document's values back.
+// in one launch, so the per-document form runs the stage and then puts every OTHER document's values back -- the field AND the solver's
+// per-document evaluation counters (only document d was logically solved) -- also when the stage fails.  Cost: O(D) per call (a D-sized
+// temporary and three device copies), i.e. the reference's `for d in 1:D update_ν!(model, d) end` costs O(D^2) here: the loop belongs to
+// mmm_ctm_update_nu(m), which is that loop as ONE launch; the per-document form exists for the reference's tests (test/mmctm.jl:92-199).
 int mmm_ctm_update_doc(mmm_ctm* m, int stage, int d)
 {
     if (!m) return MMM_ERR_ARG;
@@ -1241,23 +1244,32 @@ int mmm_ctm_update_doc(mmm_ctm* m, int stage, int d)
     const int field = stage == MMM_STAGE_ZETA ? MMM_CTM_ZETA : stage == MMM_STAGE_THETA ? MMM_CTM_THETA : stage == MMM_STAGE_NU ? MMM_CTM_NU : MMM_CTM_LAMBDA;
     double* p; size_t cnt;
     if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
+    const size_t D = (size_t)m->dm.D;
+    int* nev = stage == MMM_STAGE_NU ? m->nev_nu.p + (size_t)m->sel * D : (stage == MMM_STAGE_LAMBDA ? m->nev_lam.p + (size_t)m->sel * D : nullptr);
     DevBuf<double> save;
+    DevBuf<int> save_nev;
     MMM_HIP(ctx, save.alloc(cnt));
+    if (nev) MMM_HIP(ctx, save_nev.alloc(D));
     if (cnt) MMM_HIP(ctx, hipMemcpyAsync(save.p, p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-    rc = stage == MMM_STAGE_ZETA ? mmm_ctm_update_zeta(m) : stage == MMM_STAGE_THETA ? mmm_ctm_update_theta(m) : stage == MMM_STAGE_NU ? mmm_ctm_update_nu(m)
-                                                                                                                                       : mmm_ctm_update_lambda(m);
-    if (rc) return rc;
+    if (nev) MMM_HIP(ctx, hipMemcpyAsync(save_nev.p, nev, sizeof(int) * D, hipMemcpyDeviceToDevice, ctx->stream));
+    const int rc_stage = stage == MMM_STAGE_ZETA ? mmm_ctm_update_zeta(m) : stage == MMM_STAGE_THETA ? mmm_ctm_update_theta(m)
+                         : stage == MMM_STAGE_NU ? mmm_ctm_update_nu(m) : mmm_ctm_update_lambda(m);
+    // document d's new values into the saved copy (not after a failed stage: then everything goes back as it was), the saved copy back
     if ((rc = ctm_field(m, field, &p, &cnt))) return rc;
-    if (stage == MMM_STAGE_THETA) {
-        hipLaunchKernelGGL(k_ctm_copy_doc_theta, dim3(1), dim3(256), 0, ctx->stream, m->dev(), d, p, save.p);
-        MMM_LAUNCH_CHECK(ctx);
-    } else {
-        const size_t w = stage == MMM_STAGE_ZETA ? m->dm.M : m->dm.MK;
-        MMM_HIP(ctx, hipMemcpyAsync(save.p + (size_t)d * w, p + (size_t)d * w, sizeof(double) * w, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!rc_stage) {
+        if (stage == MMM_STAGE_THETA) {
+            hipLaunchKernelGGL(k_ctm_copy_doc_theta, dim3(1), dim3(256), 0, ctx->stream, m->dev(), d, p, save.p);
+            MMM_LAUNCH_CHECK(ctx);
+        } else {
+            const size_t w = stage == MMM_STAGE_ZETA ? m->dm.M : m->dm.MK;
+            MMM_HIP(ctx, hipMemcpyAsync(save.p + (size_t)d * w, p + (size_t)d * w, sizeof(double) * w, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (nev) MMM_HIP(ctx, hipMemcpyAsync(save_nev.p + d, nev + d, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (cnt) MMM_HIP(ctx, hipMemcpyAsync(p, save.p, sizeof(double) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+    if (nev) MMM_HIP(ctx, hipMemcpyAsync(nev, save_nev.p, sizeof(int) * D, hipMemcpyDeviceToDevice, ctx->stream));
     MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return MMM_OK;
+    return rc_stage;
 }
 
 int mmm_ctm_solver_stats(mmm_ctm* m, int64_t* n_eval_nu, int64_t* n_eval_lambda, int64_t* n_capped, int* per_doc_nu, int* per_doc_lambda)

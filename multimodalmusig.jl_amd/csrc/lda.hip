@@ -787,6 +787,8 @@ extern "C" int mmm_diag_red_stamps(unsigned long long out[32])
 
 extern "C" {
 
+constexpr int kMinWavesSingle = 4;      // single-step build: fewest waves per block the library picks by itself (shard sizes: profiles/r05_lda_small_shards.txt)
+
 static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, double eta, const int64_t* doc_ptr, const int32_t* term,
                            const int32_t* count, const double* lambda0, int I, const int* J, const double* eta_i, const int32_t* features,
                            mmm_lda** out)
@@ -851,11 +853,10 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
         dense = shape && !dup && off32 && dmode != 0 && (dmode > 0 || (big && dense_enough));
         drows = drows_env && rshape && !dup && dense_enough;
     }
-    const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ncu) && ctx->tune.grid_blocks == 0 &&
-                       ctx->tune.waves_per_block == 0;
+    const bool small = !dense && (V <= 96) && KP <= 12 && ((D + 12 * G - 1) / (12 * G) <= ncu) && ctx->tune.grid_blocks == 0;
     // single-step build: just enough waves per block to cover the corpus with one block per CU (fewer co-resident waves
-    // per SIMD = shorter step)
-    const int swaves = std::max(4, std::min(12, (D + G * ncu - 1) / (G * ncu)));
+    // per SIMD = shorter step); mmm_tuning_opts.waves_per_block pins the count (more blocks than CUs are fine: two blocks share a CU)
+    const int swaves = ctx->tune.waves_per_block > 0 ? std::min(12, ctx->tune.waves_per_block) : std::max(kMinWavesSingle, std::min(12, (D + G * ncu - 1) / (G * ncu)));
     int waves = small ? swaves : 8;
     auto lds_for = [&](int w) { return tabB * (2 + w) + (size_t)2 * w * G * KP * sizeof(double); };
     while (waves > 1 && lds_for(waves) > (small ? 150 : 80) * 1024) --waves;
@@ -875,7 +876,7 @@ static int lda_create_impl(mmm_ctx* ctx, int D, int V, int K, double alpha, doub
     const size_t VK = (size_t)V * K, KD = (size_t)K * D;
     const int docs_per_block = m->waves_e * G;
     const int blocks_per_cu = wide ? 8 : std::max(1, std::min<int>((small ? 12 : 8) / m->waves_e, (int)((160 * 1024) / m->lds_e)));
-    m->single_step = !wide && small && (int64_t)m->waves_e * G * ncu >= D;
+    m->single_step = !wide && small && (int64_t)m->waves_e * G * ncu * blocks_per_cu >= D;      // the grid covers every document at once
     m->grid_e = std::max(1, std::min((D + docs_per_block - 1) / docs_per_block, ncu * blocks_per_cu));
     if (wide) m->grid_e = std::max(1, std::min((D + kWavesPerBlock - 1) / kWavesPerBlock, ncu * blocks_per_cu));     // wave per document
     if (ctx->tune.grid_blocks > 0) m->grid_e = ctx->tune.grid_blocks;

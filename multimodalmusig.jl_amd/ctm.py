@@ -455,7 +455,15 @@ def calculate_modality_loglikelihood(X, props, ϕ, features=None, ctx=None, soft
         check(lib().mmm_mixture_loglik(ctx.h, D, K, F.shape[1], doc_ptr, tp, cp, P.ravel(), F.ravel(), C.byref(v)), ctx.h, "calculate_modality_loglikelihood")
     else:
         f = np.asarray(features, dtype=np.int64)
-        J = np.ascontiguousarray(f.max(axis=0), dtype=np.int32)
+        # J from the lengths of ϕ[k][i] (what the packed layout below follows -- IMMCTM.jl:42 takes it from the feature table, and a top value
+        # that no term uses would make the two disagree): every topic the same lengths, every feature value inside them
+        I = f.shape[1]
+        J = np.ascontiguousarray([len(ϕ[0][i]) for i in range(I)], dtype=np.int32)
+        for k in range(K):
+            if len(ϕ[k]) != I or any(len(ϕ[k][i]) != J[i] for i in range(I)):
+                raise ValueError("ϕ[%d] does not hold %d feature distributions of lengths %s" % (k, I, J.tolist()))
+        if f.size and (f.min() < 1 or (f.max(axis=0) > J).any()):
+            raise ValueError("feature values outside 1..J = %s" % J.tolist())
         F = _f64(np.concatenate([np.concatenate([np.asarray(ϕ[k][i], dtype=np.float64) for i in range(f.shape[1])]) for k in range(K)]))
         check(lib().mmm_mixture_loglik_features(ctx.h, D, K, f.shape[0], f.shape[1], J, np.ascontiguousarray((f - 1).T.ravel(), dtype=np.int32), doc_ptr, tp, cp,
                                                 P.ravel(), 1 if softmax else 0, F, C.byref(v)), ctx.h, "calculate_modality_loglikelihood")
