@@ -166,6 +166,10 @@ void orc_ar_log_vec(int n, const double* x, double* out);
 void orc_ar_digamma_vec(int n, const double* x, double* out);
 void orc_ar_exptab_vec(int n, const double* x, double* out);      /* ar_exp_tab / ar_log_tab: the table-driven exp / log of the LD_MMA objectives */
 void orc_ar_logtab_vec(int n, const double* x, double* out);
+void orc_ar_digammatab_vec(int n, const double* x, double* out);  /* ar_digamma_pos_tab: the LDA dense-row prologue's digamma over the log table */
+/* debug hook: [exp min, exp max, log min, log max] of the arguments the order-matched objectives have passed to the table-driven exp / log
+ * since the last reset (tests/golden/make_table_ranges.py records them for configs 3-5) */
+void orc_twin_arg_ranges(double out[4], int reset);
 
 void orc_ctm_update_zeta(orc_ctm* m, int d);
 void orc_ctm_update_theta(orc_ctm* m, int d);

@@ -26,6 +26,26 @@
 static const double tw_exptab[MMM_EXPTAB_N] = { MMM_EXPTAB_VALUES };
 static const double tw_logtab[MMM_LOGTAB_N] = { MMM_LOGTAB_VALUES };
 
+/* debug hook (round 5): the smallest and largest argument the table-driven exp / log have been called with by the objectives since the last
+ * reset -- tests/test_twin_cpu.py sweeps both functions against mpmath over exactly the range the solves of configs 3-5 reach
+ * (tests/golden/table_argument_ranges.json).  Finite arguments only.  Not thread-safe: the restatement is sequential. */
+static double tw_arg_range[4] = { 1e300, -1e300, 1e300, -1e300 };      /* exp min, exp max, log min, log max */
+static double tw_exp_rec(double x)
+{
+    if (x == x && x - x == 0.0) { if (x < tw_arg_range[0]) tw_arg_range[0] = x; if (x > tw_arg_range[1]) tw_arg_range[1] = x; }
+    return ar_exp_tab(x, tw_exptab);
+}
+static double tw_log_rec(double x)
+{
+    if (x == x && x - x == 0.0) { if (x < tw_arg_range[2]) tw_arg_range[2] = x; if (x > tw_arg_range[3]) tw_arg_range[3] = x; }
+    return ar_log_tab(x, tw_logtab);
+}
+void orc_twin_arg_ranges(double out[4], int reset)
+{
+    for (int i = 0; i < 4; ++i) out[i] = tw_arg_range[i];
+    if (reset) { tw_arg_range[0] = 1e300; tw_arg_range[1] = -1e300; tw_arg_range[2] = 1e300; tw_arg_range[3] = -1e300; }
+}
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -139,9 +159,9 @@ static double tw_nu_eval(const tw_obj* o, const double* x, double* g)
     for (int l = 0; l < o->L; ++l) {
         if (l >= n) { t[l] = 0.0; g[l] = 0.0; continue; }
         const double Sll = o->invSigma[(size_t)l * n + l], c = o->c[l];
-        const double E = ar_exp_tab(o->other[l] + 0.5 * x[l], tw_exptab);
+        const double E = tw_exp_rec(o->other[l] + 0.5 * x[l]);
         g[l] = 0.5 * Sll + 0.5 * c * E - 1.0 / (2.0 * x[l]);
-        t[l] = 0.5 * x[l] * Sll + c * E - 0.5 * ar_log_tab(x[l], tw_logtab);
+        t[l] = 0.5 * x[l] * Sll + c * E - 0.5 * tw_log_rec(x[l]);
     }
     return tw_sum(o, t);
 }
@@ -165,7 +185,7 @@ static double tw_lam_eval(const tw_obj* o, const double* x, double* g)
         for (; j < n; ++j) s0 = fma(o->invSigma[(size_t)j * n + l], diff[j], s0);
         const double Sd = (s0 + s1) + (s2 + s3);
         const double c = o->c[l], sumth = o->sumth[l];
-        const double E = ar_exp_tab(x[l] + 0.5 * o->other[l], tw_exptab);
+        const double E = tw_exp_rec(x[l] + 0.5 * o->other[l]);
         g[l] = Sd - sumth + c * E;
         t[l] = 0.5 * diff[l] * Sd - x[l] * sumth + c * E;
     }
@@ -664,3 +684,4 @@ void orc_ar_log_vec(int n, const double* x, double* out) { for (int i = 0; i < n
 void orc_ar_digamma_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_digamma_pos(x[i]); }
 void orc_ar_exptab_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_exp_tab(x[i], tw_exptab); }
 void orc_ar_logtab_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_log_tab(x[i], tw_logtab); }
+void orc_ar_digammatab_vec(int n, const double* x, double* out) { for (int i = 0; i < n; ++i) out[i] = ar_digamma_pos_tab(x[i], tw_logtab); }

@@ -127,7 +127,8 @@ def lib():
     L.orc_twin_tables_from_Elnphi.argtypes = [P]
     L.orc_twin_infer_pass.argtypes = [P, C.c_int]; L.orc_twin_infer_pass.restype = C.c_int
     L.orc_twin_objectives.argtypes = [C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p, f64p]
-    for name in ("exp", "log", "digamma", "exptab", "logtab"):
+    L.orc_twin_arg_ranges.argtypes = [f64p, C.c_int]
+    for name in ("exp", "log", "digamma", "exptab", "logtab", "digammatab"):
         getattr(L, "orc_ar_%s_vec" % name).argtypes = [C.c_int, f64p, f64p]
     _LIB = L
     return L

@@ -203,3 +203,64 @@ def test_rows_of_counts_theta_phase_changes_only_rounding(oracle):
     np.testing.assert_allclose(res[1][2], res[0][2], rtol=1e-13, atol=1e-300)
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-12)
     assert not np.array_equal(res[1][0], res[0][0])          # ... and it IS another association
+
+
+def test_table_functions_at_every_table_boundary_and_over_the_range_the_solves_reach(oracle):
+    """The order-matched oracle shares `ar_exp_tab` / `ar_log_tab` / `ar_digamma_pos_tab` (csrc/mmm_arith.h + the generated tables) with the
+    kernels, so a wrong table entry or a reduction that breaks at an interval boundary would be common to both sides and invisible to the
+    bit-identity tests.  Held against 40-digit mpmath here, independently of either side: at EVERY boundary of the tables (the rounding
+    boundaries (k + 1/2) ln2/128 and the nodes k ln2/128 of the exp reduction; the mantissa boundaries 1 + j/128 of the log table at every
+    binary exponent in range), each with its two neighbouring doubles, and on a dense random sample -- over the argument range the LD_MMA
+    solves of BASELINE configs 3-5 really reach (tests/golden/table_argument_ranges.json, recorded by tests/golden/make_table_ranges.py through
+    the oracle's debug hook at the configurations' full sizes) widened by a margin."""
+    import json
+    import os
+    L = oracle.lib()
+    mp.mp.dps = 40
+    rg = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "table_argument_ranges.json")))
+    cfgs = [v for k, v in rg.items() if k.startswith("config")]
+    assert len(cfgs) == 3
+    e_lo = min(c["exp_min"] for c in cfgs) - 2.0; e_hi = max(c["exp_max"] for c in cfgs) + 2.0
+    l_lo = min(c["log_min"] for c in cfgs); l_hi = max(c["log_max"] for c in cfgs) * 2.0
+    assert l_lo == 1e-7          # the lower bound of the nu solve (MMCTM.jl:157) is reached
+    rng = np.random.default_rng(5)
+
+    def run(fn, xs):
+        xs = np.ascontiguousarray(xs, dtype=np.float64); out = np.empty_like(xs); fn(xs.size, xs, out); return xs, out
+
+    def three(x):
+        return [np.nextafter(x, -np.inf), x, np.nextafter(x, np.inf)]
+
+    # ---- exp
+    step = float(mp.log(2) / 128)
+    pts = []
+    for k in range(int(np.floor(e_lo / step)) - 1, int(np.ceil(e_hi / step)) + 2):
+        pts += three(float(mp.mpf(k) * mp.log(2) / 128)) + three(float((mp.mpf(k) + mp.mpf(1) / 2) * mp.log(2) / 128))
+    xs, ys = run(L.orc_ar_exptab_vec, np.concatenate([pts, rng.uniform(e_lo, e_hi, 20000), three(e_lo), three(e_hi)]))
+    worst_e = 0.0
+    for x, y in zip(xs, ys):
+        r = mp.exp(mp.mpf(float(x)))
+        worst_e = max(worst_e, float(abs(mp.mpf(float(y)) - r) / mp.mpf(float(np.spacing(float(r))))))
+    assert worst_e < 0.52, worst_e
+    # ---- log: absolute error (it enters a sum of O(10 .. 1e4)); the documented bound is 2.5e-15 for x <= 30
+    pts = []
+    for e in range(int(np.floor(np.log2(l_lo))) - 1, int(np.ceil(np.log2(l_hi))) + 2):
+        for j in range(128):
+            pts += three(float(np.ldexp(1.0 + j / 128.0, e)))
+    pts = [p for p in pts if l_lo * 0.5 <= p <= l_hi]
+    xs, ys = run(L.orc_ar_logtab_vec, np.concatenate([pts, 10.0 ** rng.uniform(np.log10(l_lo), np.log10(l_hi), 20000), three(1e-7), three(1.0), three(l_hi)]))
+    worst_l = max(float(abs(mp.mpf(float(y)) - mp.log(mp.mpf(float(x))))) for x, y in zip(xs, ys))
+    assert worst_l < 2.5e-15, worst_l
+    # ---- digamma over the log table (LDA dense-row prologue; arguments: Dirichlet parameters 0.1 .. a document's total count)
+    pts = []
+    for e in range(2, 18):
+        for j in range(128):
+            for y in three(float(np.ldexp(1.0 + j / 128.0, e))):
+                if y - 7.0 > 1e-3:
+                    pts.append(y - 7.0)
+    xs, ys = run(L.orc_ar_digammatab_vec, np.concatenate([pts, 10.0 ** rng.uniform(-1.5, 5, 5000)]))
+    xs, ys = xs[np.abs(xs - 1.4616321449683623) > 0.05], ys[np.abs(xs - 1.4616321449683623) > 0.05]
+    worst_d = max(float(abs(mp.mpf(float(y)) - mp.digamma(mp.mpf(float(x)))) / (abs(mp.digamma(mp.mpf(float(x)))) + 1)) for x, y in zip(xs, ys))
+    assert worst_d < 4e-15, worst_d
+    print("\n  table-driven functions against mpmath at every table boundary +- 1 ulp: exp %.3f ulp over [%.2f, %.2f], log abs %.2e over [%.1e, %.1f], "
+          "digamma (|err| / (|psi| + 1)) %.2e" % (worst_e, e_lo, e_hi, worst_l, l_lo, l_hi, worst_d))
