@@ -584,7 +584,7 @@ int orc_twin_gauss(orc_ctm* m, const double* mom, int do_sigma)
     for (int c = 0; c < n; ++c) {
         int p = c; double best = fabs(A[c * n + c]);
         for (int r = c + 1; r < n; ++r) { const double a = fabs(A[r * n + c]); if (a > best) { best = a; p = r; } }
-        if (!(best > 0.0)) singular = 1;
+        if (best == 0.0) singular = 1;      /* (a NaN column is not an error upstream, nor on the device: block_inverse_wide) */
         const double piv = A[p * n + c];
         for (int q = 0; q < 2; ++q) {
             double* Mx = q ? Ai : A;
