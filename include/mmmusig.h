@@ -92,7 +92,8 @@ enum { /* mmm_tuning_opts.disable: optimisations a test or an A/B run may switch
     MMM_OFF_CTM_FUSED_GAUSS = 1 << 9,   /* Gaussian M-step as its own launch instead of block 0 of the log-likelihood launch                       */
     MMM_OFF_CTM_LL_ROWS = 1 << 10,      /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
     MMM_OFF_LDA_EARLY_PROLOGUE = 1 << 11, /* single-step E-step build: every pass forms its own Elntheta / exp(Elntheta) instead of the previous pass's merged launch */
-    MMM_OFF_ALL = (1 << 12) - 1          /* every bit this build knows; mmm_ctx_set_tuning rejects others (and non-zero reserved fields) with MMM_ERR_ARG */
+    MMM_OFF_CTM_PIPE_GAUSS = 1 << 12,    /* Gaussian M-step: the three-barrier-per-column inversion instead of the pipelined one (sum K <= 32); same bits         */
+    MMM_OFF_ALL = (1 << 13) - 1          /* every bit this build knows; mmm_ctx_set_tuning rejects others (and non-zero reserved fields) with MMM_ERR_ARG */
 };
 typedef struct {
     int lda_build;        /* MMM_BUILD_*: E-step build of LDA / ILDA handles                                                              */

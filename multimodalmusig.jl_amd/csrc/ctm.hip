@@ -147,6 +147,9 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 constexpr int kSolve10Lanes8Below = 75000;      // sum K = 10: 2 lanes x 5 coordinates -> 8 lanes x 2
 constexpr int kSolve28Lanes32Below = 9000;        // sum K = 28: 16 lanes x 2 coordinates -> 32 lanes x 1
 
+// LDS of the Gaussian M-step block: the augmented matrix twice (block_inverse_pipelined, sum K <= 32) or A and its inverse (block_inverse_wide)
+inline size_t gauss_lds_doubles(int MK) { return (size_t)(MK <= 32 ? 4 : 2) * MK * MK; }
+
 size_t solve_lds(const mmm_ctm* m)
 {
     if (m->persist) {       // [MK][Ls * CPLP] padded invSigma + [waves][64 / Ls][MK + 2] difference vectors
@@ -334,7 +337,7 @@ MstepArgs mstep_args(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma
     MstepArgs a{m->dm, m->tp, m->stats.p + r0 * m->s_stats, m->Dglobal, m->mu.p + r0 * MK, m->Sigma.p + r0 * MK * MK, m->invSigma.p + r0 * MK * MK,
                 m->gamma.p + r0 * GM, m->Elnphi.p + r0 * GM, m->immctm ? nullptr : m->phi.p + r0 * GM, m->Eeff.p + r0 * GT, m->expEeff.p + r0 * GT,
                 m->phieff.p + r0 * GT, m->status.p + r0, do_mu, do_sigma, do_gamma, gamma_from_stats, m->s_stats, m->GM, sc.active, m->nalpha,
-                m->big ? m->big_scratch.p + r0 * 2 * MK * MK : nullptr};
+                m->big ? m->big_scratch.p + r0 * 2 * MK * MK : nullptr, mmm_off(m->tune, MMM_OFF_CTM_PIPE_GAUSS) ? 1 : 0};
     a.tp.alpha += r0 * m->nalpha;      // host-side copy of the argument struct: fine
     return a;
 }
@@ -344,7 +347,7 @@ int run_mstep(mmm_ctm* m, Scope sc, int do_mu, int do_sigma, int do_gamma, int g
     mmm_ctx* ctx = m->ctx;
     const size_t MK = m->dm.MK;
     const MstepArgs a = mstep_args(m, sc, do_mu, do_sigma, do_gamma, gamma_from_stats);
-    const size_t lds = m->big ? 0 : sizeof(double) * 2 * MK * MK;
+    const size_t lds = m->big ? 0 : sizeof(double) * gauss_lds_doubles((int)MK);
     if (do_mu || do_sigma) {
         if (lds > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)k_ctm_mstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_ctm_mstep, dim3(1, sc.nrep), dim3(256), lds, ctx->stream, a);
@@ -415,7 +418,7 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
     const size_t r0 = sc.rep0;
     const int gauss = (gauss_mu || gauss_sigma) ? 1 : 0;
     const size_t lds = sizeof(double) * std::max((m->wide ? (size_t)0 : (size_t)m->dm.GT) + kWavesS * 64 + 1 + MMM_LOGTAB_N,      // table | props | log table
-                                                 gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
+                                                 gauss ? gauss_lds_doubles(m->dm.MK) : (size_t)0);
     if (m->big) {      // sum K > 64: the Gaussian M-step as its own launch (device-memory inversion), then the generic props / ll sweep
         if (gauss) { int rc = run_mstep(m, sc, gauss_mu, gauss_sigma, 0, 0); if (rc) return rc; }
         hipLaunchKernelGGL(k_ctm_loglik_big, dim3(m->grid_s, sc.nrep), dim3(kBlockS), sizeof(double) * kWavesS * 64, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
@@ -425,7 +428,7 @@ int run_loglik(mmm_ctm* m, Scope sc, double* dst_dev, size_t dst_stride, bool co
         int kmx = 8, vt = 0;
         for (int i = 0; i < M; ++i) { dr.rows[i] = m->trows[i].p; dr.SL[i] = m->tSL[i]; dr.tpoff[i] = vt; vt += 16 * m->tSL[i]; kmx = std::max(kmx, theta_dense_kmx(m->dm.K[i])); }
         dr.tpoff[M] = vt;
-        const size_t ldsd = sizeof(double) * std::max((size_t)vt * kmx + (size_t)kWavesS * 4 * kmx + 2 + MMM_LOGTAB_N, gauss ? 2 * (size_t)m->dm.MK * m->dm.MK : (size_t)0);
+        const size_t ldsd = sizeof(double) * std::max((size_t)vt * kmx + (size_t)kWavesS * 4 * kmx + 2 + MMM_LOGTAB_N, gauss ? gauss_lds_doubles(m->dm.MK) : (size_t)0);
         auto go = [&](auto kern) -> int {
             if (ldsd > 48 * 1024) MMM_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd));
             hipLaunchKernelGGL(kern, dim3(m->grid_s + gauss, sc.nrep), dim3(kBlockS), ldsd, ctx->stream, m->dev(), m->lambda.p + r0 * m->sDMK(),
@@ -1328,6 +1331,13 @@ int mmm_ctm_events(mmm_ctm* m, int64_t out[4])
     for (double v : ll) if (!std::isfinite(v)) ++out[2];
     return MMM_OK;
 }
+
+#ifdef MMM_DIAG_STAMPS
+int mmm_diag_gauss_stamps(unsigned long long out[96])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gauss_stamps), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {

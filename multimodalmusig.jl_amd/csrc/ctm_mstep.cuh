@@ -225,6 +225,7 @@ struct MstepArgs {
     size_t stats_stride; int GM; const int* active;      // batched launches
     int nalpha;
     double* big_scratch;    // sum K > 64: [R][2 MK^2] doubles in device memory for the inversion (block_inverse_big); else NULL
+    int gauss_wide;         // 1: keep the three-barrier inversion (block_inverse_wide) where the pipelined one would run (MMM_OFF_CTM_PIPE_GAUSS: A/B, tests)
 };
 
 // the per-replica pointers of a batched M-step launch.  They are formed in locals (registers); the argument struct itself
@@ -245,6 +246,23 @@ __device__ __forceinline__ bool mstep_replica(const MstepArgs& a, MstepPtrs& q)
     q.alpha = a.tp.alpha + r * a.nalpha;
     return true;
 }
+
+#ifdef MMM_DIAG_STAMPS
+// diagnostic build only (make diag): s_memtime stamps of thread 0 through the Gaussian M-step -- [0] entry, [1] mu stored, [2] Sigma filled,
+// [3 + 3c .. 5 + 3c] column c: after the pivot barrier, after the scale barrier, after the eliminate barrier, [90] inverse done,
+// [91] invSigma stored; [94] / [95] s_memrealtime (100 MHz) at entry / exit
+__device__ unsigned long long g_gauss_stamps[96];
+#define MMM_GSTAMP(i)                                                                                        \
+    do {                                                                                                     \
+        unsigned long long t_;                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && (i) < 94) g_gauss_stamps[i] = t_;                        \
+    } while (0)
+#else
+#define MMM_GSTAMP(i) do { } while (0)
+#endif
 
 // in-place Gauss-Jordan inverse with partial pivoting of the n x n matrix A (LDS, row stride n) into Ainv; log|det A| in
 // *logdet.  One block of >= 2n threads, n <= 64.  (A single-wave variant -- lanes own columns, multipliers by readlane, no
@@ -286,6 +304,7 @@ __device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logde
             if (tid == 0) { s_best[c] = best; if (best == 0.0) *singular = 1; }
         }
         __syncthreads();
+        MMM_GSTAMP(3 + 3 * c);
         const int p = *s_piv;
         const double piv = s_pv[0];
         if (tid < 2 * n) {
@@ -298,6 +317,7 @@ __device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logde
             if (p != c) Mx[p * n + j] = top;
         }
         __syncthreads();
+        MMM_GSTAMP(4 + 3 * c);
         if (r0 < rstep) {
             const double ac = A[c * n + j0], ic = Ainv[c * n + j0];
             for (int r = r0; r < n; r += rstep) {
@@ -308,13 +328,94 @@ __device__ void block_inverse_wide(int n, double* A, double* Ainv, double* logde
             }
         }
         __syncthreads();
+        MMM_GSTAMP(5 + 3 * c);
     }
     if (tid < n) s_col[tid] = log(s_best[tid]);
     __syncthreads();
     if (tid == 0) { double s = 0.0; for (int c = 0; c < n; ++c) s += s_col[c]; *logdet = s; }
 }
 
-// update_μ! / update_Σ! of one replica by the calling block (>= 128 threads); smem: 2 MK^2 doubles.  BIG (sum K > 64): the matrices live
+// Round 5, n <= 32: the same elimination with ONE block barrier per column instead of three (35-45 us -> see DESIGN section 4.2 at n = 28).
+// The matrix is the augmented [A | A^-1] of n rows x W = 2n columns and is DOUBLE-BUFFERED: the sweep of column c reads buffer `cur` and
+// writes `nxt`, so nothing waits between reading the old rows and writing the new ones.  Every update thread forms the scaled pivot entry
+// of its own column itself (low / piv: the same division, no hand-off through LDS).  Wave 0 does not sweep: while the other waves
+// eliminate column c it forms column c + 1 AS THAT SWEEP LEAVES IT (same operands, same operations: the same bits) and finds its pivot
+// (largest magnitude by DPP, lowest row by ballot -- the rule above), leaving pivot row, pivot and A[c+1][c+1] in cells of the other parity.
+// Per element the operations are exactly those of block_inverse_wide (and of the order-matched CPU restatement, orc_twin_gauss).
+// Block of >= 128 threads; M0 holds the augmented matrix on entry; returns the buffer that holds it on exit (A^-1 in columns n .. 2n-1).
+__device__ const double* block_inverse_pipelined(int n, double* M0, double* M1, double* logdet, int* singular)
+{
+    __shared__ double s_best[64], s_lg[64], s_pv[2][2];
+    __shared__ int s_p[2];
+    const int tid = threadIdx.x, nt = blockDim.x, W = 2 * n;
+    const int u = tid - 64, nu = nt - 64;
+    const int j0 = u >= 0 ? u % W : 0, r0 = u >= 0 ? u / W : 0, rstep = nu / W;      // update thread -> column j0, rows r0, r0 + rstep, ...
+    if (tid == 0) *singular = 0;
+    __syncthreads();
+    if (tid < 64) {      // pivot of column 0
+        const double a = tid < n ? M0[tid * W] : 0.0;
+        const double mag = tid < n ? fabs(a) : -1.0;
+        const double best = wave_max_dpp(mag);
+        const unsigned long long eq = __ballot(mag == best);
+        const int p = eq ? (int)__builtin_ctzll(eq) : 0;        // (no lane compares equal only if the column holds NaNs)
+        if (tid == p) { s_p[0] = p; s_pv[0][0] = a; }
+        if (tid == 0) { s_pv[0][1] = a; s_best[0] = best; if (best == 0.0) *singular = 1; }
+    }
+    __syncthreads();
+    double* cur = M0; double* nxt = M1;
+    for (int c = 0; c < n; ++c) {
+        const int par = c & 1;
+        const int p = s_p[par];
+        const double piv = s_pv[par][0], acc = s_pv[par][1];      // the pivot A[p][c], and A[c][c]: the multiplier row p carries after the swap
+        // (branch-free: rows beyond n are clamped onto row n - 1 -- such a lane loads that row's operands and stores that row's value, the
+        // same bits its owner stores -- so that no load waits behind a branch: exec-masked loops had made every row its own LDS round trip)
+        if (tid < 64) {
+            const int j = c + 1 < n ? c + 1 : c, r = tid, rc = r < n ? r : n - 1;
+            const double q1 = cur[p * W + j] / piv;
+            const double xl = cur[rc * W + j], fl = cur[rc * W + c], topj = cur[c * W + j];
+            const double x = rc == p ? topj : xl, f = rc == p ? acc : fl;
+            const double v = rc == c ? q1 : x - f * q1;
+            const double mag = (r > c && r < n) ? fabs(v) : -1.0;
+            const double best = wave_max_dpp(mag);
+            const unsigned long long eq = __ballot(mag == best);
+            const int pn = eq ? (int)__builtin_ctzll(eq) : j;
+            if (c + 1 < n) {
+                if (r == pn) { s_p[par ^ 1] = pn; s_pv[par ^ 1][0] = v; }
+                if (r == j) s_pv[par ^ 1][1] = v;
+                if (r == 0) { s_best[j] = best; if (best == 0.0) *singular = 1; }
+            }
+        } else if (r0 < rstep) {
+            constexpr int MAXR = 11;                                // rows per thread: ceil(32 / 3)
+            double xr[MAXR], fr[MAXR];
+            int rr[MAXR];
+            const double low = cur[p * W + j0], top = cur[c * W + j0];
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const int r = r0 + i * rstep;
+                rr[i] = r < n ? r : n - 1;
+                xr[i] = cur[rr[i] * W + j0];
+                fr[i] = cur[rr[i] * W + c];
+            }
+            const double q = low / piv;
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const double x = rr[i] == p ? top : xr[i];
+                const double f = rr[i] == p ? acc : fr[i];
+                const double e = j0 == c ? 0.0 : x - f * q;
+                nxt[rr[i] * W + j0] = rr[i] == c ? q : e;
+            }
+        }
+        __syncthreads();
+        MMM_GSTAMP(3 + 3 * c);
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    if (tid < n) s_lg[tid] = log(s_best[tid]);
+    __syncthreads();
+    if (tid == 0) { double s = 0.0; for (int c = 0; c < n; ++c) s += s_lg[c]; *logdet = s; }
+    return cur;
+}
+
+// update_μ! / update_Σ! of one replica by the calling block (>= 128 threads); smem: 4 MK^2 doubles (sum K <= 32: block_inverse_pipelined) or 2 MK^2.  BIG (sum K > 64): the matrices live
 // in device memory -- a compile-time switch, so that the LDS build keeps LDS addressing (a run-time choice of the base pointer turned every
 // access of the inversion into a flat one: 54 -> 84 us for the Gaussian block at sum K = 28)
 template <bool BIG>
@@ -324,29 +425,63 @@ __device__ void ctm_gauss_mstep(const MstepArgs& a, const MstepPtrs& q, double* 
     const CtmDims& dm = a.dm;
     const int MK = dm.MK, tid = threadIdx.x, nt = blockDim.x;
     const double* sLam = q.stats; const double* sNu = q.stats + MK; const double* sLL = q.stats + 2 * MK;
+#ifdef MMM_DIAG_STAMPS
+    if (tid == 0 && blockIdx.y == 0) g_gauss_stamps[94] = __builtin_amdgcn_s_memrealtime();
+#endif
+    MMM_GSTAMP(0);
     // update_μ! (MMCTM.jl:200-202)
     if (a.do_mu) { for (int i = tid; i < MK; i += nt) q.mu[i] = sLam[i] / a.Dglobal; }
     __syncthreads();
+    MMM_GSTAMP(1);
     // update_Σ! (MMCTM.jl:204-212) from raw moments: (diag Σν + Σ (λ-μ)(λ-μ)') / D with the NEW μ
     if (a.do_sigma) {
+        const bool pipe = !BIG && MK <= 32 && nt >= 128 && !a.gauss_wide;      // the one-barrier-per-column inversion over the augmented, double-buffered matrix
         double* A = BIG ? a.big_scratch + (size_t)blockIdx.y * 2 * MK * MK : smem;
         double* Ai = A + MK * MK;
-        for (int e = tid; e < MK * MK; e += nt) {
-            const int i = e % MK, j = e / MK;
-            // Σ_d (λ_i-μ_i)(λ_j-μ_j) = Σλλ' - μ_i Σλ_j - μ_j Σλ_i + D μ_i μ_j
-            const double mi = q.mu[i], mj = q.mu[j];
-            double v = sLL[e] - mi * sLam[j] - mj * sLam[i] + a.Dglobal * mi * mj;
-            if (i == j) v += sNu[i];
-            v /= a.Dglobal;
-            q.Sigma[e] = v; A[i * MK + j] = v;
+        const int ld = pipe ? 2 * MK : MK;                    // row stride of A in its buffer
+        // (every operand of an entry is requested before any entry is formed, four entries per thread at a time: the loop used to pay one
+        // L2 round trip per entry after the other, 2.5 us at sum K = 28; with do_mu the thread forms mu_i = sum lambda_i / D itself -- the
+        // division update_μ! has just made -- instead of reading it back)
+        for (int e0 = tid; e0 < MK * MK; e0 += 4 * nt) {
+            double ll[4], li[4], lj[4], nui[4], mi[4], mj[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * nt < MK * MK ? e0 + k * nt : MK * MK - 1;
+                const int i = e % MK, j = e / MK;
+                ll[k] = sLL[e]; li[k] = sLam[i]; lj[k] = sLam[j]; nui[k] = sNu[i];
+                mi[k] = a.do_mu ? 0.0 : q.mu[i]; mj[k] = a.do_mu ? 0.0 : q.mu[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + k * nt;
+                const int ec = e < MK * MK ? e : MK * MK - 1;
+                const int i = ec % MK, j = ec / MK;
+                const double mui = a.do_mu ? li[k] / a.Dglobal : mi[k], muj = a.do_mu ? lj[k] / a.Dglobal : mj[k];
+                // Σ_d (λ_i-μ_i)(λ_j-μ_j) = Σλλ' - μ_i Σλ_j - μ_j Σλ_i + D μ_i μ_j
+                double v = ll[k] - mui * lj[k] - muj * li[k] + a.Dglobal * mui * muj;
+                if (i == j) v += nui[k];
+                v /= a.Dglobal;
+                if (e < MK * MK) {
+                    q.Sigma[e] = v; A[i * ld + j] = v;
+                    if (pipe) A[i * ld + MK + j] = i == j ? 1.0 : 0.0;
+                }
+            }
         }
         __syncthreads();
+        const double* R = Ai; int ldr = MK, offr = 0;
+        MMM_GSTAMP(2);
         if constexpr (BIG) block_inverse_big(MK, A, Ai, &s_logdet, &s_sing);
+        else if (pipe) { R = block_inverse_pipelined(MK, A, A + 2 * MK * MK, &s_logdet, &s_sing); ldr = 2 * MK; offr = MK; }
         else block_inverse(MK, A, Ai, &s_logdet, &s_sing, &s_piv);
         __syncthreads();
-        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; q.invSigma[e] = Ai[i * MK + j]; }
+        MMM_GSTAMP(90);
+        for (int e = tid; e < MK * MK; e += nt) { const int i = e % MK, j = e / MK; q.invSigma[e] = R[i * ldr + offr + j]; }
         if (tid == 0 && s_sing) *q.status = 1;
         __syncthreads();
+        MMM_GSTAMP(91);
+#ifdef MMM_DIAG_STAMPS
+        if (tid == 0 && blockIdx.y == 0) g_gauss_stamps[95] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 
@@ -573,6 +708,8 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik(CtmDev c, const double* 
     const int ndoc_blocks = gauss ? gridDim.x - 1 : gridDim.x;
     if (gauss && blockIdx.x == 0) {      // block 0: dispatched first, so the serial inversion starts with the sweep, not after it
         MstepPtrs q;
+        // the inversion is one dependent chain beside a sweep that is bound by vector issue: its waves go first at every arbitration
+        __builtin_amdgcn_s_setprio(3);
         if (mstep_replica(ga, q)) ctm_gauss_mstep<false>(ga, q, smem);
         return;
     }
@@ -652,6 +789,8 @@ __global__ __launch_bounds__(kBlockS) void k_ctm_loglik_dense(CtmDev c, const do
     const int ndoc_blocks = gauss ? gridDim.x - 1 : gridDim.x;
     if (gauss && blockIdx.x == 0) {      // block 0: update_μ! / update_Σ! of the same pass beside the sweep (see k_ctm_loglik)
         MstepPtrs q;
+        // the inversion is one dependent chain beside a sweep that is bound by vector issue: its waves go first at every arbitration
+        __builtin_amdgcn_s_setprio(3);
         if (mstep_replica(ga, q)) ctm_gauss_mstep<false>(ga, q, smem);
         return;
     }
