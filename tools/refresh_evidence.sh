@@ -45,6 +45,9 @@ python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $E/bench_cfg2_steps20
 : > $E/lda_scaling.jsonl
 for D in 10000 40000 160000 640000; do python3 bench.py --docs $D --no-cpu-baseline >> $E/lda_scaling.jsonl 2> /dev/null; done
 python3 bench.py --docs 640000 --no-cpu-baseline --lda-build sparse > $E/lda_640k_csr.json 2> /dev/null
+echo "== shard sizes (what one GPU of an N-GPU strong run holds) and the solve layouts at those sizes"
+python3 tools/shard_sizes.py > $E/shard_sizes.jsonl 2> $E/shard_sizes.err; echo "shard sizes done"
+python3 tools/solve_layouts.py > $E/solve_layouts.jsonl 2> $E/solve_layouts.err; echo "solve layouts done"
 echo "== kernel summaries"
 cd /tmp && export TMPDIR=/tmp
 for c in 2 4 5; do
