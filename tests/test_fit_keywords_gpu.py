@@ -198,3 +198,49 @@ def test_lda_nonfinite_loglikelihood_is_counted_and_hyperparameters_are_fields(m
     ll = mmm.fit(g, maxiter=14, tol=1e-4, verbose=False)
     assert len(ll) == 14 and not g.converged and np.isnan(ll).all()
     assert g.events()["n_nonfinite_ll"] == 14
+
+
+def test_tuning_rejects_what_this_build_does_not_know(mmm):
+    """mmm_ctx_set_tuning: unknown `disable` bits, non-zero reserved fields and lane counts without a build are MMM_ERR_ARG -- a caller built
+    against a newer header must not have its choices dropped in silence (advisor, round 4)."""
+    import ctypes as C
+    ctx = mmm.default_context()
+    lib = mmm.lib()
+
+    def rc_of(**kw):
+        t = mmm._lib.TuningOpts()
+        for k, v in kw.items():
+            if k == "reserved0":
+                t.reserved[0] = v
+            else:
+                setattr(t, k, v)
+        return lib.mmm_ctx_set_tuning(ctx.h, C.byref(t))
+    try:
+        assert rc_of() == 0 and rc_of(disable=1 << 3) == 0 and rc_of(solve_lanes=8) == 0 and rc_of(solve_waves=2) == 0
+        assert rc_of(disable=1 << 20) == -1 and b"unknown bits" in lib.mmm_last_error(ctx.h)
+        assert rc_of(reserved0=7) == -1 and b"reserved" in lib.mmm_last_error(ctx.h)
+        assert rc_of(solve_lanes=3) == -1 and rc_of(solve_waves=9) == -1 and rc_of(lda_build=9) == -1
+        assert ctx.get_tuning().solve_waves == 2          # a rejected call leaves the last good options in place
+    finally:
+        ctx.set_tuning()
+
+
+def test_per_document_update_leaves_the_other_documents_and_their_counters_alone(mmm):
+    """`update_ν!(model, d)` / `update_λ!(model, d)` (MMCTM.jl:127-170): only document d changes -- its ν / λ and ITS evaluation counter; the
+    other documents keep values and counters of the last whole-corpus stage (advisor, round 4)."""
+    kw = _fit_case("mm")
+    X, g0 = np_ref.synth_mm(kw["D"], kw["V"], kw["K"], seed=kw["seed"], means=kw["means"], empty_frac=0.1)
+    g = mmm.MMCTM(kw["K"], [0.1, 0.1], kw["V"], X, γ0=g0)
+    mmm._lib.check(mmm.lib().mmm_ctm_iterate(g._h, 2, 1), g.ctx.h, "iterate")
+    mmm.update_ζ(g); mmm.update_ν(g)
+    before = g.solver_stats(per_doc=True)
+    nu0, lam0 = g.nu_matrix().copy(), g.lam_matrix().copy()
+    d = 11
+    g.ν[d] = g.ν[d] * 3.0                       # move document d away from its optimum: its solve has work to do
+    mmm.update_ν(g, d)
+    after = g.solver_stats(per_doc=True)
+    keep = np.arange(kw["D"]) != d
+    assert np.array_equal(after["per_doc_nu"][keep], before["per_doc_nu"][keep]) and np.array_equal(after["per_doc_lambda"], before["per_doc_lambda"])
+    assert np.array_equal(g.nu_matrix()[keep], nu0[keep]) and np.array_equal(g.lam_matrix(), lam0)
+    np.testing.assert_allclose(g.nu_matrix()[d], nu0[d], rtol=2e-3)      # ... and document d is solved again (to the solver's tolerance)
+    assert after["per_doc_nu"][d] > 1
