@@ -171,9 +171,10 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
             xc[q] = x[q];
             if (dc.on[q]) {
                 const double sigma2 = sigma[q] * sigma[q];
-                const double v = fabs(grad[q]) * sigma[q] + 0.5 * rho;
-                const double qq = dev_div(grad[q] * sigma[q], v);             // see mma_group (ctm.hip): one quotient for u / (v sigma) and u / v
-                double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
+                const double ags = fabs(grad[q]) * sigma[q];
+                const double v = ags + 0.5 * rho;
+                const double gs2 = grad[q] * sigma2;
+                double dx = dev_div(-gs2, v + dev_sqrt_pos(rho * (ags + 0.25 * rho)));      // see mma_group (ctm_estep.cuh): NLopt's step with one quotient
                 double c = x[q] + dx;
                 if (has_lb) c = dev_max_raw(c, lb);                  // (the clamps by v_max / v_min: see mma_group)
                 c = dev_min_raw(dev_max_raw(c, x[q] - 0.9 * sigma[q]), x[q] + 0.9 * sigma[q]);
@@ -181,12 +182,12 @@ __device__ int mma_big(const Obj& obj, const BigDoc& dc, double (&x)[kBigSlots],
                 dx = c - x[q];
                 const double dx2 = dx * dx;
                 const double denominv = dev_div(1.0, sigma2 - dx2);
-                gl += (grad[q] * (sigma2 * dx) + (fabs(grad[q]) * sigma[q] + 0.5 * rho) * dx2) * denominv;
-                wl += 0.5 * dx2 * denominv;
+                gl += (fma(v, dx, gs2) * dx) * denominv;
+                wl += dx2 * denominv;
             }
         }
         const double gval = fbest + wave_sum(gl);
-        const double wval = wave_sum(wl);
+        const double wval = 0.5 * wave_sum(wl);
         const double fcur = obj.eval(xc, gcur);
         ++nev;
         nonfin = nonfin || !isfinite(fcur);

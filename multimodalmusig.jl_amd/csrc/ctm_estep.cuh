@@ -192,13 +192,16 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
     const int cap = o.max_eval > 0 ? o.max_eval : 2000;
     while (!__all(done)) {
         // closed-form minimiser of the separable approximation (dual problem is trivial for m = 0)
-        // NLopt: u = g sigma^2, v = |g| sigma + rho/2, dx = (u/v) / (-1 - sqrt|1 - (u/(v sigma))^2|).  u/(v sigma) = (g sigma)/v =: q and u/v = q sigma:
-        // ONE correctly rounded quotient instead of three (the two forms differ by an ulp or two; the order-matched CPU checker of the
-        // parity tests follows this one, the index-order one keeps NLopt's)
+        // NLopt: u = g sigma^2, v = |g| sigma + rho/2, dx = (u/v) / (-1 - sqrt|1 - (u/(v sigma))^2|).  Multiplied through by v:
+        // dx = -u / (v + sqrt(v^2 - g^2 sigma^2)), and v^2 - g^2 sigma^2 = rho (|g| sigma + rho/4) exactly -- positive, no cancellation (NLopt's
+        // 1 - q^2 loses its digits next to a bound, where |q| -> 1): ONE correctly rounded quotient and one root instead of two quotients and a
+        // root (round 4 had three -> two).  The forms agree to rounding; the order-matched CPU checker of the parity tests follows this one,
+        // the index-order one keeps NLopt's (MMA_STEP in mmm_twin.c / orc_mma_minimize in mmm_oracle.c)
         const double sigma2 = sigma * sigma;
-        const double v = fabs(grad) * sigma + 0.5 * rho;
-        const double q = dev_div(grad * sigma, v);
-        double dx = dev_div(q * sigma, -1.0 - dev_sqrt(fabs(1.0 - q * q)));
+        const double ags = fabs(grad) * sigma;
+        const double v = ags + 0.5 * rho;
+        const double gs2 = grad * sigma2;
+        double dx = dev_div(-gs2, v + dev_sqrt_pos(rho * (ags + 0.25 * rho)));
         double xc = x + dx;
         // the three clamps by v_max / v_min (one instruction each instead of a compare and two selects): the same value as NLopt's
         // `if (xc < lb) xc = lb; ...` for every finite xc (lo <= hi; a NaN candidate, which only a non-finite objective produces, would be
@@ -209,10 +212,13 @@ __device__ int mma_group(const Obj& obj, bool act, int g, double& x, bool has_lb
         dx = xc - x;
         const double dx2 = dx * dx;
         const double denominv = dev_div(1.0, sigma2 - dx2);
-        const double gl = act ? (grad * (sigma2 * dx) + (fabs(grad) * sigma + 0.5 * rho) * dx2) * denominv : 0.0;
-        const double wl = act ? 0.5 * dx2 * denominv : 0.0;
+        // NLopt: gval += (g sigma^2 dx + v dx^2) / (sigma^2 - dx^2), wval += (dx^2 / 2) / (sigma^2 - dx^2) -- as dx (g sigma^2 + v dx) / (...)
+        // with the product g sigma^2 the step has formed already, and the factor 1/2 applied to the SUM (a power of two: the same bits)
+        const double gl = act ? (fma(v, dx, gs2) * dx) * denominv : 0.0;
+        const double wl = act ? dx2 * denominv : 0.0;
         double gsm = gl, wval = wl;
         gsum2<L, LP>(pc, gsm, wval);
+        wval *= 0.5;
         const double gval = fbest + gsm;
         const double fcur = obj.template eval<L, LP>(xc, gcur, pc);
         bool inner_done = false;
@@ -903,9 +909,10 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
 #pragma unroll
         for (int q = 0; q < CPL; ++q) {
             const double sigma2 = sigma[q] * sigma[q];
-            const double v = fabs(grad[q]) * sigma[q] + 0.5 * rho;
-            const double qq = dev_div(grad[q] * sigma[q], v);                 // = u / (v sigma) of NLopt's formula; u / v = qq sigma (see mma_group)
-            double dx = dev_div(qq * sigma[q], -1.0 - dev_sqrt(fabs(1.0 - qq * qq)));
+            const double ags = fabs(grad[q]) * sigma[q];
+            const double v = ags + 0.5 * rho;
+            const double gs2 = grad[q] * sigma2;
+            double dx = dev_div(-gs2, v + dev_sqrt_pos(rho * (ags + 0.25 * rho)));      // NLopt's step with one quotient (see mma_group)
             double c = x[q] + dx;
             if (has_lb) c = dev_max_raw(c, lb);                  // (the clamps by v_max / v_min: see mma_group)
             const double hi = x[q] + 0.9 * sigma[q], lo = x[q] - 0.9 * sigma[q];
@@ -916,13 +923,13 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
             const double dx2 = dx * dx;
             const double denominv = dev_div(1.0, sigma2 - dx2);
             // (q = 0 assigns: 0 + t = t in every bit but the sign of a zero, which no comparison below can see)
-            const double gt = (grad[q] * (sigma2 * dx) + (fabs(grad[q]) * sigma[q] + 0.5 * rho) * dx2) * denominv, wt = 0.5 * dx2 * denominv;
+            const double gt = (fma(v, dx, gs2) * dx) * denominv, wt = dx2 * denominv;      // (the 1/2 of wval: applied to the sum, see mma_group)
             gls = q == 0 ? gt : gls + gt;
             wls = q == 0 ? wt : wls + wt;
             if (SB) __builtin_amdgcn_sched_barrier(0);       // one coordinate at a time (the interleaved chains of all coordinates need more registers)
         }
         const double gval = fbest + qsum<LPD>(gls);
-        const double wval = qsum<LPD>(wls);
+        const double wval = 0.5 * qsum<LPD>(wls);
         const double fcur = obj.eval(xcur, gcur);
         nonfin = (fresh ? false : nonfin) || (have && !isfinite(fcur));
         const bool live = have && !fresh;

