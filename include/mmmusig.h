@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MMM_VERSION 122
+#define MMM_VERSION 123
 
 enum {
     MMM_OK = 0,
@@ -93,7 +93,8 @@ enum { /* mmm_tuning_opts.disable: optimisations a test or an A/B run may switch
     MMM_OFF_CTM_LL_ROWS = 1 << 10,      /* handles with rows of counts: props / log-likelihood sweep over the CSR arrays                           */
     MMM_OFF_LDA_EARLY_PROLOGUE = 1 << 11, /* single-step E-step build: every pass forms its own Elntheta / exp(Elntheta) instead of the previous pass's merged launch */
     MMM_OFF_CTM_PIPE_GAUSS = 1 << 12,    /* Gaussian M-step: the three-barrier-per-column inversion instead of the pipelined one (sum K <= 32); same bits         */
-    MMM_OFF_ALL = (1 << 13) - 1          /* every bit this build knows; mmm_ctx_set_tuning rejects others (and non-zero reserved fields) with MMM_ERR_ARG */
+    MMM_OFF_CTM_SOLVE_ORDER = 1 << 13,   /* solve phase: a wave's slots take its documents in index order instead of longest-lambda-solve-of-the-previous-pass first; same bits */
+    MMM_OFF_ALL = (1 << 14) - 1          /* every bit this build knows; mmm_ctx_set_tuning rejects others (and non-zero reserved fields) with MMM_ERR_ARG */
 };
 typedef struct {
     int lda_build;        /* MMM_BUILD_*: E-step build of LDA / ILDA handles                                                              */
@@ -298,7 +299,8 @@ int mmm_lda_events(mmm_lda* m, int64_t out[4]);
  * [1] = theta-phase blocks, [2] = waves per theta-phase block, [3] = blocks of the moment sums, [4] = 1 when the handle
  * takes the wide-table path (term-major posting sweep instead of LDS slabs), 2 when the fused pass's theta phase runs over rows of counts
  * (dense corpora: 16 lanes per document, statistics in registers), [5] = lanes per document in the solve phase (L, sum K for the packed
- * builds, or 2 / 4), [6] = coordinates per lane in the solve phase, [7] = 0.  The parity tests hand it to the
+ * builds, or 2 / 4), [6] = coordinates per lane in the solve phase, [7] = waves of the persistent solve launch (each takes a contiguous
+ * range of D / [7] documents; 0: one document group per wave step -- no bits depend on it).  The parity tests hand it to the
  * order-matched CPU restatement (oracle/mmm_twin.c), which then reproduces a whole fit bit for bit. */
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8]);
 /* Parity probe: out[i] = op(a[i], b[i]) evaluated by the device functions the kernels use (csrc/mmm_arith.h, dev_math.h).

@@ -165,7 +165,7 @@ class TuningOpts(C.Structure):
 
 BUILDS = {"auto": 0, "sparse": 1, "dense": 2, "wide": 3}
 OFF = {"lda_padded_rows": 1 << 0, "lda_count_rows": 1 << 1, "lda_rows16": 1 << 2, "lda_ll_join": 1 << 3, "lda_merged": 1 << 4, "p2p_folded": 1 << 5,
-       "ctm_packed": 1 << 6, "ctm_cpl": 1 << 7, "ctm_kfit": 1 << 8, "ctm_fused_gauss": 1 << 9, "ctm_ll_rows": 1 << 10, "lda_early_prologue": 1 << 11, "ctm_pipe_gauss": 1 << 12}
+       "ctm_packed": 1 << 6, "ctm_cpl": 1 << 7, "ctm_kfit": 1 << 8, "ctm_fused_gauss": 1 << 9, "ctm_ll_rows": 1 << 10, "lda_early_prologue": 1 << 11, "ctm_pipe_gauss": 1 << 12, "ctm_solve_order": 1 << 13}
 
 
 class Context:

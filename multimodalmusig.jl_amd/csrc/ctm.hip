@@ -35,7 +35,7 @@ constexpr int kKmax = 64;          // topics per modality (the theta loop is unr
 constexpr int kWavesS = 4;         // stage / auxiliary kernels
 constexpr int kBlockS = kWavesS * MMM_WAVE;
 
-enum { F_ZETA = 1, F_THETA_COMPUTE = 2, F_THETA_STORED = 4, F_THETA_STORE = 8, F_NU = 16, F_LAMBDA = 32, F_SLAB = 64 };
+enum { F_ZETA = 1, F_THETA_COMPUTE = 2, F_THETA_STORED = 4, F_THETA_STORE = 8, F_NU = 16, F_LAMBDA = 32, F_SLAB = 64, F_ORDER_LAM = 128 };
 
 struct CtmDims {
     int D, M, MK, GT;                    // GT = sum_m K_m V_m
@@ -316,6 +316,7 @@ int run_estep(mmm_ctm* m, Scope sc, int flags, const double* lam_in, double* lam
     }
     if (fork_after_theta) MMM_HIP(m->ctx, hipEventRecord(m->ctx->ev_fork, m->ctx->stream));
     if (flags & (F_NU | F_LAMBDA)) {
+        if (!mmm_off(m->tune, MMM_OFF_CTM_SOLVE_ORDER)) a.flags |= F_ORDER_LAM;      // the lambda solves' documents by the previous pass' evaluation counts (order_range)
         ProfSpan span(m->ctx);      // mmm_ctx_profile_*: event pair around the dominant kernel (the two LD_MMA solves)
         if ((rc = launch_phase<1>(m, a, solve_lds(m), m->grid_v, m->waves_s, sc.nrep))) return rc;
     }
@@ -1342,7 +1343,8 @@ int mmm_diag_gauss_stamps(unsigned long long out[96])
 int mmm_ctm_geometry(const mmm_ctm* m, int out[8])
 {
     if (!m || !out) return MMM_ERR_ARG;
-    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : (m->tdense ? 2 : 0); out[5] = m->Ls; out[6] = m->cpl; out[7] = 0;
+    out[0] = m->L; out[1] = m->grid_e; out[2] = m->waves_e; out[3] = m->grid_m; out[4] = m->wide ? 1 : (m->tdense ? 2 : 0); out[5] = m->Ls; out[6] = m->cpl;
+    out[7] = m->persist ? m->grid_v * m->waves_s : 0;
     return MMM_OK;
 }
 

@@ -885,13 +885,38 @@ struct LamObjC {
 // to its slowest document with the other slots idle -- 1.3-2x the mean at 32 slots); a new document's first evaluation f(x0)
 // rides in the common trip with the candidate point = x0.  Every document goes through exactly the operations of mma_group,
 // whatever its slot and its neighbours.
+// The order in which a wave's slots take the documents of its range: by the evaluation counts of the PREVIOUS pass' solve (nev_out still
+// holds them when the phase starts), longest first, ties in index order -- s_perm[p] = offset in the range of the p-th document taken.
+// In lock step a wave runs to its last solve with the other slots idle; the long solves started first leave the short ones for the end
+// (the counts of consecutive passes correlate at 0.5-0.7 for the lambda solves of config 5, not at all for the nu solves:
+// tools/sim_solve_schedule.py).  A document's solve does not depend on its slot or its neighbours: not a bit changes.  n <= 64.
+__device__ __forceinline__ void order_range(const int* prev, int r0, int n, int lane, int* s_perm)
+{
+    const int pv = lane < n ? prev[r0 + lane] : 0;
+    const int key = lane < n ? ((pv < 0 ? -pv : pv) & (MMM_NEV_NONFINITE - 1)) : -1;
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const int kj = __builtin_amdgcn_readlane(key, j);
+        rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
+    }
+    lds_wave_sync();
+    if (lane < n) s_perm[rank] = lane;
+    lds_wave_sync();
+}
+
 template <int MKT, int LPD, bool SB, class Obj>
-__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out)
+__device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0, int r1, int lane, bool has_lb, double lb, const SolveOpts& o, int* nev_out,
+                                            bool by_count, int* s_perm)
 {
     constexpr int CPL = CplGeom<MKT, LPD>::CPL, G = MMM_WAVE / LPD;
     const int g = lane / LPD, l = lane % LPD;
-    int d = r0 + g, next = r0 + G;
-    bool have = d < r1, fresh = true;
+    const int n = r1 - r0;
+    const bool ord = by_count && nev_out != nullptr && n > G && n <= MMM_WAVE;      // (n <= G: every document has a slot at once)
+    if (ord) order_range(nev_out, r0, n, lane, s_perm);
+    auto doc_at = [&](int p) { return r0 + (ord ? s_perm[p < n ? p : 0] : p); };
+    int next = G;
+    bool have = g < n, fresh = true;
+    int d = doc_at(g);
     double x[CPL], sigma[CPL], grad[CPL], gcur[CPL], xcur[CPL], xprev[CPL];
     // NLopt's sigma update looks at the SIGN of (xcur - xprev) (xprev - xprevprev).  Only the sign of the older step is kept (+1 / 0 / -1 as a
     // float): the product of two nonzero steps can neither underflow (steps are >= 1e-23 in magnitude here) nor overflow, so
@@ -993,7 +1018,7 @@ __device__ __forceinline__ void solve_range(Obj& obj, const CplDocs& dc, int r0,
             const int nd = next + __popcll(fm & ((1ull << (g * LPD)) - 1ull));
             next += __popcll(fm);
             if (finished) {
-                d = nd; have = nd < r1;
+                d = doc_at(nd); have = nd < n;
                 obj.load(dc, have ? d : -1, x);
                 rho = 1.0; k = 1; nev = 0; fresh = true;
 #pragma unroll
@@ -1027,6 +1052,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     double* sScr = sS + MK * Gm::ROW;
     double* sMu = sScr + (size_t)NW * G * (MK + 2);      // [LPD * CPL]
     __shared__ __attribute__((aligned(16))) double sTabs[MMM_EXPTAB_N + MMM_LOGTAB_N];      // exp | log tables of the objectives
+    __shared__ int sPerm[16][MMM_WAVE];      // per wave: the order of its documents (order_range)
     stage_solve_tabs(sTabs);
     {
         for (int e = tid; e < LPD * CPL; e += blockDim.x) sMu[e] = e < MK ? p_mu[e] : 0.0;
@@ -1059,7 +1085,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         for (int q = 0; q < CPL; ++q) obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0;
         obj.modpack = modpack;
         obj.l = l; obj.lane_on = lane_on; obj.tabs = sTabs;
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, false, sPerm[wid]);      // (the nu solves' counts of consecutive passes do not correlate)
     }
     // the λ solves read the ν this wave has just stored (any slot may have solved a given document's ν)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1071,6 +1097,6 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         obj.tabs = sTabs;
         obj.smu = sMu;
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
-        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam);
+        solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, false, 0.0, o, p_nev_lam, (a.flags & F_ORDER_LAM) != 0, sPerm[wid]);
     }
 }

@@ -253,7 +253,7 @@ class _CTM:
         """Launch geometry that fixes the order of the sums across documents (mmm_ctm_geometry)."""
         g = (C.c_int * 8)()
         check(lib().mmm_ctm_geometry(self._h, g), self.ctx.h, "geometry")
-        return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "grid_m": g[3], "wide": int(g[4] == 1), "tdense": int(g[4] == 2), "Ls": g[5], "cpl": g[6]}
+        return {"L": g[0], "grid_e": g[1], "waves_e": g[2], "grid_m": g[3], "wide": int(g[4] == 1), "tdense": int(g[4] == 2), "Ls": g[5], "cpl": g[6], "solve_waves": g[7]}
 
     def objectives(self, d):
         """(λ_objective value, ∇λ, ν_objective value, ∇ν) of document d at its stored λ, ν, ζ, θ (common.jl:11-36)."""

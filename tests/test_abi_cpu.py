@@ -18,7 +18,7 @@ def test_library_builds_and_exports_every_declared_symbol(mmm):
     for name in sorted(declared):
         assert hasattr(L, name), "header declares %s but the library does not export it" % name
     assert set(mmm._lib.declared_symbols()) == declared
-    assert L.mmm_version() == 122
+    assert L.mmm_version() == 123
 
 
 def test_no_cpu_fallback_without_gpu(mmm):

@@ -439,6 +439,36 @@ def test_solve_phase_layouts_bit_identical_to_oracle(mmm, oracle, tuning, off, c
         _same_state(g, o, D, MK)
 
 
+@pytest.mark.parametrize("lanes,case,D", [(2, "imm10", 1500), (16, "cfg4_shape", 900)])
+def test_solve_phase_document_order_keeps_every_bit(mmm, oracle, tuning, lanes, case, D):
+    """Round 5: the slots of a persistent solve wave take the documents of its range longest-lambda-solve-of-the-previous-pass first
+    (order_range, ctm_estep.cuh; MMM_OFF_CTM_SOLVE_ORDER: index order).  A solve does not depend on its slot: the fit with the order, the
+    fit without it and the order-matched oracle (which knows nothing of slots) agree in every bit and every evaluation count.  A
+    pretended 4-CU device, so that a wave's range holds more documents than it has slots and at most 64 (the case the order applies to)."""
+    if case == "imm10":
+        kw = dict(D=D, K=[10], V=[96], seed=61, means=[1500], imm_features=SNV3)
+    else:
+        kw = dict(_fit_case(case)); kw["D"] = D
+    MK = sum(kw["K"])
+    tuning(solve_lanes=lanes, geometry_cus=4)
+    X, g, o = _pair(mmm, oracle, order="device", **kw)
+    geo = g.geometry()
+    slots = 64 // geo["Ls"]
+    assert geo["solve_waves"] > 0 and slots < D // geo["solve_waves"] and -(-D // geo["solve_waves"]) <= 64, geo
+    tuning(solve_lanes=lanes, geometry_cus=4, disable=("ctm_solve_order",))
+    _, g0, _ = _pair(mmm, oracle, order="device", **kw)
+    assert g0.geometry() == geo
+    for it in range(5):
+        for h in (g, g0):
+            mmm._lib.check(mmm.lib().mmm_ctm_iterate(h._h, 1, 1), h.ctx.h, "iterate")
+        assert o.twin_pass(True) == 0
+        st, st0 = g.solver_stats(per_doc=True), g0.solver_stats(per_doc=True)
+        assert np.array_equal(st["per_doc_nu"], o.nev_nu[:D]) and np.array_equal(st["per_doc_lambda"], o.nev_lambda[:D])
+        assert np.array_equal(st["per_doc_lambda"], st0["per_doc_lambda"]) and np.array_equal(st["per_doc_nu"], st0["per_doc_nu"])
+        _same_state(g, o, D, MK)
+        _same_bits(g.lam_matrix(), g0.lam_matrix(), "lambda (ordered vs index order)"); _same_bits(g.nu_matrix(), g0.nu_matrix(), "nu (ordered vs index order)")
+
+
 @pytest.mark.parametrize("case", ["cfg4_shape", "cfg3_shape", "imm10", "mm16_12", "mm"])
 def test_rows_of_counts_theta_phase_bit_identical_to_oracle(mmm, oracle, tuning, case):
     """The fused pass's theta phase over rows of counts (k_ctm_theta_dense, round 3: dense corpora -- by default from 32 documents per CU,
