@@ -763,6 +763,7 @@ struct NuObjC {
     using Gm = CplGeom<MKT, LPD>;
     double lam[Gm::CPL], c[Gm::CPL], Sll[Gm::CPL];
     int modpack, l;       // the modality of coordinate q of this lane in bits [4q, 4q + 4)
+    int uni;              // wave-uniform: bit q = every lane's coordinates q and q - 1 share their modality
     bool lane_on, on;      // lane_on: the lane holds coordinates (l < ACT); on: ... of a document
     const double* tabs;    // LDS: [exp table | log table]
     // start point and constants of document d (d < 0: an empty slot).  Lanes that are not `on` keep x = 0 and contribute exact zeros.
@@ -775,8 +776,11 @@ struct NuObjC {
         for (int q = 0; q < Gm::CPL; ++q) {
             x[q] = d < 0 ? 0.0 : dc.nu[row + q];
             lam[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
+            // Ndivζ (MMCTM.jl:119-125): one quotient per modality -- where every lane's coordinate q lies in the modality of its coordinate
+            // q - 1 (`uni`, wave-uniform: always, for one modality) the quotient is taken over; dev_div = the IEEE quotient for these operands
+            if (q > 0 && ((uni >> q) & 1)) { c[q] = c[q - 1]; continue; }
             const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)];
-            c[q] = Nl / zl;                                     // Ndivζ (MMCTM.jl:119-125)
+            c[q] = dev_div(Nl, zl);
         }
     }
     __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
@@ -810,6 +814,7 @@ struct LamObjC {
     double nu[Gm::CPL], c[Gm::CPL], sumth[Gm::CPL];
     const double* smu;    // mu in LDS, [LPD * CPL] in the lane layout (0 for lanes without coordinates): CPL registers fewer than a copy per lane
     int modpack, l;       // the modality of coordinate q of this lane in bits [4q, 4q + 4)
+    int uni;              // (see NuObjC)
     bool lane_on, on;
     const double* sS;     // padded layout above
     double* scr;          // group-private LDS, MKT doubles (+ pad): the differences x - mu of the whole document
@@ -824,8 +829,9 @@ struct LamObjC {
             x[q] = d < 0 ? 0.0 : dc.lam_in[row + q];
             nu[q] = d < 0 ? 1.0 : dc.nu[row + q];
             sumth[q] = d < 0 ? 0.0 : dc.sumth[row + q];
+            if (q > 0 && ((uni >> q) & 1)) { c[q] = c[q - 1]; continue; }      // (see NuObjC::load)
             const double Nl = d < 0 ? 0.0 : dc.Ndm[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)], zl = d < 0 ? 1.0 : dc.zeta[(size_t)d * dc.M + ((modpack >> (4 * q)) & 15)];
-            c[q] = Nl / zl;
+            c[q] = dev_div(Nl, zl);
         }
     }
     __device__ __forceinline__ void store(const CplDocs& dc, int d, const double (&x)[Gm::CPL]) const
@@ -1077,13 +1083,17 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
         for (int m = 0; m < M; ++m) if (i >= dm.koff[m] && i < dm.koff[m + 1]) mm = m;
         modpack |= mm << (4 * q);
     }
+    int uni = 0;
+#pragma unroll
+    for (int q = 1; q < CPL; ++q) uni |= __all(((modpack >> (4 * q)) & 15) == ((modpack >> (4 * (q - 1))) & 15)) ? 1 << q : 0;
+    uni = __builtin_amdgcn_readfirstlane(uni);
     const SolveOpts o = a.opt;
     // ---- update_ν! (MMCTM.jl:156-170): LD_MMA, lower bound 1e-7, from the current ν, with the old λ -- for every document of the range
     if (a.flags & F_NU) {
         NuObjC<MKT, LPD, SB> obj;
 #pragma unroll
         for (int q = 0; q < CPL; ++q) obj.Sll[q] = lane_on ? p_invSigma[(size_t)(l * CPL + q) * MK + l * CPL + q] : 0.0;
-        obj.modpack = modpack;
+        obj.modpack = modpack; obj.uni = uni;
         obj.l = l; obj.lane_on = lane_on; obj.tabs = sTabs;
         solve_range<MKT, LPD, SB>(obj, dc, r0, r1, lane, true, o.nu_lower, o, p_nev_nu, false, sPerm[wid]);      // (the nu solves' counts of consecutive passes do not correlate)
     }
@@ -1093,7 +1103,7 @@ __global__ __launch_bounds__(256, OCC) void k_ctm_solve_cpl(CtmEArgs a)
     // ---- update_λ! (MMCTM.jl:127-143): LD_MMA, unbounded, with the new ν
     if (a.flags & F_LAMBDA) {
         LamObjC<MKT, LPD, SB> obj;
-        obj.modpack = modpack;
+        obj.modpack = modpack; obj.uni = uni;
         obj.tabs = sTabs;
         obj.smu = sMu;
         obj.l = l; obj.lane_on = lane_on; obj.sS = sS; obj.scr = sScr + ((size_t)wid * G + g) * (MK + 2);
