@@ -805,7 +805,9 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
         }
     }
     if (ctx->tune.grid_blocks > 0) m->grid_e = ctx->tune.grid_blocks;
-    m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ncu * 4));
+    // (one block short of four per CU: the log-likelihood launch carries the Gaussian M-step as one block more, and a 1,025th block waits for a
+    // slot -- a second round of one block: + 3.3 us at config 5, + 4.6 us at config 4)
+    m->grid_s = std::max(1, std::min((D + kWavesS - 1) / kWavesS, ncu * 4 - 1));
     m->waves_s = 4;
     // solve phase: packed document groups (sum K lanes per document) for the shapes with a build (MMM_OFF_CTM_PACKED: the 16-lane rows)
     m->Ls = m->L;
