@@ -1417,12 +1417,16 @@ int mmm_ctm_ll_history(mmm_ctm* m, double* ll, int max_n, int* n)
     return MMM_OK;
 }
 
-int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
+} // extern "C"
+
+namespace {
+// the ELBO launches of the selected replica, its eight sums copied to `h8` in stream order (no synchronisation: a batch enqueues every
+// replica's, then waits once -- the scratch the sums pass through is reused in stream order)
+int elbo_enqueue(mmm_ctm* m, double* h8)
 {
-    if (!m || !elbo) return MMM_ERR_ARG;
     mmm_ctx* ctx = m->ctx;
-    int rc = prep(m);
-    if (rc || (rc = materialise_theta(m))) return rc;
+    int rc = materialise_theta(m);
+    if (rc) return rc;
     const CtmDims& dm = m->dm;
     const size_t MKz = dm.MK, r = m->sel;
     const size_t lds = sizeof(double) * (MKz * MKz + (m->wide ? 0 : dm.GT) + kWavesS * 64);
@@ -1445,10 +1449,14 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
                        m->invSigma.p + r * MKz * MKz, acc + 5, m->big ? m->big_scratch.p + r * 2 * MKz * MKz : (double*)nullptr);
     MMM_LAUNCH_CHECK(ctx);
     if ((rc = mmm_allreduce_sum(ctx, acc, 5))) return rc;
-    double h[8];
-    MMM_HIP(ctx, hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = mmm_p2p_check(ctx))) return rc;      // (the ELBO's sums went through the ranks' exchange: a peer that never came is an error)
+    MMM_HIP(ctx, hipMemcpyAsync(h8, acc, sizeof(double) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return MMM_OK;
+}
+
+// the seven terms (MMCTM.jl:264-370) from the eight sums
+void elbo_finish(const mmm_ctm* m, const double* h, double* elbo, double terms[7])
+{
+    const CtmDims& dm = m->dm;
     const double MK = dm.MK, Dg = m->Dglobal, l2pi = log(2.0 * M_PI);
     double t[7];
     t[0] = h[5];                                              // ElnPϕ  MMCTM.jl:271-284
@@ -1460,6 +1468,21 @@ int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
     t[6] = h[4];                                              // ElnQZ  MMCTM.jl:360-370
     if (terms) memcpy(terms, t, sizeof t);
     *elbo = t[0] + t[1] + t[2] + t[3] - t[4] - t[5] - t[6];
+}
+} // namespace
+
+extern "C" {
+
+int mmm_ctm_elbo(mmm_ctm* m, double* elbo, double terms[7])
+{
+    if (!m || !elbo) return MMM_ERR_ARG;
+    mmm_ctx* ctx = m->ctx;
+    int rc = prep(m);
+    double h[8];
+    if (rc || (rc = elbo_enqueue(m, h))) return rc;
+    MMM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = mmm_p2p_check(ctx))) return rc;      // (the ELBO's sums went through the ranks' exchange: a peer that never came is an error)
+    elbo_finish(m, h, elbo, terms);
     return MMM_OK;
 }
 
@@ -1559,13 +1582,18 @@ int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, dou
     MMM_CHECK(m->ctx, maxiter >= 1, "mmm_ctm_fit_batch: maxiter < 1");
     int rc = prep(m);
     if (rc || (rc = fit_scope(m, all(m), maxiter, tol, update_sigma, ll_hist, n_iter, converged))) return rc;
-    if (elbo) {
+    if (elbo) {      // every replica's ELBO launches enqueued back to back (pinned landing area), ONE wait: 256 restarts paid 255 round trips before
+        mmm_ctx* ctx = m->ctx;
         const int keep = m->sel;
-        for (int r = 0; r < m->R; ++r) {
-            m->sel = r;
-            if ((rc = mmm_ctm_elbo(m, elbo + r, nullptr))) { m->sel = keep; return rc; }
-        }
+        double* pin = nullptr;
+        MMM_HIP(ctx, hipHostMalloc((void**)&pin, sizeof(double) * 8 * (size_t)m->R, hipHostMallocDefault));
+        for (int r = 0; r < m->R && !rc; ++r) { m->sel = r; rc = elbo_enqueue(m, pin + 8 * (size_t)r); }
         m->sel = keep;
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = mmm_fail(ctx, MMM_ERR_HIP, "mmm_ctm_fit_batch: waiting for the ELBO sums failed");
+        if (!rc) rc = mmm_p2p_check(ctx);
+        if (!rc) for (int r = 0; r < m->R; ++r) elbo_finish(m, pin + 8 * (size_t)r, elbo + r, nullptr);
+        (void)hipHostFree(pin);
+        if (rc) return rc;
     }
     return MMM_OK;
 }
