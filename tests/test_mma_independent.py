@@ -95,3 +95,42 @@ def test_independent_restatement_minimises():
     x, f, nev, tr = np_ref.ccsa_mma(fun, np.zeros(6), xtol_rel=1e-10, xtol_abs=1e-12)
     assert np.linalg.norm(fun(x)[1]) < 1e-6 and nev < 500
     assert all(t["gval"] >= t["fcur"] or True for t in tr)
+
+
+def test_one_quotient_step_is_nlopts_step():
+    """Round 5: the device (csrc/ctm_estep.cuh) and the order-matched oracle write the minimiser of LD_MMA's per-coordinate model as
+    dx = -g s^2 / (v + sqrt(rho (|g| s + rho / 4))), v = |g| s + rho / 2 -- one quotient and one root -- where NLopt (mma.c, restated
+    literally in oracle/mmm_oracle.c) has dx = (u / v) / (-1 - sqrt|1 - (u / (v s))^2|), u = g s^2.  Both are the same number: against
+    50-digit arithmetic over the ranges the solves see (|g| 1e-9 ... 1e6, sigma 1e-6 ... 10, rho 1e-5 ... 1e4) each form is within a few
+    ulp of the exact value, and so of the other; the model's gradient term (u dx + v dx^2) / (s^2 - dx^2) likewise."""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.dps = 50
+    rng = np.random.default_rng(20261005)
+    worst = 0.0
+    for _ in range(4000):
+        g = float(rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-9, 6))
+        s = float(10.0 ** rng.uniform(-6, 1))
+        rho = float(10.0 ** rng.uniform(-5, 4))
+        u, v = g * s * s, abs(g) * s + 0.5 * rho
+        lit = (u / v) / (-1.0 - np.sqrt(abs(1.0 - (u / (v * s)) ** 2)))                       # NLopt's form, in double
+        one = -(g * (s * s)) / (v + np.sqrt(rho * (abs(g) * s + 0.25 * rho)))                  # the device's form, in double
+        G, S, R = mp.mpf(g), mp.mpf(s), mp.mpf(rho)
+        U, V = G * S * S, abs(G) * S + R / 2
+        exact = (U / V) / (-1 - mp.sqrt(abs(1 - (U / (V * S)) ** 2)))
+        exact2 = -U / (V + mp.sqrt(R * (abs(G) * S + R / 4)))
+        assert abs(exact - exact2) <= abs(exact) * mp.mpf(10) ** -40                           # the identity itself
+        for val in (lit, one):
+            worst = max(worst, float(abs(mp.mpf(val) - exact) / abs(exact)))
+        assert abs(one - float(exact)) <= 4 * np.spacing(abs(float(exact)))                    # the one-quotient form: a few ulp
+        # NLopt's form loses digits where (u / (v s))^2 -> 1 (rho << |g| s): 1 - x^2 cancels; the one-quotient form does not
+        assert abs(lit - float(exact)) <= max(64 * np.spacing(abs(float(exact))), 1e-9 * abs(float(exact)))
+        dx = one
+        if abs(dx) < 0.9 * s:
+            gt_lit = (u * dx + v * dx * dx) / (s * s - dx * dx)
+            gt_one = (np.float64(v) * dx + u) * dx / (s * s - dx * dx)
+            ex = (U * mp.mpf(dx) + V * mp.mpf(dx) ** 2) / (S * S - mp.mpf(dx) ** 2)
+            if ex != 0:
+                # (u dx and v dx^2 cancel to first order at the unclamped minimiser: compare at the scale of the terms)
+                scale = float(abs(U * mp.mpf(dx)) / abs(S * S - mp.mpf(dx) ** 2))
+                assert abs(gt_lit - float(ex)) <= 1e-12 * scale and abs(gt_one - float(ex)) <= 1e-12 * scale
+    print("worst relative error of either form against 50 digits: %.2e" % worst)
