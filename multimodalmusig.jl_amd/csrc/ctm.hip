@@ -1589,7 +1589,8 @@ int mmm_ctm_fit_batch(mmm_ctm* m, int maxiter, double tol, int update_sigma, dou
         MMM_HIP(ctx, hipHostMalloc((void**)&pin, sizeof(double) * 8 * (size_t)m->R, hipHostMallocDefault));
         for (int r = 0; r < m->R && !rc; ++r) { m->sel = r; rc = elbo_enqueue(m, pin + 8 * (size_t)r); }
         m->sel = keep;
-        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = mmm_fail(ctx, MMM_ERR_HIP, "mmm_ctm_fit_batch: waiting for the ELBO sums failed");
+        // (the wait also on the way out of a failed enqueue: copies into the landing area may be in flight)
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = mmm_fail(ctx, MMM_ERR_HIP, "mmm_ctm_fit_batch: waiting for the ELBO sums failed");
         if (!rc) rc = mmm_p2p_check(ctx);
         if (!rc) for (int r = 0; r < m->R; ++r) elbo_finish(m, pin + 8 * (size_t)r, elbo + r, nullptr);
         (void)hipHostFree(pin);
