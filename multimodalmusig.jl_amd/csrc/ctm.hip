@@ -145,7 +145,8 @@ size_t estep_lds(const mmm_ctm* m, int flags)     // theta phase
 
 // shard sizes (documents, on a 256-CU device) below which the solve phase takes more lanes per document (create_impl; measured: profiles/r05_solve_layouts.jsonl)
 constexpr int kSolve10Lanes8Below = 75000;      // sum K = 10: 2 lanes x 5 coordinates -> 8 lanes x 2
-constexpr int kSolve28Lanes32Below = 9000;        // sum K = 28: 16 lanes x 2 coordinates -> 32 lanes x 1
+constexpr int kSolve28Lanes32Below = 9000;
+constexpr int kSolve28Waves4From = 40000;         // sum K = 28 as 16 x 2: three -> four persistent waves per SIMD        // sum K = 28: 16 lanes x 2 coordinates -> 32 lanes x 1
 
 // LDS of the Gaussian M-step block: the augmented matrix twice (block_inverse_pipelined, sum K <= 32) or A and its inverse (block_inverse_wide)
 inline size_t gauss_lds_doubles(int MK) { return (size_t)(MK <= 32 ? 4 : 2) * MK * MK; }
@@ -830,7 +831,10 @@ int create_impl(mmm_ctx* ctx, int R, int D, int M, const int* K, const int* V, c
                 m->persist = true;
             } else if (dm.MK == 28) {
                 const bool wide32 = want == 32 || (want == 0 && (int64_t)D * R < kSolve28Lanes32Below * (ncu / 256.0));
-                if (wide32) { m->Ls = 32; m->cpl = 1; m->lam_occ = 4; } else { m->Ls = 16; m->cpl = 2; m->lam_occ = 3; }
+                // (16 x 2 needs 125 VGPRs: four waves per SIMD fit.  With three or more documents per slot the fourth wave pays -- config 4 at
+                // 50,000 documents 0.875 -> 0.861 ms per pass; at 25,000 / 12,500 documents it costs 4 % / 8 %: tools/ab_tuning.py, solve_waves)
+                const bool four = (int64_t)D * R >= kSolve28Waves4From * (ncu / 256.0);
+                if (wide32) { m->Ls = 32; m->cpl = 1; m->lam_occ = 4; } else { m->Ls = 16; m->cpl = 2; m->lam_occ = four ? 4 : 3; }
                 m->persist = true;
             }
         }
